@@ -1,0 +1,150 @@
+/*
+ * nk2d.h -- C ABI of libnk2d.so, the MI355X (gfx950) implementation of the
+ * py_driver_2d Krylov / finite-difference-JVP hot path of
+ * klindsay28/Newton-Krylov_OOC.
+ *
+ * Every entry point replaces one piece of the reference's Python plugin surface
+ * (paths relative to the reference tree):
+ *
+ *   nk2d_create / nk2d_destroy      class-level set-up of the processes,
+ *                                   nk_ooc/py_driver_2d/model_state.py:44-65
+ *   nk2d_set_region                 region_mask / grid_weight / region mean matrix,
+ *                                   nk_ooc/model_config.py:249-315
+ *   nk2d_vec_*                      one tracer module's values (tracer, depth, ypos),
+ *                                   nk_ooc/tracer_module_state_base.py:400-440
+ *   nk2d_tend                       TracerModuleState.comp_tend + iage.comp_tend,
+ *                                   nk_ooc/py_driver_2d/tracer_module_state.py:98-108,
+ *                                   nk_ooc/py_driver_2d/iage.py:22-41
+ *   nk2d_vmix_coeff                 VertMix.mixing_coeff, py_driver_2d/vert_mix.py:44-101
+ *   nk2d_jacobian_diags             comp_jacobian (five diagonals of the CSR matrix),
+ *                                   py_driver_2d/tracer_module_state.py:262-270, iage.py:43-64
+ *   nk2d_comp_fcn                   ModelState.comp_fcn's solve_ivp("Radau") year,
+ *                                   nk_ooc/py_driver_2d/model_state.py:95-121
+ *   nk2d_precond_setup/apply        iage.apply_precond_jacobian, py_driver_2d/iage.py:66-93
+ *   nk2d_dot                        TracerModuleStateBase.dot_prod (weighted region mean),
+ *                                   nk_ooc/tracer_module_state_base.py:379-388
+ *   nk2d_axpby / nk2d_scale / nk2d_diff_scale
+ *                                   state algebra with region-broadcast scalars,
+ *                                   nk_ooc/tracer_module_state_base.py:200-369,502-515
+ *   nk2d_lin_comb                   model_state_base.lin_comb, nk_ooc/model_state_base.py:619-624
+ *   nk2d_mgs                        ModelStateBase.mod_gram_schmidt, model_state_base.py:365-377
+ *   nk2d_apply_region_mask          TracerModuleStateBase.apply_region_mask, :494-500
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Functions return 0 on
+ * success and a negative code on failure; nk2d_last_error(ctx) gives the message.
+ * The caller owns every host buffer.  Host arrays are contiguous fp64, C order
+ * (tracer, depth, ypos) for states and (depth, ypos) for planes.  A context owns
+ * one HIP stream on one device; calls on one context are not thread safe,
+ * different contexts may be driven concurrently (one per GPU / tracer module).
+ * All arithmetic is IEEE fp64.
+ */
+#ifndef NK2D_H
+#define NK2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nk2d_ctx nk2d_ctx;
+/* device-resident state vector of one tracer module (opaque device pointer) */
+typedef void* nk2d_vec;
+
+#define NK2D_MAX_TRACERS 4
+#define NK2D_SCHED_WIDTH 6 /* doubles per accepted step: t, t_new, h, n_newton, t_jac, h_lu */
+
+typedef struct nk2d_desc {
+    int32_t nz;            /* depth levels */
+    int32_t ny;            /* ypos levels */
+    int32_t tc;            /* tracers in the module (iage: 2) */
+    int32_t device_id;     /* HIP device ordinal */
+    const double* depth_edges; /* [nz+1] */
+    const double* ypos_edges;  /* [ny+1] */
+    const double* vvel;        /* [nz][ny+1]  Advection.vvel */
+    const double* wvel;        /* [nz+1][ny]  Advection.wvel */
+    const double* hmix_coeff;  /* [nz][ny-1]  HorizMix._mixing_coeff (includes 1/dy) */
+    const double* bldepth_max; /* [ny]  VertMix.bldepth's bldepth_max profile */
+    double bldepth_min;        /* 35 m */
+    double bld_tvals[4];       /* knots of the seasonal fraction, seconds */
+    double bld_fvals[4];       /* values at the knots (0,1,1,0) */
+    double vmix_log_shallow;   /* ln(10)    */
+    double vmix_log_deep;      /* ln(5e-4)  */
+    double vmix_half_width;    /* 20 m      */
+    /* module sources: tend[tr][0][:] -= surf_rate[tr]*c[tr][0][:]; tend += const_src;
+       tend -= decay_rate[tr]*c everywhere */
+    double surf_rate[NK2D_MAX_TRACERS];
+    double decay_rate[NK2D_MAX_TRACERS];
+    double const_src;
+    double t0, t1;             /* time_range, seconds */
+    double rtol, atol;         /* Radau tolerances (1e-6, 1e-6) */
+    double max_step_frac;      /* max_step = frac*(t1-t0) (0.01) */
+    double lin_tol;            /* target relative accuracy of the inner line-relaxation solves */
+} nk2d_desc;
+
+typedef struct nk2d_stats {
+    int64_t nfev, njev, nlu;       /* SciPy-compatible counters */
+    int64_t nsteps, nrejected;     /* accepted steps, rejected attempts */
+    int64_t nnewton, nsolve;       /* Newton iterations, linear solves */
+    int64_t nsweeps;               /* line-relaxation sweeps (kernel launches) */
+    int64_t nlaunch;               /* total kernel launches */
+    double seconds;                /* host wall time of the call */
+} nk2d_stats;
+
+int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out);
+void nk2d_destroy(nk2d_ctx* ctx);
+const char* nk2d_last_error(const nk2d_ctx* ctx);
+const char* nk2d_version(void);
+
+/* region_mask [nz][ny] (int32, 0 = outside), grid_weight [nz][ny]; nreg = max(mask) */
+int nk2d_set_region(nk2d_ctx* ctx, const int32_t* mask, const double* weight, int32_t nreg);
+
+int nk2d_vec_alloc(nk2d_ctx* ctx, nk2d_vec* out);
+int nk2d_vec_free(nk2d_ctx* ctx, nk2d_vec v);
+int nk2d_vec_upload(nk2d_ctx* ctx, nk2d_vec v, const double* host);   /* [tc][nz][ny] */
+int nk2d_vec_download(nk2d_ctx* ctx, nk2d_vec v, double* host);
+int nk2d_vec_copy(nk2d_ctx* ctx, nk2d_vec dst, nk2d_vec src);
+int nk2d_vec_zero(nk2d_ctx* ctx, nk2d_vec v);
+
+/* deterministic kernels */
+int nk2d_tend(nk2d_ctx* ctx, double t, nk2d_vec y, nk2d_vec f);
+int nk2d_vmix_coeff(nk2d_ctx* ctx, double t, double* host_out /* [nz-1][ny] */);
+/* diags: [5][tc][nz][ny] in the order up(k-1), south(j-1), centre, north(j+1), down(k+1) */
+int nk2d_jacobian_diags(nk2d_ctx* ctx, double t, double* host_out);
+/* solve ((mu/h) I - J(t_jac)) x = b by line relaxation; complex when mu_im != 0.
+   b_re/b_im/x_re/x_im are device vectors (b_im, x_im ignored for real systems). */
+int nk2d_shifted_solve(nk2d_ctx* ctx, double t_jac, double h, double mu_re, double mu_im,
+                       nk2d_vec b_re, nk2d_vec b_im, nk2d_vec x_re, nk2d_vec x_im,
+                       int32_t* sweeps_out);
+
+/* one forward year: fx = y(t1) - x, region-masked.
+   replay: optional schedule [replay_n][NK2D_SCHED_WIDTH] to consume (step-replay mode);
+   record: optional buffer [record_cap][NK2D_SCHED_WIDTH] receiving the accepted steps. */
+int nk2d_comp_fcn(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats,
+                  const double* replay, int64_t replay_n,
+                  double* record, int64_t record_cap, int64_t* record_n);
+
+/* preconditioner  M^-1 v = (I - prod_k (I - dt J(t_k)))^-1 v - v */
+int nk2d_precond_setup(nk2d_ctx* ctx);
+int nk2d_precond_apply(nk2d_ctx* ctx, nk2d_vec v, nk2d_vec out);
+
+/* state algebra; region scalars are host arrays [nreg], broadcast with fill 1.0 where mask<=0 */
+int nk2d_dot(nk2d_ctx* ctx, nk2d_vec a, nk2d_vec b, double* out /* [nreg] */);
+int nk2d_axpby(nk2d_ctx* ctx, nk2d_vec out, const double* a, nk2d_vec x, const double* b, nk2d_vec y);
+int nk2d_scale(nk2d_ctx* ctx, nk2d_vec out, nk2d_vec x, const double* s);
+int nk2d_diff_scale(nk2d_ctx* ctx, nk2d_vec out, nk2d_vec x, nk2d_vec y, const double* s);
+int nk2d_lin_comb(nk2d_ctx* ctx, nk2d_vec out, int32_t n, const nk2d_vec* vecs,
+                  const double* coef /* [n][nreg] */);
+/* in-place modified Gram-Schmidt of w against n basis vectors; h_out [n][nreg] */
+int nk2d_mgs(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* h_out);
+int nk2d_apply_region_mask(nk2d_ctx* ctx, nk2d_vec v);
+
+/* block until every operation queued on the context's stream has finished */
+int nk2d_sync(nk2d_ctx* ctx);
+/* the context's HIP stream (hipStream_t as void*), for event timing by the caller */
+void* nk2d_stream(nk2d_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NK2D_H */

@@ -1,0 +1,616 @@
+// nk2d_api.hip -- C ABI entry points (include/nk2d.h): context life cycle, layout
+// conversion, region-weighted state algebra (dot / axpby / lin_comb / MGS) and thin
+// wrappers over the model kernels.
+#include "nk2d_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace {
+
+template <typename T>
+int dev_alloc(nk2d_ctx* c, T** p, size_t n) {
+    NK2D_CHECK(c, hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
+    NK2D_CHECK(c, hipMemsetAsync(*p, 0, sizeof(T) * std::max<size_t>(n, 1), c->stream));
+    return 0;
+}
+
+int ensure_stage(nk2d_ctx* c, size_t n) {
+    if (n <= c->stage_elems) return 0;
+    if (c->STAGE) NK2D_CHECK(c, hipFree(c->STAGE));
+    c->STAGE = nullptr;
+    c->stage_elems = 0;
+    NK2D_CHECK(c, hipMalloc((void**)&c->STAGE, sizeof(double) * n));
+    c->stage_elems = n;
+    return 0;
+}
+
+// host row-major [nrows][ncols] -> packed device plane of ncols columns
+int upload_plane(nk2d_ctx* c, const double* host, int nrows, int ncols, double* dst, double fill = 0.0) {
+    const size_t n = (size_t)nrows * ncols;
+    NK2D_TRY(ensure_stage(c, n));
+    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_TRY(nk2d_k_pack_plane(c, c->STAGE, nrows, ncols, dst, fill));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void build_front(nk2d_ctx* c, const std::vector<double>& dzr, const std::vector<double>& dyr) {
+    const int nz = c->nz, ny = c->ny;
+    const double* v = c->d.vvel;
+    const double* w = c->d.wvel;
+    const double* kh = c->d.hmix_coeff;
+    std::vector<std::pair<double, double>> pts;  // (q, s)
+    pts.reserve((size_t)nz * ny);
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j) {
+            const double a_up = (k > 0) ? (-0.5 * w[(size_t)k * ny + j]) * dzr[k] : 0.0;
+            const double a_dn = (k < nz - 1) ? (0.5 * w[(size_t)(k + 1) * ny + j]) * dzr[k] : 0.0;
+            const double a_s = (j > 0) ? (0.5 * v[(size_t)k * (ny + 1) + j]) * dyr[j] : 0.0;
+            const double a_n = (j < ny - 1) ? (-0.5 * v[(size_t)k * (ny + 1) + j + 1]) * dyr[j] : 0.0;
+            const double h_s = (j > 0) ? kh[(size_t)k * (ny - 1) + j - 1] * dyr[j] : 0.0;
+            const double h_n = (j < ny - 1) ? kh[(size_t)k * (ny - 1) + j] * dyr[j] : 0.0;
+            const double s = std::fabs(a_s + h_s) + std::fabs(a_n + h_n);
+            const double q = (h_s + h_n) - (a_s + a_n) - 2.0 * (a_up + a_dn);
+            if (s > 0.0) pts.emplace_back(q, s);
+        }
+    std::sort(pts.begin(), pts.end());
+    c->front_q.clear();
+    c->front_s.clear();
+    double smax = -1.0;
+    for (auto& p : pts)
+        if (p.second > smax) {
+            smax = p.second;
+            c->front_q.push_back(p.first);
+            c->front_s.push_back(p.second);
+        }
+}
+
+}  // namespace
+
+extern "C" const char* nk2d_version(void) { return "nk2d 0.1 (gfx950)"; }
+
+extern "C" const char* nk2d_last_error(const nk2d_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int nk2d_sync(nk2d_ctx* c) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
+    c->d = *desc;
+    c->nz = desc->nz; c->ny = desc->ny; c->tc = desc->tc;
+    if (c->nz < 2 || c->ny < 1 || c->tc < 1 || c->tc > NK2D_MAX_TRACERS) return nk2d_fail(c, "nk2d_create: bad grid / tracer count");
+    c->E = (c->nz + 63) / 64;
+    if (c->E > NK2D_MAX_E) return nk2d_fail(c, "nk2d_create: nz > 512 levels not supported by this build");
+    c->nzp = c->E * 64;
+    c->ncol = c->tc * c->ny;
+    c->nv = (size_t)c->ncol * c->nzp;
+    c->np = (size_t)c->ny * c->nzp;
+    c->nreg = 0;
+    c->dev = desc->device_id;
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int nz = c->nz, ny = c->ny;
+    // ---- packed static planes
+    NK2D_TRY(dev_alloc(c, &c->VV, (size_t)(ny + 1) * c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->KH, (size_t)(ny + 1) * c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->WT, c->np));
+    NK2D_TRY(dev_alloc(c, &c->WB, c->np));
+    NK2D_TRY(dev_alloc(c, &c->DZR, (size_t)c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->ZM0, (size_t)c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->ZM1, (size_t)c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->DM, (size_t)c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->DMR, (size_t)c->nzp));
+    NK2D_TRY(dev_alloc(c, &c->DYR, (size_t)ny));
+    NK2D_TRY(dev_alloc(c, &c->BLDMAX, (size_t)ny));
+    NK2D_TRY(dev_alloc(c, &c->MASK, c->np));
+    NK2D_TRY(dev_alloc(c, &c->WN, c->np));
+    NK2D_TRY(dev_alloc(c, &c->JL, c->np));
+    NK2D_TRY(dev_alloc(c, &c->JU, c->np));
+    NK2D_TRY(dev_alloc(c, &c->JS, c->np));
+    NK2D_TRY(dev_alloc(c, &c->JN, c->np));
+    NK2D_TRY(dev_alloc(c, &c->JC, c->np));
+    for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->KV[i], c->np));
+    NK2D_TRY(dev_alloc(c, &c->Y, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->YOLD, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->F, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->Z, 3 * c->nv));
+    NK2D_TRY(dev_alloc(c, &c->ZP, 3 * c->nv));
+    NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
+    NK2D_TRY(dev_alloc(c, &c->BR, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->BCR, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->BCI, c->nv));
+    for (int i = 0; i < 2; ++i) {
+        NK2D_TRY(dev_alloc(c, &c->XR[i], c->nv));
+        NK2D_TRY(dev_alloc(c, &c->XCR[i], c->nv));
+        NK2D_TRY(dev_alloc(c, &c->XCI[i], c->nv));
+    }
+    NK2D_TRY(dev_alloc(c, &c->TMP, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
+    NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
+    c->rcoef_elems = 0;
+    c->RCOEF = nullptr;
+
+    // ---- axis metrics exactly as SpatialAxis derives them (spatial_axis.py:35-39)
+    std::vector<double> zmid(nz), dz(nz), dzr(nz), dzm(nz), dzmr(nz), zm1(nz), dy(ny), dyr(ny);
+    for (int k = 0; k < nz; ++k) {
+        zmid[k] = 0.5 * (desc->depth_edges[k] + desc->depth_edges[k + 1]);
+        dz[k] = desc->depth_edges[k + 1] - desc->depth_edges[k];
+        dzr[k] = 1.0 / dz[k];
+    }
+    for (int k = 0; k < nz; ++k) {
+        zm1[k] = (k < nz - 1) ? zmid[k + 1] : 0.0;
+        dzm[k] = (k < nz - 1) ? zmid[k + 1] - zmid[k] : 0.0;
+        dzmr[k] = (k < nz - 1) ? 1.0 / dzm[k] : 0.0;
+    }
+    for (int j = 0; j < ny; ++j) {
+        dy[j] = desc->ypos_edges[j + 1] - desc->ypos_edges[j];
+        dyr[j] = 1.0 / dy[j];
+    }
+    NK2D_TRY(upload_plane(c, desc->vvel, nz, ny + 1, c->VV));
+    {
+        std::vector<double> khf((size_t)nz * (ny + 1), 0.0);
+        for (int k = 0; k < nz; ++k)
+            for (int jf = 1; jf < ny; ++jf) khf[(size_t)k * (ny + 1) + jf] = desc->hmix_coeff[(size_t)k * (ny - 1) + jf - 1];
+        NK2D_TRY(upload_plane(c, khf.data(), nz, ny + 1, c->KH));
+    }
+    NK2D_TRY(upload_plane(c, desc->wvel, nz, ny, c->WT));
+    NK2D_TRY(upload_plane(c, desc->wvel + ny, nz, ny, c->WB));
+    NK2D_TRY(upload_plane(c, dzr.data(), nz, 1, c->DZR));
+    NK2D_TRY(upload_plane(c, zmid.data(), nz, 1, c->ZM0));
+    NK2D_TRY(upload_plane(c, zm1.data(), nz, 1, c->ZM1));
+    NK2D_TRY(upload_plane(c, dzm.data(), nz, 1, c->DM));
+    NK2D_TRY(upload_plane(c, dzmr.data(), nz, 1, c->DMR));
+    NK2D_CHECK(c, hipMemcpy(c->DYR, dyr.data(), sizeof(double) * ny, hipMemcpyHostToDevice));
+    NK2D_CHECK(c, hipMemcpy(c->BLDMAX, desc->bldepth_max, sizeof(double) * ny, hipMemcpyHostToDevice));
+    build_front(c, dzr, dyr);
+    // the descriptor's pointers are not kept
+    c->d.depth_edges = c->d.ypos_edges = c->d.vvel = c->d.wvel = c->d.hmix_coeff = c->d.bldepth_max = nullptr;
+    // default region: everything in region 1 with unit weights until nk2d_set_region is called
+    {
+        std::vector<int32_t> m((size_t)nz * ny, 1);
+        std::vector<double> w((size_t)nz * ny, 1.0);
+        NK2D_TRY(nk2d_set_region(c, m.data(), w.data(), 1));
+    }
+    return 0;
+}
+
+extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
+    if (!desc || !out) return -2;
+    nk2d_ctx* c = new (std::nothrow) nk2d_ctx();
+    if (!c) return -2;
+    c->stream = nullptr;
+    c->STAGE = nullptr;
+    c->stage_elems = 0;
+    c->precond = nullptr;
+    c->st = nk2d_stats();
+    *out = c;  // returned even on failure so that nk2d_last_error can be read
+    return create_impl(c, desc);
+}
+
+extern "C" void nk2d_destroy(nk2d_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->dev);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    nk2d_precond_free(c);
+    double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
+                      c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
+                      c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
+                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF};
+    for (double* b : bufs)
+        if (b) hipFree(b);
+    if (c->MASK) hipFree(c->MASK);
+    if (c->hRED) hipHostFree(c->hRED);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------
+// regions
+// ---------------------------------------------------------------------------------
+__global__ void k_to_int(const double* __restrict__ src, int32_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)src[i];
+}
+
+extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* weight, int32_t nreg) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (nreg < 1) return nk2d_fail(c, "nk2d_set_region: nreg < 1");
+    const size_t P = (size_t)c->nz * c->ny;
+    // rows of the region mean matrix: w / sum_region(w), summed in flat index order
+    // (model_config.py:292-315)
+    std::vector<double> wn(P, 0.0), mk(P, 0.0);
+    for (int r = 1; r <= nreg; ++r) {
+        double sum = 0.0;
+        for (size_t i = 0; i < P; ++i)
+            if (mask[i] == r) sum += weight[i];
+        const double sum_r = 1.0 / sum;
+        for (size_t i = 0; i < P; ++i)
+            if (mask[i] == r) wn[i] = sum_r * weight[i];
+    }
+    for (size_t i = 0; i < P; ++i) {
+        if (mask[i] > nreg) return nk2d_fail(c, "nk2d_set_region: mask value exceeds nreg");
+        mk[i] = (double)mask[i];
+    }
+    NK2D_TRY(upload_plane(c, wn.data(), c->nz, c->ny, c->WN));
+    NK2D_TRY(upload_plane(c, mk.data(), c->nz, c->ny, c->TMP));  // TMP has at least np elements
+    hipLaunchKernelGGL(k_to_int, dim3((unsigned)((c->np + 255) / 256)), dim3(256), 0, c->stream, c->TMP, c->MASK, c->np);
+    NK2D_CHECK(c, hipGetLastError());
+    if (nreg != c->nreg) {
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipFree(c->PART));
+        c->PART = nullptr;
+        NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol * nreg));
+        if (c->RCOEF) NK2D_CHECK(c, hipFree(c->RCOEF));
+        c->RCOEF = nullptr;
+        c->rcoef_elems = (size_t)nreg * 1024 + 4096;
+        NK2D_TRY(dev_alloc(c, &c->RCOEF, c->rcoef_elems));
+        if ((size_t)nreg * 2 > 4096) return nk2d_fail(c, "nk2d_set_region: too many regions");
+    }
+    c->nreg = nreg;
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// vectors
+// ---------------------------------------------------------------------------------
+extern "C" int nk2d_vec_alloc(nk2d_ctx* c, nk2d_vec* out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* p = nullptr;
+    NK2D_TRY(dev_alloc(c, &p, c->nv));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    *out = p;
+    return 0;
+}
+extern "C" int nk2d_vec_free(nk2d_ctx* c, nk2d_vec v) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    if (v) NK2D_CHECK(c, hipFree(v));
+    return 0;
+}
+extern "C" int nk2d_vec_upload(nk2d_ctx* c, nk2d_vec v, const double* host) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    const size_t n = (size_t)c->tc * c->nz * c->ny;
+    NK2D_TRY(ensure_stage(c, n));
+    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_TRY(nk2d_k_pack_state(c, c->STAGE, (double*)v));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int nk2d_vec_download(nk2d_ctx* c, nk2d_vec v, double* host) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    const size_t n = (size_t)c->tc * c->nz * c->ny;
+    NK2D_TRY(ensure_stage(c, n));
+    NK2D_TRY(nk2d_k_unpack_state(c, (const double*)v, c->STAGE));
+    NK2D_CHECK(c, hipMemcpyAsync(host, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int nk2d_vec_copy(nk2d_ctx* c, nk2d_vec dst, nk2d_vec src) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipMemcpyAsync(dst, src, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+extern "C" int nk2d_vec_zero(nk2d_ctx* c, nk2d_vec v) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipMemsetAsync(v, 0, sizeof(double) * c->nv, c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// deterministic model kernels
+// ---------------------------------------------------------------------------------
+extern "C" int nk2d_tend(nk2d_ctx* c, double t, nk2d_vec y, nk2d_vec f) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* out[1] = {c->KV[4]};
+    NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
+    NK2D_TRY(nk2d_k_tend(c, (const double*)y, c->KV[4], (double*)f));
+    return 0;
+}
+
+extern "C" int nk2d_vmix_coeff(nk2d_ctx* c, double t, double* host_out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* out[1] = {c->KV[4]};
+    NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
+    const size_t n = (size_t)(c->nz - 1) * c->ny;
+    NK2D_TRY(ensure_stage(c, n));
+    NK2D_TRY(nk2d_k_unpack_plane(c, c->KV[4], c->nz - 1, c->ny, c->STAGE));
+    NK2D_CHECK(c, hipMemcpyAsync(host_out, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nk2d_jacobian_diags(nk2d_ctx* c, double t, double* host_out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* out[1] = {c->KV[4]};
+    NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
+    const size_t P = (size_t)c->nz * c->ny;
+    NK2D_TRY(ensure_stage(c, P));
+    const double* planes[5] = {c->JL, c->JS, c->JC, c->JN, c->JU};
+    std::vector<double> tmp(P);
+    for (int d = 0; d < 5; ++d) {
+        NK2D_TRY(nk2d_k_unpack_plane(c, planes[d], c->nz, c->ny, c->STAGE));
+        NK2D_CHECK(c, hipMemcpyAsync(tmp.data(), c->STAGE, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        for (int tr = 0; tr < c->tc; ++tr) {
+            double* dst = host_out + ((size_t)d * c->tc + tr) * P;
+            std::memcpy(dst, tmp.data(), sizeof(double) * P);
+            if (d == 2) {
+                // module part of the diagonal (iage.py:55-64)
+                for (int j = 0; j < c->ny; ++j) dst[j] = dst[j] + (-c->d.surf_rate[tr]);
+                if (c->d.decay_rate[tr] != 0.0)
+                    for (size_t i = 0; i < P; ++i) dst[i] = dst[i] + (-c->d.decay_rate[tr]);
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int nk2d_shifted_solve(nk2d_ctx* c, double t_jac, double h, double mu_re, double mu_im, nk2d_vec b_re,
+                                  nk2d_vec b_im, nk2d_vec x_re, nk2d_vec x_im, int32_t* sweeps_out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* out[1] = {c->KV[4]};
+    NK2D_TRY(nk2d_k_vmix(c, 1, &t_jac, out));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
+    const bool cplxsys = mu_im != 0.0;
+    const int m = nk2d_sweeps_for(c, mu_re / h);
+    int src = 0;
+    for (int it = 0; it < m; ++it) {
+        NK2D_TRY(nk2d_k_sweep(c, !cplxsys, cplxsys, it == 0, mu_re / h, mu_re / h, mu_im / h, (const double*)b_re,
+                              (const double*)b_re, (const double*)b_im, src));
+        src = 1 - src;
+    }
+    if (!cplxsys) {
+        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XCR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(x_im, c->XCI[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    }
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    if (sweeps_out) *sweeps_out = m;
+    return 0;
+}
+
+extern "C" int nk2d_comp_fcn(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,
+                             int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (record_n) *record_n = 0;
+    return nk2d_radau_year(c, x, fx, stats, replay, replay_n, record, record_cap, record_n);
+}
+
+// ---------------------------------------------------------------------------------
+// region-weighted state algebra
+// ---------------------------------------------------------------------------------
+// value of a per-region scalar at a cell (tracer_module_state_base.py:502-515): fill 1.0
+// where the mask is <= 0
+__device__ __forceinline__ double bcast(const double* __restrict__ coef, int m) { return (m > 0) ? coef[m - 1] : 1.0; }
+
+template <int E>
+__global__ void k_dot(int ncol, int ny, int nreg, const double* __restrict__ a, const double* __restrict__ b,
+                      const double* __restrict__ wn, const int32_t* __restrict__ mask, double* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    double aa[E], bb[E], ww[E];
+    int mm[E];
+    load_col<E>(a, task, lane, aa);
+    load_col<E>(b, task, lane, bb);
+    load_col<E>(wn, j, lane, ww);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        mm[e] = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        aa[e] = ww[e] * (aa[e] * bb[e]);
+    }
+    for (int r = 1; r <= nreg; ++r) {
+        double acc = 0.0;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (mm[e] == r) { acc += aa[e]; any = true; }
+        double tot = 0.0;
+        if (__any(any)) tot = wave_sum(acc);
+        if (lane == 0) part[(size_t)task * nreg + (r - 1)] = tot;
+    }
+}
+
+// out = bcast(a) x + bcast(b) y ; products first, then the sum
+template <int E>
+__global__ void k_axpby(int ncol, int ny, const double* __restrict__ ca, const double* __restrict__ x,
+                        const double* __restrict__ cb, const double* __restrict__ y, const int32_t* __restrict__ mask,
+                        double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    double xx[E], yy[E];
+    load_col<E>(x, task, lane, xx);
+    load_col<E>(y, task, lane, yy);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int m = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        xx[e] = bcast(ca, m) * xx[e] + bcast(cb, m) * yy[e];
+    }
+    store_col<E>(out, task, lane, xx);
+}
+
+// out = bcast(s) * (x - y)   (y may be null: out = bcast(s) * x)
+template <int E>
+__global__ void k_diff_scale(int ncol, int ny, const double* __restrict__ x, const double* __restrict__ y,
+                             const double* __restrict__ cs, const int32_t* __restrict__ mask, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    double xx[E], yy[E];
+    load_col<E>(x, task, lane, xx);
+    if (y) load_col<E>(y, task, lane, yy);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int m = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        const double d = y ? (xx[e] - yy[e]) : xx[e];
+        xx[e] = d * bcast(cs, m);
+    }
+    store_col<E>(out, task, lane, xx);
+}
+
+// w -= bcast(h) * v   (one modified Gram-Schmidt projection, model_state_base.py:375-376)
+template <int E>
+__global__ void k_mgs_update(int ncol, int ny, double* __restrict__ w, const double* __restrict__ v,
+                             const double* __restrict__ h, const int32_t* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    double ww[E], vv[E];
+    load_col<E>(w, task, lane, ww);
+    load_col<E>(v, task, lane, vv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int m = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        ww[e] = ww[e] - bcast(h, m) * vv[e];
+    }
+    store_col<E>(w, task, lane, ww);
+}
+
+// res = c_0 X_0; res += c_j X_j  (model_state_base.py:619-624)
+template <int E>
+__global__ void k_lin_comb(int ncol, int ny, int n, int nreg, const double* const* __restrict__ vecs,
+                           const double* __restrict__ coef, const int32_t* __restrict__ mask, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    int mm[E];
+    double acc[E], xx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) mm[e] = mask[(size_t)j * (E * 64) + e * 64 + lane];
+    for (int i = 0; i < n; ++i) {
+        load_col<E>(vecs[i], task, lane, xx);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double t = bcast(coef + (size_t)i * nreg, mm[e]) * xx[e];
+            acc[e] = (i == 0) ? t : acc[e] + t;
+        }
+    }
+    store_col<E>(out, task, lane, acc);
+}
+
+template <int E>
+__global__ void k_mask(int ncol, int ny, double* __restrict__ v, const int32_t* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int j = task % ny;
+    double vv[E];
+    load_col<E>(v, task, lane, vv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int m = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        vv[e] = (m != 0) ? vv[e] : 0.0;
+    }
+    store_col<E>(v, task, lane, vv);
+}
+
+static int stage_coef(nk2d_ctx* c, const double* host, size_t n, size_t offset) {
+    if (offset + n > c->rcoef_elems) return nk2d_fail(c, "region coefficient staging overflow");
+    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + offset, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int launch_dot(nk2d_ctx* c, const double* a, const double* b) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_dot<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+                                               c->ny, c->nreg, a, b, c->WN, c->MASK, c->PART));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int nk2d_dot(nk2d_ctx* c, nk2d_vec a, nk2d_vec b, double* out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_TRY(launch_dot(c, (const double*)a, (const double*)b));
+    return nk2d_k_reduce(c, c->ncol, c->nreg, out);
+}
+
+extern "C" int nk2d_axpby(nk2d_ctx* c, nk2d_vec out, const double* a, nk2d_vec x, const double* b, nk2d_vec y) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_TRY(stage_coef(c, a, c->nreg, 0));
+    NK2D_TRY(stage_coef(c, b, c->nreg, c->nreg));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_axpby<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+                                               c->ny, c->RCOEF, (const double*)x, c->RCOEF + c->nreg, (const double*)y,
+                                               c->MASK, (double*)out));
+    NK2D_CHECK(c, hipGetLastError());
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));  // RCOEF is reused by the next call
+    return 0;
+}
+
+extern "C" int nk2d_scale(nk2d_ctx* c, nk2d_vec out, nk2d_vec x, const double* s) {
+    return nk2d_diff_scale(c, out, x, nullptr, s);
+}
+
+extern "C" int nk2d_diff_scale(nk2d_ctx* c, nk2d_vec out, nk2d_vec x, nk2d_vec y, const double* s) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_TRY(stage_coef(c, s, c->nreg, 0));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_diff_scale<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, c->ny, (const double*)x, (const double*)y, c->RCOEF, c->MASK,
+                                               (double*)out));
+    NK2D_CHECK(c, hipGetLastError());
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nk2d_lin_comb(nk2d_ctx* c, nk2d_vec out, int32_t n, const nk2d_vec* vecs, const double* coef) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (n < 1 || n > 512) return nk2d_fail(c, "nk2d_lin_comb: n out of range");
+    // pointers are staged behind the coefficients (8-byte slots)
+    const size_t ncoef = (size_t)n * c->nreg;
+    if (ncoef + (size_t)n > c->rcoef_elems) return nk2d_fail(c, "nk2d_lin_comb: too many vectors");
+    NK2D_TRY(stage_coef(c, coef, ncoef, 0));
+    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + ncoef, vecs, sizeof(void*) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_lin_comb<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, c->ny, n, c->nreg, (const double* const*)(c->RCOEF + ncoef),
+                                               c->RCOEF, c->MASK, (double*)out));
+    NK2D_CHECK(c, hipGetLastError());
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nk2d_mgs(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* h_out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if ((size_t)(n + 1) * c->nreg > 4096) return nk2d_fail(c, "nk2d_mgs: too many basis vectors");
+    // sequential projections; each h_i stays on the device until the end
+    for (int i = 0; i < n; ++i) {
+        NK2D_TRY(launch_dot(c, (const double*)w, (const double*)basis[i]));
+        // reduce into RED[(i+1)*nreg ...]; slot 0 is scratch of nk2d_k_reduce
+        NK2D_TRY(nk2d_k_reduce(c, c->ncol, c->nreg, nullptr));
+        NK2D_CHECK(c, hipMemcpyAsync(c->RED + (size_t)(i + 1) * c->nreg, c->RED, sizeof(double) * c->nreg,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mgs_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                                   c->ncol, c->ny, (double*)w, (const double*)basis[i],
+                                                   c->RED + (size_t)(i + 1) * c->nreg, c->MASK));
+        NK2D_CHECK(c, hipGetLastError());
+    }
+    if (n > 0) {
+        NK2D_CHECK(c, hipMemcpyAsync(c->hRED, c->RED + c->nreg, sizeof(double) * n * c->nreg, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_out, c->hRED, sizeof(double) * n * c->nreg);
+    }
+    return 0;
+}
+
+extern "C" int nk2d_apply_region_mask(nk2d_ctx* c, nk2d_vec v) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mask<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+                                               c->ny, (double*)v, c->MASK));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}

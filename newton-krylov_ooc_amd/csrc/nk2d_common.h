@@ -1,0 +1,317 @@
+// nk2d_common.h -- context, device layout and wave-level primitives shared by the
+// translation units of libnk2d.so (gfx950 only).
+//
+// Device layout ("lane-blocked columns").  A state vector of one tracer module is
+// [tc][ny] columns; a column holds the nz depth levels of one (tracer, ypos) pair and
+// is owned by ONE 64-lane wavefront.  With E = ceil(nz/64) levels per lane, level
+// k = lane*E + e is stored at
+//
+//        ((tr*ny + j)*E + e)*64 + lane
+//
+// so that (a) every load/store of a column is a fully coalesced 512-byte row per e,
+// (b) the vertical neighbours k-1 / k+1 are in the lane's own registers or one DPP
+// shuffle away, which is what the vertical-mixing stencil and the per-column
+// tridiagonal solves need, and (c) the horizontal neighbours (j-1, j+1) are the same
+// (e, lane) slot of the adjacent column.  Levels k >= nz are padding and hold 0.
+// Host arrays (C order (tracer, depth, ypos)) are converted at upload / download.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nk2d.h"
+
+#define NK2D_WAVE 64
+#define NK2D_WAVES_PER_BLOCK 4
+#define NK2D_BLOCK (NK2D_WAVE * NK2D_WAVES_PER_BLOCK)
+#define NK2D_MAX_E 8
+
+struct nk2d_ctx {
+    nk2d_desc d;
+    int nz, ny, tc, E, nzp, ncol, nreg;
+    size_t nv;  // doubles per state vector  (tc*ny*nzp)
+    size_t np;  // doubles per (depth, ypos) plane (ny*nzp)
+    int dev;
+    hipStream_t stream;
+    std::string err;
+
+    // static, packed planes (device)
+    double* VV;      // vvel at ypos faces, (ny+1) columns
+    double* KH;      // horizontal mixing coeff at ypos faces, (ny+1) columns, walls 0
+    double* WT;      // wvel at the top face of cell k,    ny columns
+    double* WB;      // wvel at the bottom face of cell k, ny columns
+    double* DZR;     // depth.delta_r           [nzp]
+    double* ZM0;     // depth.mid[k]            [nzp]
+    double* ZM1;     // depth.mid[k+1]          [nzp]
+    double* DM;      // depth.delta_mid[k]      [nzp]
+    double* DMR;     // depth.delta_mid_r[k]    [nzp]
+    double* DYR;     // ypos.delta_r            [ny]
+    double* BLDMAX;  // bldepth_max             [ny]
+    // region data
+    int32_t* MASK;   // [np]
+    double* WN;      // grid_weight / sum over region [np]
+    // Jacobian planes at t_jac (tracer independent part), np each
+    double *JL, *JU, *JS, *JN, *JC;
+    // vertical mixing planes: 3 stage times, current t, scratch
+    double* KV[5];
+    // Radau work vectors (nv each unless noted)
+    double *Y, *YOLD, *F, *Z /*3nv*/, *ZP /*3nv*/, *W /*3nv*/;
+    double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
+    // reductions
+    double* PART;    // per-task partials
+    double* RED;     // reduced scalars (device)
+    double* hRED;    // pinned host mirror
+    // staging for host <-> device layout conversion
+    double* STAGE;
+    size_t stage_elems;
+    // region scalars staged on device for the algebra kernels
+    double* RCOEF;
+    size_t rcoef_elems;
+
+    // host copies for the line-relaxation contraction bound
+    std::vector<double> front_q, front_s;
+    // preconditioner (banded LU), see nk2d_precond.hip
+    void* precond;
+
+    // counters of the running comp_fcn
+    nk2d_stats st;
+};
+
+#define NK2D_CHECK(ctx, call)                                                        \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_) + " at " + \
+                         __FILE__ + ":" + std::to_string(__LINE__);                  \
+            return -1;                                                               \
+        }                                                                            \
+    } while (0)
+
+#define NK2D_TRY(expr)            \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static inline int nk2d_fail(nk2d_ctx* c, const std::string& msg, int code = -2) {
+    c->err = msg;
+    return code;
+}
+
+static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK - 1) / NK2D_WAVES_PER_BLOCK; }
+
+// run `stmt` with a compile-time constant EE equal to the runtime levels-per-lane
+#define NK2D_DISPATCH_E(Eval, ...)                                 \
+    switch (Eval) {                                                  \
+        case 1: { constexpr int EE = 1; __VA_ARGS__; } break;               \
+        case 2: { constexpr int EE = 2; __VA_ARGS__; } break;               \
+        case 3: { constexpr int EE = 3; __VA_ARGS__; } break;               \
+        case 4: { constexpr int EE = 4; __VA_ARGS__; } break;               \
+        case 5: { constexpr int EE = 5; __VA_ARGS__; } break;               \
+        case 6: { constexpr int EE = 6; __VA_ARGS__; } break;               \
+        case 7: { constexpr int EE = 7; __VA_ARGS__; } break;               \
+        case 8: { constexpr int EE = 8; __VA_ARGS__; } break;               \
+        default: break;                                              \
+    }
+
+// ---------------------------------------------------------------------------------
+// device primitives
+// ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx c_make(double r, double i) { cplx z; z.re = r; z.im = i; return z; }
+
+// arithmetic helpers overloaded for double / cplx so the solver template serves both
+__device__ __forceinline__ double t_from_real(double a, double) { return a; }
+__device__ __forceinline__ cplx t_from_real(double a, cplx) { return c_make(a, 0.0); }
+__device__ __forceinline__ double t_zero(double) { return 0.0; }
+__device__ __forceinline__ cplx t_zero(cplx) { return c_make(0.0, 0.0); }
+__device__ __forceinline__ double t_one(double) { return 1.0; }
+__device__ __forceinline__ cplx t_one(cplx) { return c_make(1.0, 0.0); }
+
+__device__ __forceinline__ double t_neg(double a) { return -a; }
+__device__ __forceinline__ cplx t_neg(cplx a) { return c_make(-a.re, -a.im); }
+__device__ __forceinline__ double t_mul(double a, double b) { return a * b; }
+__device__ __forceinline__ cplx t_mul(cplx a, cplx b) {
+    return c_make(__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.re, b.im, a.im * b.re));
+}
+__device__ __forceinline__ double t_mulr(double a, double s) { return a * s; }
+__device__ __forceinline__ cplx t_mulr(cplx a, double s) { return c_make(a.re * s, a.im * s); }
+// a - b*c
+__device__ __forceinline__ double t_nfma(double a, double b, double c) { return __builtin_fma(-b, c, a); }
+__device__ __forceinline__ cplx t_nfma(cplx a, cplx b, cplx c) {
+    double re = __builtin_fma(-b.re, c.re, a.re);
+    re = __builtin_fma(b.im, c.im, re);
+    double im = __builtin_fma(-b.re, c.im, a.im);
+    im = __builtin_fma(-b.im, c.re, im);
+    return c_make(re, im);
+}
+// a - b*s with s real
+__device__ __forceinline__ double t_nfmar(double a, double b, double s) { return __builtin_fma(-b, s, a); }
+__device__ __forceinline__ cplx t_nfmar(cplx a, cplx b, double s) {
+    return c_make(__builtin_fma(-b.re, s, a.re), __builtin_fma(-b.im, s, a.im));
+}
+__device__ __forceinline__ double t_recip(double a) { return 1.0 / a; }
+__device__ __forceinline__ cplx t_recip(cplx a) {
+    double n = 1.0 / __builtin_fma(a.re, a.re, a.im * a.im);
+    return c_make(a.re * n, -a.im * n);
+}
+
+__device__ __forceinline__ double shfl_up_t(double v, int s) { return __shfl_up(v, s, 64); }
+__device__ __forceinline__ cplx shfl_up_t(cplx v, int s) { return c_make(__shfl_up(v.re, s, 64), __shfl_up(v.im, s, 64)); }
+__device__ __forceinline__ double shfl_down_t(double v, int s) { return __shfl_down(v, s, 64); }
+__device__ __forceinline__ cplx shfl_down_t(cplx v, int s) { return c_make(__shfl_down(v.re, s, 64), __shfl_down(v.im, s, 64)); }
+
+// sum over the 64 lanes in a fixed tree order; the total is valid in lane 0
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// value at level k-1 for every level a lane owns (fill at k = 0)
+template <int E>
+__device__ __forceinline__ void shift_prev(const double (&a)[E], double (&o)[E], int lane, double fill) {
+    double up = __shfl_up(a[E - 1], 1, 64);
+    o[0] = (lane == 0) ? fill : up;
+#pragma unroll
+    for (int e = 1; e < E; ++e) o[e] = a[e - 1];
+}
+// value at level k+1 for every level a lane owns (fill past the last lane)
+template <int E>
+__device__ __forceinline__ void shift_next(const double (&a)[E], double (&o)[E], int lane, double fill) {
+    double dn = __shfl_down(a[0], 1, 64);
+    o[E - 1] = (lane == 63) ? fill : dn;
+#pragma unroll
+    for (int e = 0; e < E - 1; ++e) o[e] = a[e + 1];
+}
+
+template <int E>
+__device__ __forceinline__ void load_col(const double* __restrict__ base, size_t col, int lane, double (&o)[E]) {
+    const double* p = base + col * (size_t)(E * 64) + lane;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = p[e * 64];
+}
+template <int E>
+__device__ __forceinline__ void store_col(double* __restrict__ base, size_t col, int lane, const double (&v)[E]) {
+    double* p = base + col * (size_t)(E * 64) + lane;
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[e * 64] = v[e];
+}
+
+// Tridiagonal solve of one column held by one wave (E consecutive rows per lane):
+//     a[i] x[i-1] + d[i] x[i] + c[i] x[i+1] = r[i]
+// a, c real; d, r real or complex.  Rows past the column end must be identity rows
+// (a = c = 0, d = 1, r = 0).  Partition method: each lane eliminates inside its block
+// of E rows (two sweeps), the 64 block-end unknowns form a tridiagonal system that is
+// solved by parallel cyclic reduction with wave shuffles, then the interior unknowns
+// follow by substitution.  No pivoting: the matrices here are strictly diagonally
+// dominant (shifted M-matrices).  On exit r holds x.
+template <int E, typename T>
+__device__ __forceinline__ void tridiag_wave(const double (&a)[E], const double (&c)[E], const T (&d)[E],
+                                             T (&r)[E], int lane) {
+    T inv[E], al[E], be[E];
+    T dlast = d[0];
+    inv[0] = t_recip(d[0]);
+    al[0] = t_from_real(a[0], T());
+#pragma unroll
+    for (int i = 1; i < E; ++i) {
+        T m = t_mulr(inv[i - 1], a[i]);
+        T dd = t_nfmar(d[i], m, c[i - 1]);
+        dlast = dd;
+        inv[i] = t_recip(dd);
+        al[i] = t_neg(t_mul(m, al[i - 1]));
+        r[i] = t_nfma(r[i], m, r[i - 1]);
+    }
+    T A, B, C, R;
+    if constexpr (E >= 2) {
+        be[E - 1] = t_zero(T());
+        be[E - 2] = t_from_real(c[E - 2], T());
+#pragma unroll
+        for (int i = E - 3; i >= 0; --i) {
+            T m = t_mulr(inv[i + 1], c[i]);
+            al[i] = t_nfma(al[i], m, al[i + 1]);
+            be[i] = t_neg(t_mul(m, be[i + 1]));
+            r[i] = t_nfma(r[i], m, r[i + 1]);
+        }
+        T n_al = shfl_down_t(al[0], 1), n_inv = shfl_down_t(inv[0], 1);
+        T n_be = shfl_down_t(be[0], 1), n_r = shfl_down_t(r[0], 1);
+        T g = t_mulr(n_inv, c[E - 1]);  // zero on the last lane and on padding rows
+        A = al[E - 1];
+        B = t_nfma(dlast, g, n_al);
+        C = t_neg(t_mul(g, n_be));
+        R = t_nfma(r[E - 1], g, n_r);
+    } else {
+        A = t_from_real(a[0], T());
+        B = d[0];
+        C = t_from_real(c[0], T());
+        R = r[0];
+    }
+    // parallel cyclic reduction over the 64 block-end unknowns
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        T iB = t_recip(B);
+        T Am = shfl_up_t(A, s), iBm = shfl_up_t(iB, s), Cm = shfl_up_t(C, s), Rm = shfl_up_t(R, s);
+        T Ap = shfl_down_t(A, s), iBp = shfl_down_t(iB, s), Cp = shfl_down_t(C, s), Rp = shfl_down_t(R, s);
+        bool hm = lane >= s, hp = lane + s < 64;
+        T k1 = hm ? t_mul(A, iBm) : t_zero(T());
+        T k2 = hp ? t_mul(C, iBp) : t_zero(T());
+        if (!hm) { Am = t_zero(T()); Cm = t_zero(T()); Rm = t_zero(T()); }
+        if (!hp) { Ap = t_zero(T()); Cp = t_zero(T()); Rp = t_zero(T()); }
+        T nB = t_nfma(t_nfma(B, Cm, k1), Ap, k2);
+        T nR = t_nfma(t_nfma(R, Rm, k1), Rp, k2);
+        A = t_neg(t_mul(Am, k1));
+        C = t_neg(t_mul(Cp, k2));
+        B = nB;
+        R = nR;
+    }
+    T xl = t_mul(R, t_recip(B));
+    T xp = shfl_up_t(xl, 1);
+    if (lane == 0) xp = t_zero(T());
+    if constexpr (E >= 2) {
+#pragma unroll
+        for (int i = 0; i < E - 1; ++i) {
+            T v = t_nfma(t_nfma(r[i], al[i], xp), be[i], xl);
+            r[i] = t_mul(inv[i], v);
+        }
+    }
+    r[E - 1] = xl;
+}
+
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------
+// host-side entry points implemented across the translation units
+// ---------------------------------------------------------------------------------
+// nk2d_kernels.hip
+int nk2d_k_pack_plane(nk2d_ctx* c, const double* src_dev, int nrows, int ncols, double* dst, double fill);
+int nk2d_k_pack_state(nk2d_ctx* c, const double* src_dev, double* dst);
+int nk2d_k_unpack_state(nk2d_ctx* c, const double* src, double* dst_dev);
+int nk2d_k_unpack_plane(nk2d_ctx* c, const double* src, int nrows, int ncols, double* dst_dev);
+int nk2d_k_vmix(nk2d_ctx* c, int nt, const double* times, double* const* out);
+int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f);
+int nk2d_k_jac(nk2d_ctx* c, const double* kv);
+int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre, double ccr, double cci,
+                 const double* br, const double* bcr, const double* bci, int src);
+int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
+int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
+int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
+int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
+int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci);
+int nk2d_r_newton_update(nk2d_ctx* c, int buf);
+int nk2d_r_err_rhs(nk2d_ctx* c, double h);
+int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h);
+int nk2d_r_err_norm(nk2d_ctx* c, const double* err);
+int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys);
+int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out);
+int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out);
+// nk2d_radau.hip
+int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,
+                    int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n);
+// nk2d_precond.hip
+void nk2d_precond_free(nk2d_ctx* c);

@@ -1,0 +1,861 @@
+// nk2d_kernels.hip -- model kernels of the py_driver_2d hot path for gfx950:
+// layout conversion, vertical-mixing coefficient, fused advection/mixing tendency,
+// Jacobian planes, line-relaxation sweeps of the shifted systems and the elementwise
+// pieces of the Radau IIA step.  One wavefront owns one (tracer, ypos) column, see
+// nk2d_common.h.  Compiled with -ffp-contract=off: the tendency and coefficient
+// kernels keep the reference's operation order (nk_ooc/py_driver_2d/advection.py:51-76,
+// horiz_mix.py:50-71, vert_mix.py:24-87, iage.py:22-41); fused multiply-adds are
+// written out explicitly only inside the tridiagonal solves.
+#include "nk2d_common.h"
+
+#include <cmath>
+#include <cstring>
+
+struct DevP {
+    int nz, ny, tc, ncol;
+    const double *VV, *KH, *WT, *WB, *DZR, *ZM0, *ZM1, *DM, *DMR, *DYR, *BLDMAX;
+    double surf[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
+    double atol, rtol;
+};
+
+static DevP make_devp(const nk2d_ctx* c) {
+    DevP p;
+    p.nz = c->nz; p.ny = c->ny; p.tc = c->tc; p.ncol = c->ncol;
+    p.VV = c->VV; p.KH = c->KH; p.WT = c->WT; p.WB = c->WB; p.DZR = c->DZR;
+    p.ZM0 = c->ZM0; p.ZM1 = c->ZM1; p.DM = c->DM; p.DMR = c->DMR; p.DYR = c->DYR;
+    p.BLDMAX = c->BLDMAX;
+    for (int i = 0; i < NK2D_MAX_TRACERS; ++i) { p.surf[i] = c->d.surf_rate[i]; p.decay[i] = c->d.decay_rate[i]; }
+    p.csrc = c->d.const_src;
+    p.atol = c->d.atol; p.rtol = c->d.rtol;
+    return p;
+}
+
+// Radau IIA constants (scipy/integrate/_ivp/radau.py:11-40, values as evaluated by CPython)
+__constant__ double cTI[3][3] = {
+    {4.17871859155190428, 0.32768282076106237, 0.52337644549944951},
+    {-4.17871859155190428, -0.32768282076106237, 0.47662355450055044},
+    {0.50287263494578682, -2.57192694985560522, 0.59603920482822492}};
+__constant__ double cT[3][3] = {
+    {0.09443876248897524, -0.14125529502095421, 0.03002919410514742},
+    {0.25021312296533332, 0.20412935229379994, -0.38294211275726192},
+    {1.0, 1.0, 0.0}};
+__constant__ double cP[3][3] = {
+    {10.048809399827414, -25.62959144707664, 15.580782047249224},
+    {-1.382142733160748, 10.296258113743303, -8.914115380582556},
+    {0.3333333333333333, -2.6666666666666665, 3.3333333333333335}};
+__constant__ double cE[3] = {-10.048809399827414, 1.382142733160748, -0.3333333333333333};
+
+#define TASK_PROLOGUE(ntasks)                                              \
+    const int lane = threadIdx.x & 63;                                     \
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6); \
+    if (task >= (ntasks)) return;
+
+// ---------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------
+// src: row-major [nrows][ncols] (row = depth level); dst: packed columns
+template <int E>
+__global__ void k_pack_plane(const double* __restrict__ src, int nrows, int ncols, double* __restrict__ dst, double fill) {
+    TASK_PROLOGUE(ncols)
+    double v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int k = lane * E + e;
+        v[e] = (k < nrows) ? src[(size_t)k * ncols + task] : fill;
+    }
+    store_col<E>(dst, task, lane, v);
+}
+template <int E>
+__global__ void k_unpack_plane(const double* __restrict__ src, int nrows, int ncols, double* __restrict__ dst) {
+    TASK_PROLOGUE(ncols)
+    double v[E];
+    load_col<E>(src, task, lane, v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int k = lane * E + e;
+        if (k < nrows) dst[(size_t)k * ncols + task] = v[e];
+    }
+}
+// state (tc, nz, ny) <-> packed [tc*ny] columns
+template <int E>
+__global__ void k_pack_state(const double* __restrict__ src, int nz, int ny, int ncol, double* __restrict__ dst) {
+    TASK_PROLOGUE(ncol)
+    const int tr = task / ny, j = task - tr * ny;
+    double v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int k = lane * E + e;
+        v[e] = (k < nz) ? src[((size_t)tr * nz + k) * ny + j] : 0.0;
+    }
+    store_col<E>(dst, task, lane, v);
+}
+template <int E>
+__global__ void k_unpack_state(const double* __restrict__ src, int nz, int ny, int ncol, double* __restrict__ dst) {
+    TASK_PROLOGUE(ncol)
+    const int tr = task / ny, j = task - tr * ny;
+    double v[E];
+    load_col<E>(src, task, lane, v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int k = lane * E + e;
+        if (k < nz) dst[((size_t)tr * nz + k) * ny + j] = v[e];
+    }
+}
+
+int nk2d_k_pack_plane(nk2d_ctx* c, const double* src_dev, int nrows, int ncols, double* dst, double fill) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pack_plane<EE>, dim3(nk2d_grid(ncols)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               src_dev, nrows, ncols, dst, fill));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+int nk2d_k_unpack_plane(nk2d_ctx* c, const double* src, int nrows, int ncols, double* dst_dev) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_unpack_plane<EE>, dim3(nk2d_grid(ncols)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               src, nrows, ncols, dst_dev));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+int nk2d_k_pack_state(nk2d_ctx* c, const double* src_dev, double* dst) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pack_state<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               src_dev, c->nz, c->ny, c->ncol, dst));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+int nk2d_k_unpack_state(nk2d_ctx* c, const double* src, double* dst_dev) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_unpack_state<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               src, c->nz, c->ny, c->ncol, dst_dev));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// np.interp restated for the host (numpy/core/src/multiarray/compiled_base.c semantics)
+// ---------------------------------------------------------------------------------
+int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out) {
+    if (x > xp[n - 1]) { *out = fp[n - 1]; return 0; }
+    if (x < xp[0]) { *out = fp[0]; return 0; }
+    int j = 0;
+    while (j + 1 < n && xp[j + 1] <= x) ++j;  // xp[j] <= x < xp[j+1]
+    if (j == n - 1 || xp[j] == x) { *out = fp[j]; return 0; }
+    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    *out = slope * (x - xp[j]) + fp[j];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// vertical mixing coefficient (vert_mix.py:44-87 with spatial_axis.py:136-187)
+// ---------------------------------------------------------------------------------
+struct VmixArgs {
+    double frac[4];
+    double* out[4];
+    double bldmin, y0, y1, hw;
+};
+
+__device__ __forceinline__ double ramp2(double x, double x0, double x1, double y0, double y1, double slope) {
+    if (x > x1) return y1;
+    if (x < x0) return y0;
+    if (x == x1) return y1;
+    if (x == x0) return y0;
+    return slope * (x - x0) + y0;
+}
+
+template <int E>
+__global__ void k_vmix(DevP P, VmixArgs A, int nt) {
+    TASK_PROLOGUE(P.ny * nt)
+    const int ti = task / P.ny, j = task - ti * P.ny;
+    const double frac = A.frac[ti];
+    const double bld = A.bldmin + (P.BLDMAX[j] - A.bldmin) * frac;
+    const double x0 = bld - A.hw, x1 = bld + A.hw;
+    const double y0 = A.y0, y1 = A.y1;
+    const double slope = (y1 - y0) / (x1 - x0);
+    double zm0[E], zm1[E], dm[E], dmr[E], wb[E], kv[E];
+    load_col<E>(P.ZM0, 0, lane, zm0);
+    load_col<E>(P.ZM1, 0, lane, zm1);
+    load_col<E>(P.DM, 0, lane, dm);
+    load_col<E>(P.DMR, 0, lane, dmr);
+    load_col<E>(P.WB, j, lane, wb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        double val = 0.0;
+        if (k < P.nz - 1) {
+            const double e0 = zm0[e], e1 = zm1[e];
+            const double ye0 = ramp2(e0, x0, x1, y0, y1, slope);
+            const double ye1 = ramp2(e1, x0, x1, y0, y1, slope);
+            double res = 0.5 * (ye0 + ye1);
+            const bool in0 = (e0 <= x0) && (x0 < e1);
+            const bool in1 = (e0 <= x1) && (x1 < e1);
+            if (in0) {
+                double s = (x0 - e0) * (0.5 * (ye0 + y0));
+                if (in1) {
+                    s = s + (x1 - x0) * (0.5 * (y0 + y1));
+                    s = s + (e1 - x1) * (0.5 * (y1 + ye1));
+                } else {
+                    s = s + (e1 - x0) * (0.5 * (y0 + ye1));
+                }
+                res = s * dmr[e];
+            } else if (in1) {
+                double s = (x1 - e0) * (0.5 * (ye0 + y1));
+                s = s + (e1 - x1) * (0.5 * (y1 + ye1));
+                res = s * dmr[e];
+            }
+            double kk = exp(res);
+            const double pec = ((0.5 * dm[e]) * fabs(wb[e])) / kk;
+            kk = kk * ((pec > 1.0) ? pec : 1.0);
+            val = kk * dmr[e];
+        }
+        kv[e] = val;
+    }
+    store_col<E>(A.out[ti], j, lane, kv);
+}
+
+int nk2d_k_vmix(nk2d_ctx* c, int nt, const double* times, double* const* out) {
+    if (nt < 1 || nt > 4) return nk2d_fail(c, "nk2d_k_vmix: nt out of range");
+    VmixArgs A;
+    for (int i = 0; i < nt; ++i) {
+        nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &A.frac[i]);
+        A.out[i] = out[i];
+    }
+    A.bldmin = c->d.bldepth_min; A.y0 = c->d.vmix_log_shallow; A.y1 = c->d.vmix_log_deep;
+    A.hw = c->d.vmix_half_width;
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_vmix<EE>, dim3(nk2d_grid(c->ny * nt)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               P, A, nt));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// tendency of one column: advection + horizontal mixing + vertical mixing + sources
+// ---------------------------------------------------------------------------------
+template <int E>
+struct ColCoef {
+    double vS[E], vN[E], khS[E], khN[E], wT[E], wB[E], dzr[E];
+    double dyr;
+};
+
+template <int E>
+__device__ __forceinline__ void load_coef(const DevP& P, int j, int lane, ColCoef<E>& cf) {
+    load_col<E>(P.VV, j, lane, cf.vS);
+    load_col<E>(P.VV, j + 1, lane, cf.vN);
+    load_col<E>(P.KH, j, lane, cf.khS);
+    load_col<E>(P.KH, j + 1, lane, cf.khN);
+    load_col<E>(P.WT, j, lane, cf.wT);
+    load_col<E>(P.WB, j, lane, cf.wB);
+    load_col<E>(P.DZR, 0, lane, cf.dzr);
+    cf.dyr = P.DYR[j];
+}
+
+// c: own column, cs / cn: columns j-1 / j+1 (any finite values at the walls, their
+// face coefficients are zero), kv: vertical mixing coeff between level k and k+1
+template <int E>
+__device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, const double (&c)[E],
+                                         const double (&cs)[E], const double (&cn)[E], const double (&kv)[E],
+                                         int tr, int lane, double (&out)[E]) {
+    double cprev[E], cnext[E], kvprev[E];
+    shift_prev<E>(c, cprev, lane, 0.0);
+    shift_next<E>(c, cnext, lane, 0.0);
+    shift_prev<E>(kv, kvprev, lane, 0.0);
+    const double surf = P.surf[tr], decay = P.decay[tr];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        // advection, flux form (advection.py:58-74)
+        const double fyS = (0.5 * (c[e] + cs[e])) * cf.vS[e];
+        const double fyN = (0.5 * (cn[e] + c[e])) * cf.vN[e];
+        double t = cf.dyr * (fyS - fyN);
+        const double fzT = (0.5 * (c[e] + cprev[e])) * cf.wT[e];
+        const double fzB = (0.5 * (cnext[e] + c[e])) * cf.wB[e];
+        t = t + cf.dzr[e] * (fzB - fzT);
+        // horizontal mixing (horiz_mix.py:60-69)
+        const double gS = cf.khS[e] * (c[e] - cs[e]);
+        const double gN = cf.khN[e] * (cn[e] - c[e]);
+        t = t + cf.dyr * (gN - gS);
+        // vertical mixing (vert_mix.py:33-40)
+        const double hT = kvprev[e] * (c[e] - cprev[e]);
+        const double hB = kv[e] * (cnext[e] - c[e]);
+        t = t + cf.dzr[e] * (hB - hT);
+        // module sources (iage.py:31-39)
+        if (k == 0) t = t - surf * c[e];
+        if (decay != 0.0) t = t - decay * c[e];
+        t = t + P.csrc;
+        out[e] = (k < P.nz) ? t : 0.0;
+    }
+}
+
+template <int E>
+__global__ void k_tend(DevP P, const double* __restrict__ y, const double* __restrict__ kvp, double* __restrict__ f) {
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double c[E], cs[E], cn[E], kv[E], out[E];
+    load_col<E>(y, task, lane, c);
+    load_col<E>(y, (j > 0) ? task - 1 : task, lane, cs);
+    load_col<E>(y, (j < P.ny - 1) ? task + 1 : task, lane, cn);
+    load_col<E>(kvp, j, lane, kv);
+    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, out);
+    store_col<E>(f, task, lane, out);
+}
+
+int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_tend<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               P, y, kv, f));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Jacobian planes (advection.py:111-173, horiz_mix.py:100-142, vert_mix.py:140-182)
+// up = d tend[k]/d c[k-1], dn = .../d c[k+1], south = .../d c[j-1], north = .../d c[j+1]
+// ---------------------------------------------------------------------------------
+template <int E>
+__global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict__ JL, double* __restrict__ JU,
+                      double* __restrict__ JS, double* __restrict__ JN, double* __restrict__ JC) {
+    TASK_PROLOGUE(P.ny)
+    const int j = task;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double kv[E], kvprev[E], up[E], dn[E], so[E], no[E], ce[E];
+    load_col<E>(kvp, j, lane, kv);
+    shift_prev<E>(kv, kvprev, lane, 0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        const bool valid = k < P.nz;
+        const double a_up = (k > 0 && valid) ? (-0.5 * cf.wT[e]) * cf.dzr[e] : 0.0;
+        const double a_s = (j > 0 && valid) ? (0.5 * cf.vS[e]) * cf.dyr : 0.0;
+        const double a_n = (j < P.ny - 1 && valid) ? (-0.5 * cf.vN[e]) * cf.dyr : 0.0;
+        const double a_dn = (k < P.nz - 1) ? (0.5 * cf.wB[e]) * cf.dzr[e] : 0.0;
+        const double a_c = ((a_up + a_s) + a_n) + a_dn;
+        const double h_s = (j > 0 && valid) ? cf.khS[e] * cf.dyr : 0.0;
+        const double h_n = (j < P.ny - 1 && valid) ? cf.khN[e] * cf.dyr : 0.0;
+        const double h_c = -(h_s + h_n);
+        const double v_up = (k > 0 && valid) ? kvprev[e] * cf.dzr[e] : 0.0;
+        const double v_dn = (k < P.nz - 1) ? kv[e] * cf.dzr[e] : 0.0;
+        const double v_c = -(v_up + v_dn);
+        up[e] = a_up + v_up;
+        dn[e] = a_dn + v_dn;
+        so[e] = a_s + h_s;
+        no[e] = a_n + h_n;
+        ce[e] = (a_c + h_c) + v_c;
+    }
+    store_col<E>(JL, j, lane, up);
+    store_col<E>(JU, j, lane, dn);
+    store_col<E>(JS, j, lane, so);
+    store_col<E>(JN, j, lane, no);
+    store_col<E>(JC, j, lane, ce);
+}
+
+int nk2d_k_jac(nk2d_ctx* c, const double* kv) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_jac<EE>, dim3(nk2d_grid(c->ny)), dim3(NK2D_BLOCK), 0, c->stream, P, kv,
+                                               c->JL, c->JU, c->JS, c->JN, c->JC));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// line-relaxation sweep for (c I - J) x = b:
+//   x_new[:, j] = T_j^-1 ( b[:, j] + S x_old[:, j-1] + N x_old[:, j+1] ),
+//   T_j = tridiag(-JL, c - JC + extra, -JU) of column j.
+// Real tasks first, complex tasks after; one wave per (system, tracer, column).
+// ---------------------------------------------------------------------------------
+struct SweepArgs {
+    const double *JL, *JU, *JS, *JN, *JC;
+    const double *br, *bcr, *bci;
+    const double *xr_old, *xcr_old, *xci_old;
+    double *xr_new, *xcr_new, *xci_new;
+    double cre, ccr, cci;
+    int nreal, ntasks, first;
+};
+
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
+    TASK_PROLOGUE(A.ntasks)
+    const bool is_c = task >= A.nreal;
+    const int col = is_c ? task - A.nreal : task;
+    const int tr = col / P.ny, j = col - tr * P.ny;
+    double jl[E], ju[E], jc[E], a[E], cc[E];
+    load_col<E>(A.JL, j, lane, jl);
+    load_col<E>(A.JU, j, lane, ju);
+    load_col<E>(A.JC, j, lane, jc);
+    double dre[E];
+    const double shift_re = is_c ? A.ccr : A.cre;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        const bool valid = k < P.nz;
+        a[e] = valid ? -jl[e] : 0.0;
+        cc[e] = valid ? -ju[e] : 0.0;
+        double d = (shift_re - jc[e]) + P.decay[tr];
+        if (k == 0) d = d + P.surf[tr];
+        dre[e] = valid ? d : 1.0;
+    }
+    const int cs_col = (j > 0) ? col - 1 : col, cn_col = (j < P.ny - 1) ? col + 1 : col;
+    double js[E], jn[E];
+    if (!A.first) {
+        load_col<E>(A.JS, j, lane, js);
+        load_col<E>(A.JN, j, lane, jn);
+    }
+    if (!is_c) {
+        double r[E];
+        load_col<E>(A.br, col, lane, r);
+        if (!A.first) {
+            double xs[E], xn[E];
+            load_col<E>(A.xr_old, cs_col, lane, xs);
+            load_col<E>(A.xr_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], r[e]));
+        }
+        tridiag_wave<E, double>(a, cc, dre, r, lane);
+        store_col<E>(A.xr_new, col, lane, r);
+    } else {
+        cplx r[E], d[E];
+        double rr[E], ri[E];
+        load_col<E>(A.bcr, col, lane, rr);
+        load_col<E>(A.bci, col, lane, ri);
+        if (!A.first) {
+            double xs[E], xn[E];
+            load_col<E>(A.xcr_old, cs_col, lane, xs);
+            load_col<E>(A.xcr_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) rr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], rr[e]));
+            load_col<E>(A.xci_old, cs_col, lane, xs);
+            load_col<E>(A.xci_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) ri[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], ri[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane * E + e) < P.nz;
+            r[e] = c_make(rr[e], ri[e]);
+            d[e] = c_make(dre[e], valid ? A.cci : 0.0);
+        }
+        tridiag_wave<E, cplx>(a, cc, d, r, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { rr[e] = r[e].re; ri[e] = r[e].im; }
+        store_col<E>(A.xcr_new, col, lane, rr);
+        store_col<E>(A.xci_new, col, lane, ri);
+    }
+}
+
+// src = index of the ping-pong buffer holding the previous iterate; the new iterate
+// goes to buffer 1-src.
+int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre, double ccr, double cci,
+                 const double* br, const double* bcr, const double* bci, int src) {
+    SweepArgs A;
+    A.JL = c->JL; A.JU = c->JU; A.JS = c->JS; A.JN = c->JN; A.JC = c->JC;
+    A.br = br; A.bcr = bcr; A.bci = bci;
+    A.xr_old = c->XR[src]; A.xcr_old = c->XCR[src]; A.xci_old = c->XCI[src];
+    A.xr_new = c->XR[1 - src]; A.xcr_new = c->XCR[1 - src]; A.xci_new = c->XCI[1 - src];
+    A.cre = cre; A.ccr = ccr; A.cci = cci;
+    A.nreal = do_real ? c->ncol : 0;
+    A.ntasks = A.nreal + (do_cplx ? c->ncol : 0);
+    A.first = first ? 1 : 0;
+    if (A.ntasks == 0) return 0;
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_sweep<EE>, dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    c->st.nsweeps++;
+    return 0;
+}
+
+// contraction bound of the line relaxation: rho <= max_i s_i / (c + q_i)
+int nk2d_sweeps_for(nk2d_ctx* c, double c_real) {
+    double rho = 0.0;
+    const size_t n = c->front_q.size();
+    for (size_t i = 0; i < n; ++i) {
+        const double den = c_real + c->front_q[i];
+        if (!(den > 0.0)) return 400;
+        const double r = c->front_s[i] / den;
+        if (r > rho) rho = r;
+    }
+    if (rho <= 0.0) return 1;  // no horizontal coupling: the line solve is exact
+    if (rho >= 0.999) return 400;
+    int m = (int)std::ceil(std::log(c->d.lin_tol) / std::log(rho));
+    if (m < 2) m = 2;
+    if (m > 400) m = 400;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------
+// fixed-order final reduction of per-task partials: RED[r] = sum_task PART[task*nout + r]
+// ---------------------------------------------------------------------------------
+__global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, double* __restrict__ out) {
+    __shared__ double sh[NK2D_BLOCK];
+    for (int r = 0; r < nout; ++r) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < ntasks; i += NK2D_BLOCK) s += part[(size_t)i * nout + r];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[r] = sh[0];
+        __syncthreads();
+    }
+}
+
+int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, c->PART, ntasks, nout, c->RED);
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    if (host_out) {
+        NK2D_CHECK(c, hipMemcpyAsync(c->hRED, c->RED, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(host_out, c->hRED, sizeof(double) * nout);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Radau IIA elementwise kernels (scipy/integrate/_ivp/radau.py)
+// ---------------------------------------------------------------------------------
+// Z0 from the previous step's collocation polynomial, W = TI Z0 (radau.py:445-448,95)
+template <int E>
+__global__ void k_predict(int ncol, const double* __restrict__ y, const double* __restrict__ yold,
+                          const double* __restrict__ zp, size_t nv, double x0, double x1, double x2,
+                          double* __restrict__ z, double* __restrict__ w) {
+    TASK_PROLOGUE(ncol)
+    double yy[E], yo[E], z0[E], z1[E], z2[E];
+    load_col<E>(y, task, lane, yy);
+    load_col<E>(yold, task, lane, yo);
+    load_col<E>(zp, task, lane, z0);
+    load_col<E>(zp + nv, task, lane, z1);
+    load_col<E>(zp + 2 * nv, task, lane, z2);
+    const double xs[3] = {x0, x1, x2};
+    double o[3][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double q[3];
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double p1 = xs[i], p2 = p1 * xs[i], p3 = p2 * xs[i];
+            double v = (q[0] * p1 + q[1] * p2) + q[2] * p3;
+            v = v + yo[e];
+            o[i][e] = v - yy[e];
+        }
+    }
+    double wv[E];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) store_col<E>(z + i * nv, task, lane, o[i]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
+        store_col<E>(w + r * nv, task, lane, wv);
+    }
+}
+
+// stage tendencies F_i = fun(t + c_i h, y + Z_i) and transformed residuals
+// f_real = F^T TI_REAL - M_real W0, f_complex = F^T TI_COMPLEX - M_complex (W1 + i W2)
+// (radau.py:104-111)
+struct StageArgs {
+    const double *y, *z, *w;
+    const double* kv[3];
+    double *br, *bcr, *bci;
+    size_t nv;
+    double mreal, mcr, mci;
+};
+
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_stage(DevP P, StageArgs A) {
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double y0[E], ys[E], yn[E];
+    load_col<E>(A.y, task, lane, y0);
+    load_col<E>(A.y, cs_col, lane, ys);
+    load_col<E>(A.y, cn_col, lane, yn);
+    double fr[E], fcr[E], fci[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double c[E], cs[E], cn[E], kv[E], f[E];
+        load_col<E>(A.z + i * A.nv, task, lane, c);
+        load_col<E>(A.z + i * A.nv, cs_col, lane, cs);
+        load_col<E>(A.z + i * A.nv, cn_col, lane, cn);
+        load_col<E>(A.kv[i], j, lane, kv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
+        tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            fr[e] = fr[e] + f[e] * cTI[0][i];
+            fcr[e] = fcr[e] + f[e] * cTI[1][i];
+            fci[e] = fci[e] + f[e] * cTI[2][i];
+        }
+    }
+    double w0[E], w1[E], w2[E];
+    load_col<E>(A.w, task, lane, w0);
+    load_col<E>(A.w + A.nv, task, lane, w1);
+    load_col<E>(A.w + 2 * A.nv, task, lane, w2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        fr[e] = fr[e] - A.mreal * w0[e];
+        fcr[e] = fcr[e] - (A.mcr * w1[e] - A.mci * w2[e]);
+        fci[e] = fci[e] - (A.mcr * w2[e] + A.mci * w1[e]);
+    }
+    store_col<E>(A.br, task, lane, fr);
+    store_col<E>(A.bcr, task, lane, fcr);
+    store_col<E>(A.bci, task, lane, fci);
+}
+
+// dW -> sum((dW/scale)^2) partial, W += dW, Z = T W  (radau.py:113-129)
+template <int E>
+__global__ void k_newton_update(DevP P, const double* __restrict__ y, const double* __restrict__ xr,
+                                const double* __restrict__ xcr, const double* __restrict__ xci, double* __restrict__ w,
+                                double* __restrict__ z, size_t nv, double* __restrict__ part) {
+    TASK_PROLOGUE(P.ncol)
+    double yy[E], d0[E], d1[E], d2[E], w0[E], w1[E], w2[E];
+    load_col<E>(y, task, lane, yy);
+    load_col<E>(xr, task, lane, d0);
+    load_col<E>(xcr, task, lane, d1);
+    load_col<E>(xci, task, lane, d2);
+    load_col<E>(w, task, lane, w0);
+    load_col<E>(w + nv, task, lane, w1);
+    load_col<E>(w + 2 * nv, task, lane, w2);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double sc = P.atol + fabs(yy[e]) * P.rtol;
+        const double a = d0[e] / sc, b = d1[e] / sc, c = d2[e] / sc;
+        acc += (a * a + b * b) + c * c;
+        w0[e] = w0[e] + d0[e];
+        w1[e] = w1[e] + d1[e];
+        w2[e] = w2[e] + d2[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[task] = acc;
+    store_col<E>(w, task, lane, w0);
+    store_col<E>(w + nv, task, lane, w1);
+    store_col<E>(w + 2 * nv, task, lane, w2);
+    double zz[E];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+        store_col<E>(z + r * nv, task, lane, zz);
+    }
+}
+
+// error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
+template <int E>
+__global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
+                          double* __restrict__ out) {
+    TASK_PROLOGUE(ncol)
+    double ff[E], z0[E], z1[E], z2[E];
+    load_col<E>(f, task, lane, ff);
+    load_col<E>(z, task, lane, z0);
+    load_col<E>(z + nv, task, lane, z1);
+    load_col<E>(z + 2 * nv, task, lane, z2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / h;
+        ff[e] = ff[e] + ze;
+    }
+    store_col<E>(out, task, lane, ff);
+}
+
+// filtered error estimate right-hand side  fun(t, y + error) + Z^T E / h  (radau.py:485-487)
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK)
+    k_err_rhs2(DevP P, const double* __restrict__ y, const double* __restrict__ err, const double* __restrict__ kvp,
+               const double* __restrict__ z, size_t nv, double h, double* __restrict__ out) {
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double c[E], cs[E], cn[E], t0[E], kv[E], ff[E];
+    load_col<E>(y, task, lane, c);
+    load_col<E>(err, task, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
+    load_col<E>(y, cs_col, lane, cs);
+    load_col<E>(err, cs_col, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) cs[e] = cs[e] + t0[e];
+    load_col<E>(y, cn_col, lane, cn);
+    load_col<E>(err, cn_col, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
+    load_col<E>(kvp, j, lane, kv);
+    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    double z0[E], z1[E], z2[E];
+    load_col<E>(z, task, lane, z0);
+    load_col<E>(z + nv, task, lane, z1);
+    load_col<E>(z + 2 * nv, task, lane, z2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / h;
+        ff[e] = ff[e] + ze;
+    }
+    store_col<E>(out, task, lane, ff);
+}
+
+// sum((err / (atol + max(|y|, |y + Z2|) rtol))^2)  (radau.py:480-481)
+template <int E>
+__global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
+                           const double* __restrict__ err, double* __restrict__ part) {
+    TASK_PROLOGUE(P.ncol)
+    double yy[E], z2[E], er[E];
+    load_col<E>(y, task, lane, yy);
+    load_col<E>(z2p, task, lane, z2);
+    load_col<E>(err, task, lane, er);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double yn = yy[e] + z2[e];
+        const double sc = P.atol + fmax(fabs(yy[e]), fabs(yn)) * P.rtol;
+        const double a = er[e] / sc;
+        acc += a * a;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[task] = acc;
+}
+
+// sum(((ca a + cb b) / (atol + |ys| rtol))^2), used by the initial-step heuristic
+template <int E>
+__global__ void k_wnorm(DevP P, const double* __restrict__ a, const double* __restrict__ b, double ca, double cb,
+                        const double* __restrict__ ys, double* __restrict__ part) {
+    TASK_PROLOGUE(P.ncol)
+    double aa[E], bb[E], yy[E];
+    load_col<E>(a, task, lane, aa);
+    if (b) load_col<E>(b, task, lane, bb);
+    load_col<E>(ys, task, lane, yy);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double sc = P.atol + fabs(yy[e]) * P.rtol;
+        double v = b ? (ca * aa[e] + cb * bb[e]) : aa[e];
+        v = v / sc;
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[task] = acc;
+}
+
+// out = a + s*b
+template <int E>
+__global__ void k_axpy(int ncol, const double* __restrict__ a, double s, const double* __restrict__ b,
+                       double* __restrict__ out) {
+    TASK_PROLOGUE(ncol)
+    double aa[E], bb[E];
+    load_col<E>(a, task, lane, aa);
+    load_col<E>(b, task, lane, bb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) aa[e] = aa[e] + s * bb[e];
+    store_col<E>(out, task, lane, aa);
+}
+
+// y(T) - y0 with y(T) = y_old + Q [1,1,1] (radau.py:557-570, ivp.py:718-722), region masked
+template <int E>
+__global__ void k_final(int ncol, int ny, const double* __restrict__ yold, const double* __restrict__ zp, size_t nv,
+                        const double* __restrict__ y0, const int32_t* __restrict__ mask, double* __restrict__ out) {
+    TASK_PROLOGUE(ncol)
+    const int j = task % ny;
+    double yo[E], z0[E], z1[E], z2[E], yy[E];
+    load_col<E>(yold, task, lane, yo);
+    load_col<E>(zp, task, lane, z0);
+    load_col<E>(zp + nv, task, lane, z1);
+    load_col<E>(zp + 2 * nv, task, lane, z2);
+    load_col<E>(y0, task, lane, yy);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double q[3];
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+        double v = (q[0] + q[1]) + q[2];
+        v = v + yo[e];
+        v = v - yy[e];
+        const int m = mask[(size_t)j * (E * 64) + e * 64 + lane];
+        yo[e] = (m != 0) ? v : 0.0;
+    }
+    store_col<E>(out, task, lane, yo);
+}
+
+// --- host wrappers used by the Radau driver --------------------------------------
+int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_predict<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, c->Y, c->YOLD, c->ZP, c->nv, x0, x1, x2, c->Z, c->W));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci) {
+    StageArgs A;
+    A.y = c->Y; A.z = c->Z; A.w = c->W;
+    A.kv[0] = c->KV[0]; A.kv[1] = c->KV[1]; A.kv[2] = c->KV[2];
+    A.br = c->BR; A.bcr = c->BCR; A.bci = c->BCI;
+    A.nv = c->nv; A.mreal = mreal; A.mcr = mcr; A.mci = mci;
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_stage<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_newton_update(nk2d_ctx* c, int buf) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_newton_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               P, c->Y, c->XR[buf], c->XCR[buf], c->XCI[buf], c->W, c->Z, c->nv, c->PART));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, c->F, c->Z, c->nv, h, c->BR));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs2<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
+                                               c->Y, err, c->KV[3], c->Z, c->nv, h, c->BR));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_err_norm(nk2d_ctx* c, const double* err) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_norm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
+                                               c->Y, c->Z + 2 * c->nv, err, c->PART));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys) {
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_wnorm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, a,
+                                               b, ca, cb, ys, c->PART));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_axpy<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, a, s, b, out));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_final<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                               c->ncol, c->ny, c->YOLD, c->ZP, c->nv, y0, c->MASK, out));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}

@@ -1,0 +1,257 @@
+"""Device engine of ONE tracer module: a thin object layer over the nk2d C ABI.
+
+`ModuleEngine` owns an `nk2d_ctx` (one HIP stream on one GPU) and hands out
+device-resident vectors (`DevVec`).  Nothing here computes on the host; every
+method is a ctypes call into `csrc/libnk2d.so`.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .grid import BLDEPTH_MIN, YEAR, bldepth_time_knots
+
+
+class Nk2dError(RuntimeError):
+    pass
+
+
+def _dp(arr):
+    return arr.ctypes.data_as(_lib.c_double_p)
+
+
+class DevVec:
+    """a state vector (tracer, depth, ypos) of one tracer module, resident in HBM"""
+
+    __slots__ = ("eng", "ptr")
+
+    def __init__(self, eng, ptr):
+        self.eng = eng
+        self.ptr = ptr
+
+    def __del__(self):
+        eng, ptr = self.eng, self.ptr
+        self.ptr = None
+        if ptr is not None and eng is not None and eng._ctx is not None:
+            eng._lib.nk2d_vec_free(eng._ctx, ptr)
+
+    def to_host(self):
+        return self.eng.download(self)
+
+    def copy(self):
+        res = self.eng.new_vec()
+        self.eng._chk(self.eng._lib.nk2d_vec_copy(self.eng._ctx, res.ptr, self.ptr))
+        return res
+
+
+class ModuleEngine:
+    """HIP engine for one tracer module on one (depth, ypos) grid"""
+
+    def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, device_id=0,
+                 time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
+                 lin_tol=1.0e-13):
+        self._lib = _lib.load()
+        self._ctx = None
+        self.grid = grid
+        self.nz = len(grid.depth)
+        self.ny = len(grid.ypos)
+        self.tc = int(tc)
+        self.shape = (self.tc, self.nz, self.ny)
+        self.nreg = 1
+        desc = _lib.Desc()
+        desc.nz, desc.ny, desc.tc, desc.device_id = self.nz, self.ny, self.tc, int(device_id)
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (
+            grid.depth.edges, grid.ypos.edges, grid.vvel, grid.wvel, grid.hmix_coeff,
+            grid.bldepth_max)]
+        (desc.depth_edges, desc.ypos_edges, desc.vvel, desc.wvel, desc.hmix_coeff,
+         desc.bldepth_max) = [_dp(a) for a in keep]
+        desc.bldepth_min = BLDEPTH_MIN
+        tvals, fvals = bldepth_time_knots()
+        desc.bld_tvals = (ctypes.c_double * 4)(*tvals)
+        desc.bld_fvals = (ctypes.c_double * 4)(*fvals)
+        desc.vmix_log_shallow = float(np.log(1.0e1))
+        desc.vmix_log_deep = float(np.log(5.0e-4))
+        desc.vmix_half_width = 20.0
+        surf = list(surf_rate) + [0.0] * (_lib.MAX_TRACERS - len(surf_rate))
+        decay = list(decay_rate) + [0.0] * (_lib.MAX_TRACERS - len(decay_rate))
+        desc.surf_rate = (ctypes.c_double * _lib.MAX_TRACERS)(*surf)
+        desc.decay_rate = (ctypes.c_double * _lib.MAX_TRACERS)(*decay)
+        desc.const_src = float(const_src)
+        desc.t0, desc.t1 = float(time_range[0]), float(time_range[1])
+        desc.rtol, desc.atol = float(rtol), float(atol)
+        desc.max_step_frac = float(max_step_frac)
+        desc.lin_tol = float(lin_tol)
+        ctx = ctypes.c_void_p()
+        rc = self._lib.nk2d_create(ctypes.byref(desc), ctypes.byref(ctx))
+        if rc != 0:
+            msg = self._lib.nk2d_last_error(ctx).decode() if ctx else "allocation failed"
+            if ctx:
+                self._lib.nk2d_destroy(ctx)
+            raise Nk2dError(f"nk2d_create failed ({rc}): {msg}")
+        self._ctx = ctx
+        self._precond_ready = False
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.nk2d_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Nk2dError(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
+
+    # ---- regions ------------------------------------------------------------
+    def set_region(self, mask, weight):
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        if mask.shape != (self.nz, self.ny) or weight.shape != (self.nz, self.ny):
+            raise ValueError("region mask / weight must have shape (nz, ny)")
+        nreg = int(mask.max())
+        self._chk(self._lib.nk2d_set_region(
+            self._ctx, mask.ctypes.data_as(_lib.c_int32_p), _dp(weight), nreg))
+        self.nreg = nreg
+
+    # ---- vectors ------------------------------------------------------------
+    def new_vec(self):
+        ptr = ctypes.c_void_p()
+        self._chk(self._lib.nk2d_vec_alloc(self._ctx, ctypes.byref(ptr)))
+        return DevVec(self, ptr)
+
+    def upload(self, host, out=None):
+        host = np.ascontiguousarray(host, dtype=np.float64).reshape(self.shape)
+        out = self.new_vec() if out is None else out
+        self._chk(self._lib.nk2d_vec_upload(self._ctx, out.ptr, _dp(host)))
+        return out
+
+    def download(self, vec):
+        host = np.empty(self.shape)
+        self._chk(self._lib.nk2d_vec_download(self._ctx, vec.ptr, _dp(host)))
+        return host
+
+    def sync(self):
+        self._chk(self._lib.nk2d_sync(self._ctx))
+
+    # ---- deterministic kernels ------------------------------------------------
+    def tend(self, t, y, out=None):
+        out = self.new_vec() if out is None else out
+        self._chk(self._lib.nk2d_tend(self._ctx, float(t), y.ptr, out.ptr))
+        return out
+
+    def vmix_coeff(self, t):
+        host = np.empty((self.nz - 1, self.ny))
+        self._chk(self._lib.nk2d_vmix_coeff(self._ctx, float(t), _dp(host)))
+        return host
+
+    def jacobian_diags(self, t):
+        """(5, tc, nz, ny): up, south, centre, north, down"""
+        host = np.empty((5, self.tc, self.nz, self.ny))
+        self._chk(self._lib.nk2d_jacobian_diags(self._ctx, float(t), _dp(host)))
+        return host
+
+    def shifted_solve(self, t_jac, h, mu, b_re, b_im=None):
+        """x = ((mu/h) I - J(t_jac))^-1 b; returns (x_re, x_im or None, sweeps)"""
+        mu = complex(mu)
+        x_re = self.new_vec()
+        x_im = self.new_vec() if mu.imag != 0.0 else None
+        sweeps = ctypes.c_int32()
+        self._chk(self._lib.nk2d_shifted_solve(
+            self._ctx, float(t_jac), float(h), mu.real, mu.imag, b_re.ptr,
+            b_im.ptr if b_im is not None else None, x_re.ptr,
+            x_im.ptr if x_im is not None else None, ctypes.byref(sweeps)))
+        return x_re, x_im, sweeps.value
+
+    # ---- the forward year -------------------------------------------------------
+    def comp_fcn(self, x, out=None, replay=None, record=False, record_cap=65536):
+        """F(x) = y(T) - x.  Returns (fx, stats dict, schedule or None)."""
+        out = self.new_vec() if out is None else out
+        stats = _lib.Stats()
+        rp, rn = None, 0
+        if replay is not None:
+            replay = np.ascontiguousarray(replay, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+            rp, rn = _dp(replay), replay.shape[0]
+        rec, recn = None, ctypes.c_int64(0)
+        if record:
+            rec = np.zeros((record_cap, _lib.SCHED_WIDTH))
+        self._chk(self._lib.nk2d_comp_fcn(
+            self._ctx, x.ptr, out.ptr, ctypes.byref(stats), rp, rn,
+            _dp(rec) if rec is not None else None, record_cap if record else 0,
+            ctypes.byref(recn)))
+        sched = rec[: recn.value].copy() if record else None
+        return out, stats.as_dict(), sched
+
+    # ---- preconditioner -----------------------------------------------------------
+    def precond_setup(self):
+        self._chk(self._lib.nk2d_precond_setup(self._ctx))
+        self._precond_ready = True
+
+    def precond_apply(self, v, out=None):
+        if not self._precond_ready:
+            self.precond_setup()
+        out = self.new_vec() if out is None else out
+        self._chk(self._lib.nk2d_precond_apply(self._ctx, v.ptr, out.ptr))
+        return out
+
+    # ---- region-weighted algebra -----------------------------------------------------
+    def _reg(self, vals):
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(vals, dtype=np.float64), (self.nreg,)))
+        return arr
+
+    def dot(self, a, b):
+        out = np.empty(self.nreg)
+        self._chk(self._lib.nk2d_dot(self._ctx, a.ptr, b.ptr, _dp(out)))
+        return out
+
+    def axpby(self, a, x, b, y, out=None):
+        """out = bcast(a) x + bcast(b) y"""
+        out = self.new_vec() if out is None else out
+        ca, cb = self._reg(a), self._reg(b)
+        self._chk(self._lib.nk2d_axpby(self._ctx, out.ptr, _dp(ca), x.ptr, _dp(cb), y.ptr))
+        return out
+
+    def scale(self, x, s, out=None):
+        out = self.new_vec() if out is None else out
+        cs = self._reg(s)
+        self._chk(self._lib.nk2d_scale(self._ctx, out.ptr, x.ptr, _dp(cs)))
+        return out
+
+    def diff_scale(self, x, y, s, out=None):
+        """out = (x - y) bcast(s)"""
+        out = self.new_vec() if out is None else out
+        cs = self._reg(s)
+        self._chk(self._lib.nk2d_diff_scale(self._ctx, out.ptr, x.ptr, y.ptr, _dp(cs)))
+        return out
+
+    def lin_comb(self, vecs, coef, out=None):
+        """out = sum_i bcast(coef[i]) vecs[i], accumulated in order; coef (n, nreg)"""
+        out = self.new_vec() if out is None else out
+        coef = np.ascontiguousarray(coef, dtype=np.float64).reshape(len(vecs), self.nreg)
+        ptrs = (ctypes.c_void_p * len(vecs))(*[v.ptr for v in vecs])
+        self._chk(self._lib.nk2d_lin_comb(self._ctx, out.ptr, len(vecs), ptrs, _dp(coef)))
+        return out
+
+    def mgs(self, w, basis):
+        """in-place modified Gram-Schmidt of w against basis; returns h (n, nreg)"""
+        h = np.empty((len(basis), self.nreg))
+        ptrs = (ctypes.c_void_p * len(basis))(*[v.ptr for v in basis])
+        self._chk(self._lib.nk2d_mgs(self._ctx, w.ptr, len(basis), ptrs, _dp(h)))
+        return h
+
+    def apply_region_mask(self, v):
+        self._chk(self._lib.nk2d_apply_region_mask(self._ctx, v.ptr))
+        return v
+
+
+def iage_engine(grid, device_id=0, **kwargs):
+    """engine of the `iage` tracer module (two tracers; surface restoring at
+    24/day over 10 m and 100x slower; unit ageing source), iage.py:12-41"""
+    rate = 24.0 / 86400.0 * 10.0 / grid.depth.delta[0]
+    slow = 0.01
+    return ModuleEngine(grid, tc=2, surf_rate=(rate, slow * rate),
+                        const_src=1.0 / (365.0 * 86400.0), device_id=device_id, **kwargs)

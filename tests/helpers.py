@@ -1,0 +1,18 @@
+"""shared helpers of the test-suite (oracle-side set-up)"""
+import numpy as np
+
+from oracle.grid import default_axes
+from oracle.model import Iage, Py2dModel
+
+
+def oracle_iage(nz, ny, max_abs_vvel=0.1, horiz_mix_coeff=1000.0):
+    depth, ypos = default_axes(nz, ny)
+    model = Py2dModel(depth, ypos, max_abs_vvel, horiz_mix_coeff)
+    return model, Iage(model)
+
+
+def rel_err(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    den = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))

@@ -1,0 +1,61 @@
+"""GPU parity of the forward year (comp_fcn) against the oracle.
+
+Two modes ("parity reality check"):
+* step replay -- the HIP integrator consumes the accepted-step schedule recorded by
+  the oracle (which reproduces SciPy's Radau bit for bit); the map is then smooth and
+  the result must agree to 1e-10 relative;
+* free running -- the HIP controller takes its own decisions; the reference's own
+  reproducibility floor is ~1e-6 (a 1e-15 input perturbation already flips step
+  decisions), so the comparison uses the reference CI tolerance atol 1e-6 / rtol 1e-3
+  (scripts/ci_py_driver_2d_iage.sh:38).
+"""
+import numpy as np
+import pytest
+
+from helpers import oracle_iage, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    return iage_engine(Grid2d.default(nz, ny, vv, kh), **kw)
+
+
+CASES = [("20x3_columns", 20, 3, 0.0, 0.0), ("26x26", 26, 26, 0.1, 1000.0),
+         ("26x26_bumpy", 26, 26, 0.1, 1000.0)]
+
+
+@pytest.mark.parametrize("tag,nz,ny,vv,kh", CASES)
+def test_comp_fcn_replay(golden_dir, tag, nz, ny, vv, kh):
+    from oracle import radau
+
+    g = np.load(f"{golden_dir}/comp_fcn_{tag}.npz")
+    _, tm = oracle_iage(nz, ny, vv, kh)
+    want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
+    assert np.array_equal(want, g["fcn"])  # the oracle reproduces the reference run
+    sched = np.array(solver.schedule, dtype=np.float64)
+    eng = make_engine(nz, ny, vv, kh)
+    fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=sched)
+    got = eng.download(fx).reshape(-1)
+    assert stats["nsteps"] == len(sched)
+    assert rel_err(got, want) < 1e-10, rel_err(got, want)
+
+
+@pytest.mark.parametrize("tag,nz,ny,vv,kh", CASES)
+def test_comp_fcn_free(golden_dir, tag, nz, ny, vv, kh):
+    g = np.load(f"{golden_dir}/comp_fcn_{tag}.npz")
+    eng = make_engine(nz, ny, vv, kh)
+    fx, stats, sched = eng.comp_fcn(eng.upload(g["y0"]), record=True)
+    got = eng.download(fx).reshape(-1)
+    # reference CI tolerance for fcn files
+    assert np.allclose(got, g["fcn"], rtol=1.0e-3, atol=1.0e-6), np.max(np.abs(got - g["fcn"]))
+    assert len(sched) == stats["nsteps"]
+    # the controller takes the same kind of path as SciPy's: counters within 10 %
+    for key in ("nfev", "njev", "nlu"):
+        assert abs(stats[key] - int(g[key])) <= 0.1 * int(g[key]) + 5, (key, stats[key], int(g[key]))
+    # the recorded schedule replays to the same answer (smooth map)
+    fx2, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=sched)
+    assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-12
