@@ -1,0 +1,500 @@
+"""Device-resident model state with the reference's `ModelState` plugin surface.
+
+Mirrors, for the py_driver_2d model, what the solvers call on a model state
+(`nk_ooc/model_state_base.py`, `nk_ooc/tracer_module_state_base.py`,
+`nk_ooc/py_driver_2d/model_state.py`): construction from a file name (or the
+pseudo-files "zeros" / "gen_init_iterate"), `comp_fcn`, `apply_precond_jacobian`,
+`gen_precond_jacobian`, `comp_jacobian_fcn_state_prod`, `dump`, `dot_prod` / `norm` /
+`mean`, `mod_gram_schmidt`, module-level `lin_comb`, and the arithmetic operators with
+float / `ndarray[ntm, nreg]` / state operands, including the step-log idempotence
+contract and the NetCDF3 file trail.
+
+The values live in HBM (one `DevVec` per tracer module, one `ModuleEngine` = one HIP
+stream per module, optionally on different GPUs); every operation is a kernel launch
+through the C ABI.  Files are written at the same points as the reference; a
+snapshot cache keyed by file name serves re-opens from HBM instead of re-reading.
+"""
+
+import logging
+import os
+import subprocess
+
+import numpy as np
+
+from . import ncio
+from .engine import ModuleEngine, iage_engine
+from .grid import Grid2d, SpatialAxis
+
+YEAR = 365.0 * 86400.0
+
+
+def _strtobool(val):
+    val = str(val).lower()
+    if val in ("y", "yes", "t", "true", "on", "1"):
+        return True
+    if val in ("n", "no", "f", "false", "off", "0"):
+        return False
+    raise ValueError(f"invalid truth value {val!r}")
+
+
+def _class_name(obj):
+    return f"{obj.__module__}.{type(obj).__name__}"
+
+
+class TracerModuleState:
+    """the tracers of one module, resident on the module's GPU"""
+
+    __array_priority__ = 100
+
+    def __init__(self, name, module_def, engine, vec):
+        self.name = name
+        self._tracer_module_def = module_def
+        self.tracer_names = list(module_def["tracers"])
+        self.tracer_cnt = len(self.tracer_names)
+        units = {meta.get("attrs", {}).get("units") for meta in module_def["tracers"].values()}
+        self.units = units.pop() if len(units) == 1 else None
+        self.eng = engine
+        self.vec = vec
+
+    def _like(self, vec):
+        return TracerModuleState(self.name, self._tracer_module_def, self.eng, vec)
+
+    def copy(self):
+        return self._like(self.vec.copy())
+
+    def get_tracer_vals_all(self):
+        return self.eng.download(self.vec)
+
+    def log_vals(self, msg, vals):
+        logger = logging.getLogger(__name__)
+        vals = np.asarray(vals)
+        if vals.ndim >= 1 and vals.shape[-1] == 1:
+            self.log_vals(msg, vals[..., 0])
+            return
+        if vals.ndim == 0:
+            logger.info("%s[%s]=%e", msg, self.name, vals)
+        elif vals.ndim == 1:
+            for j in range(vals.shape[0]):
+                logger.info("%s[%s,%d]=%e", msg, self.name, j, vals[j])
+        elif vals.ndim == 2:
+            for i in range(vals.shape[0]):
+                for j in range(vals.shape[1]):
+                    logger.info("%s[%s,%d,%d]=%e", msg, self.name, i, j, vals[i, j])
+        else:
+            raise ValueError(f"vals.ndim={vals.ndim} not handled")
+
+    # ---- reductions ---------------------------------------------------------
+    def dot_prod(self, other):
+        return self.eng.dot(self.vec, other.vec)
+
+    def mean(self):
+        return self.eng.dot(self.vec, self.eng_ones())
+
+    def eng_ones(self):
+        ones = getattr(self.eng, "_ones_vec", None)
+        if ones is None:
+            ones = self.eng.upload(np.ones(self.eng.shape))
+            self.eng._ones_vec = ones
+        return ones
+
+    # ---- arithmetic (new objects) -----------------------------------------------
+    def _coef(self, other):
+        """float or ndarray[nreg] -> region coefficient array, else None"""
+        if isinstance(other, (int, float)):
+            return np.full(self.eng.nreg, float(other))
+        if isinstance(other, np.ndarray) and other.shape == (self.eng.nreg,):
+            return other
+        return None
+
+    def __neg__(self):
+        return self._like(self.eng.scale(self.vec, -1.0))
+
+    def __add__(self, other):
+        if not isinstance(other, TracerModuleState):
+            return NotImplemented
+        return self._like(self.eng.axpby(1.0, self.vec, 1.0, other.vec))
+
+    def __sub__(self, other):
+        if not isinstance(other, TracerModuleState):
+            return NotImplemented
+        return self._like(self.eng.diff_scale(self.vec, other.vec, 1.0))
+
+    def __mul__(self, other):
+        coef = self._coef(other)
+        if coef is None:
+            return NotImplemented
+        return self._like(self.eng.scale(self.vec, coef))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        coef = self._coef(other)
+        if coef is None:
+            return NotImplemented
+        return self._like(self.eng.scale(self.vec, 1.0 / coef))
+
+    # ---- arithmetic (in place) -------------------------------------------------------
+    def __iadd__(self, other):
+        if not isinstance(other, TracerModuleState):
+            return NotImplemented
+        self.eng.axpby(1.0, self.vec, 1.0, other.vec, out=self.vec)
+        return self
+
+    def __isub__(self, other):
+        if not isinstance(other, TracerModuleState):
+            return NotImplemented
+        self.eng.diff_scale(self.vec, other.vec, 1.0, out=self.vec)
+        return self
+
+    def __imul__(self, other):
+        coef = self._coef(other)
+        if coef is None:
+            return NotImplemented
+        self.eng.scale(self.vec, coef, out=self.vec)
+        return self
+
+    def __itruediv__(self, other):
+        coef = self._coef(other)
+        if coef is None:
+            return NotImplemented
+        self.eng.scale(self.vec, 1.0 / coef, out=self.vec)
+        return self
+
+
+def _module_engine(name, module_def, grid, device_id, modelinfo):
+    """HIP engine for a tracer module of py_driver_2d"""
+    py_mod_name = module_def.get("py_mod_name", name)
+    kwargs = {}
+    if "lin_tol" in modelinfo:
+        kwargs["lin_tol"] = float(modelinfo["lin_tol"])
+    if py_mod_name == "iage":
+        return iage_engine(grid, device_id=device_id, **kwargs)
+    raise NotImplementedError(
+        f"tracer module {name} (py_mod_name={py_mod_name}) has no HIP engine yet")
+
+
+class ModelState:
+    """state of all tracer modules; one engine (GPU stream) per module"""
+
+    __array_priority__ = 100
+
+    model_config_obj = None
+    time_range = (0.0, YEAR)
+    write_files = True      # keep the reference's NetCDF trail on disk
+    device_map = None       # optional {tracer_module_name: device ordinal}
+    _engines = None
+    _grid = None
+    _resident = {}
+    last_stats = None       # stats of the most recent comp_fcn, per module
+
+    # ---- class-level set-up (py_driver_2d/model_state.py:44-65) -----------------------
+    @classmethod
+    def reset_class(cls):
+        if cls._engines:
+            for eng in cls._engines.values():
+                eng.close()
+        cls._engines = None
+        cls._grid = None
+        cls._resident = {}
+        cls.model_config_obj = None
+
+    @classmethod
+    def _set_class_vars(cls):
+        if cls._engines is not None:
+            return
+        cfg = cls.model_config_obj
+        if cfg is None:
+            raise RuntimeError("ModelState.model_config_obj is None")
+        modelinfo = cfg.modelinfo
+        data, _ = ncio.read_file(modelinfo["grid_vars_fname"])
+        axes = []
+        for key in ("depth_axisname", "ypos_axisname"):
+            axisname = modelinfo[key]
+            edges_name = f"{axisname}_edges"
+            units = ncio.read_var_attrs(modelinfo["grid_vars_fname"], edges_name).get("units")
+            axes.append(SpatialAxis(axisname, data[edges_name], units))
+        cls.depth, cls.ypos = axes
+        cls._grid = Grid2d(cls.depth, cls.ypos, float(modelinfo["max_abs_vvel"]),
+                           float(modelinfo["horiz_mix_coeff"]))
+        cls._engines = {}
+        for name in modelinfo["tracer_module_names"].split(","):
+            module_def = cfg.tracer_module_defs[name]
+            device_id = (cls.device_map or {}).get(name, 0)
+            eng = _module_engine(name, module_def, cls._grid, device_id, modelinfo)
+            mask_name = next(iter(module_def["tracers"].values()))["region_mask_varname"]
+            gv = cfg.grid_vars[mask_name]
+            eng.set_region(gv["region_mask"], gv["grid_weight"])
+            cls._engines[name] = eng
+
+    # ---- construction ------------------------------------------------------------------
+    def __init__(self, fname, _modules=None):
+        self._set_class_vars()
+        cfg = self.model_config_obj
+        names = cfg.modelinfo["tracer_module_names"].split(",")
+        self.tracer_modules = np.empty(len(names), dtype=object)
+        if _modules is not None:
+            for ind, tms in enumerate(_modules):
+                self.tracer_modules[ind] = tms
+            return
+        cached = self._resident.get(os.path.abspath(fname)) if isinstance(fname, str) else None
+        for ind, name in enumerate(names):
+            module_def = cfg.tracer_module_defs[name]
+            eng = self._engines[name]
+            if cached is not None:
+                vec = cached[ind].copy()
+            else:
+                vec = eng.upload(self._load_host(fname, module_def, eng))
+            self.tracer_modules[ind] = TracerModuleState(name, module_def, eng, vec)
+
+    def _load_host(self, fname, module_def, eng):
+        """(tc, nz, ny) host values of one module from a file or pseudo-file
+        (py_driver_2d/tracer_module_state.py:30-69)"""
+        shape = (len(self.depth), len(self.ypos))
+        tracers = module_def["tracers"]
+        if fname == "zeros":
+            return np.zeros((len(tracers),) + shape)
+        if fname == "gen_init_iterate":
+            vals = []
+            for tracer_name, metadata in tracers.items():
+                src = metadata
+                if "init_iterate_vals" not in metadata:
+                    if "shadows" not in metadata:
+                        raise ValueError(f"gen_init_iterate failure for {tracer_name}")
+                    src = tracers[metadata["shadows"]]
+                column = np.interp(self.depth.mid, src["init_iterate_val_depths"],
+                                   src["init_iterate_vals"])
+                vals.append(np.broadcast_to(column[:, np.newaxis], shape))
+            return np.stack(vals)
+        data, _ = ncio.read_file(fname, list(tracers))
+        for tracer_name in tracers:
+            if data[tracer_name].shape != shape:
+                raise ValueError(f"unexpected dimension lengths for {tracer_name} in {fname}")
+        return np.stack([data[name] for name in tracers])
+
+    def _new(self, modules):
+        return type(self)(None, _modules=modules)
+
+    def copy(self):
+        return self._new([tms.copy() for tms in self.tracer_modules])
+
+    # ---- files ----------------------------------------------------------------------------
+    def dump(self, fname, caller=None):
+        """write the state to a NetCDF3 file (model_state_base.py:93-111) and remember a
+        device snapshot under that name"""
+        if fname is None:
+            return self
+        if caller is None:
+            raise ValueError("caller unknown")
+        self._resident[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
+        if self.write_files:
+            tracer_vals = {}
+            for tms in self.tracer_modules:
+                host = tms.get_tracer_vals_all()
+                for ind, tracer_name in enumerate(tms.tracer_names):
+                    tracer_vals[tracer_name] = host[ind]
+            history = ncio.history_stamp(f"{_class_name(self)}.dump", caller)
+            ncio.write_state_file(fname, [self.depth, self.ypos], tracer_vals, history)
+        return self
+
+    # ---- logging ----------------------------------------------------------------------------
+    def log_vals(self, msg, vals):
+        for ind, tms in enumerate(self.tracer_modules):
+            if isinstance(msg, list):
+                for msg_ind, submsg in enumerate(msg):
+                    tms.log_vals(submsg, vals[msg_ind, ind, ...])
+            else:
+                tms.log_vals(msg, vals[ind, ...])
+
+    def log(self, msg=None):
+        msg_full = ["mean", "norm"] if msg is None else [f"{msg},mean", f"{msg},norm"]
+        self.log_vals(msg_full, np.stack((self.mean(), self.norm())))
+
+    # ---- reductions ---------------------------------------------------------------------------
+    def _per_module(self, fcn):
+        res = np.empty((len(self.tracer_modules), self.model_config_obj.region_cnt))
+        for ind, tms in enumerate(self.tracer_modules):
+            res[ind, :] = fcn(ind, tms)
+        return res
+
+    def mean(self):
+        return self._per_module(lambda ind, tms: tms.mean())
+
+    def dot_prod(self, other):
+        return self._per_module(lambda ind, tms: tms.dot_prod(other.tracer_modules[ind]))
+
+    def norm(self):
+        return np.sqrt(self.dot_prod(self))
+
+    def mod_gram_schmidt(self, basis_cnt, fname_fcn, quantity):
+        """in-place modified Gram-Schmidt against basis files 0..basis_cnt-1
+        (model_state_base.py:365-377); the projections run back to back on the device"""
+        basis = [type(self)(fname_fcn(quantity, i_val)) for i_val in range(basis_cnt)]
+        h_val = np.empty((len(self.tracer_modules), basis_cnt, self.model_config_obj.region_cnt))
+        for ind, tms in enumerate(self.tracer_modules):
+            h_val[ind] = tms.eng.mgs(tms.vec, [b.tracer_modules[ind].vec for b in basis])
+        return h_val
+
+    # ---- arithmetic -------------------------------------------------------------------------------
+    def _binary(self, other, op):
+        if isinstance(other, ModelState):
+            mods = [op(a, b) for a, b in zip(self.tracer_modules, other.tracer_modules)]
+        elif isinstance(other, float):
+            mods = [op(a, other) for a in self.tracer_modules]
+        elif isinstance(other, np.ndarray) and other.shape[0] == len(self.tracer_modules):
+            mods = [op(a, other[ind, ...]) for ind, a in enumerate(self.tracer_modules)]
+        else:
+            return NotImplemented
+        if any(m is NotImplemented for m in mods):
+            return NotImplemented
+        return self._new(mods)
+
+    def _inplace(self, other, op):
+        for ind, tms in enumerate(self.tracer_modules):
+            if isinstance(other, ModelState):
+                arg = other.tracer_modules[ind]
+            elif isinstance(other, float):
+                arg = other
+            elif isinstance(other, np.ndarray) and other.shape[0] == len(self.tracer_modules):
+                arg = other[ind, ...]
+            else:
+                return NotImplemented
+            self.tracer_modules[ind] = op(tms, arg)
+        return self
+
+    def __neg__(self):
+        return self._new([-tms for tms in self.tracer_modules])
+
+    def __add__(self, other):
+        return self._binary(other, lambda a, b: a + b) if isinstance(other, ModelState) else NotImplemented
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self._binary(other, lambda a, b: a - b) if isinstance(other, ModelState) else NotImplemented
+
+    def __mul__(self, other):
+        return self._binary(other, lambda a, b: a * b)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return self._binary(other, lambda a, b: a / b)
+
+    def __iadd__(self, other):
+        if not isinstance(other, ModelState):
+            return NotImplemented
+        return self._inplace(other, lambda a, b: a.__iadd__(b))
+
+    def __isub__(self, other):
+        if not isinstance(other, ModelState):
+            return NotImplemented
+        return self._inplace(other, lambda a, b: a.__isub__(b))
+
+    def __imul__(self, other):
+        return self._inplace(other, lambda a, b: a.__imul__(b))
+
+    def __itruediv__(self, other):
+        return self._inplace(other, lambda a, b: a.__itruediv__(b))
+
+    # ---- the function whose root is sought ------------------------------------------------------------
+    def comp_fcn(self, res_fname, solver_state, hist_fname=None):
+        """one forward model year per tracer module on its GPU: F(x) = y(T) - x
+        (py_driver_2d/model_state.py:67-139)"""
+        logger = logging.getLogger(__name__)
+        fcn_complete_step = f"comp_fcn complete for {res_fname}"
+        if solver_state is not None and solver_state.step_logged(fcn_complete_step):
+            logger.debug('"%s" logged, returning result', fcn_complete_step)
+            return type(self)(res_fname)
+        if hist_fname is not None:
+            raise NotImplementedError(
+                "history (dense output) files are written by the Newton driver row, "
+                "not by the Krylov hot path")
+        mods, stats = [], []
+        for tms in self.tracer_modules:
+            fx, st, _ = tms.eng.comp_fcn(tms.vec)
+            mods.append(tms._like(fx))
+            stats.append(st)
+        type(self).last_stats = stats
+        res_ms = self._new(mods)
+        # zero_extra_tracers: no shadow tracers in the py_driver_2d modules handled here;
+        # apply_region_mask is fused into the kernel that forms y(T) - x
+        caller = f"{_class_name(self)}.comp_fcn_postprocess called from {_class_name(self)}.comp_fcn"
+        res_ms.dump(res_fname, caller)
+        if solver_state is not None:
+            solver_state.log_step(fcn_complete_step)
+            modelinfo = self.model_config_obj.modelinfo
+            if _strtobool(modelinfo.get("reinvoke", "False")):
+                cmd = [modelinfo["invoker_script_fname"], "--resume"]
+                logger.info('cmd="%s"', " ".join(cmd))
+                subprocess.Popen(cmd)
+                raise SystemExit
+        return res_ms
+
+    def apply_region_mask(self):
+        for tms in self.tracer_modules:
+            tms.eng.apply_region_mask(tms.vec)
+        return self
+
+    # ---- preconditioner ------------------------------------------------------------------------------------
+    def gen_precond_jacobian(self, hist_fname, precond_fname, solver_state):
+        """file(s) the preconditioner reads (model_state_base.py:404-481).  The iage
+        preconditioner needs nothing from it; the file carries the `time` axis of the
+        history file as in the reference."""
+        step = f"ModelStateBase.gen_precond_jacobian {precond_fname}"
+        if solver_state is not None and solver_state.step_logged(step, per_iteration=False):
+            return
+        if self.write_files:
+            if hist_fname is not None and os.path.exists(hist_fname):
+                data, _ = ncio.read_file(hist_fname, ["time"])
+                time = data["time"]
+            else:
+                time = np.linspace(self.time_range[0], self.time_range[1], 61)
+            attrs = {"long_name": "time", "units": "seconds since 0001-01-01", "calendar": "noleap"}
+            history = ncio.history_stamp(f"{_class_name(self)}.gen_precond_jacobian")
+            ncio.write_vars_file(precond_fname, {"time": len(time)},
+                                 {"time": (("time",), ">f8", attrs, time)}, history)
+        if solver_state is not None:
+            solver_state.log_step(step, per_iteration=False)
+
+    def apply_precond_jacobian(self, precond_fname, res_fname, solver_state):
+        """M^-1 self, module by module (py_driver_2d/model_state.py:235-270)"""
+        logger = logging.getLogger(__name__)
+        fcn_complete_step = f"apply_precond_jacobian complete for {res_fname}"
+        if solver_state is not None and solver_state.step_logged(fcn_complete_step):
+            logger.debug('"%s" logged, returning result', fcn_complete_step)
+            return type(self)(res_fname)
+        res_ms = self._new([tms._like(tms.eng.precond_apply(tms.vec)) for tms in self.tracer_modules])
+        if solver_state is not None:
+            solver_state.log_step(fcn_complete_step)
+        return res_ms.dump(res_fname, f"{_class_name(self)}.apply_precond_jacobian")
+
+    # ---- finite-difference Jacobian-vector product ---------------------------------------------------------
+    def comp_jacobian_fcn_state_prod(self, fcn, direction, res_fname, solver_state):
+        """(F(self + sigma d) - F(self)) / sigma with sigma = 1e-4 |self| per
+        (module, region); assumes |d| = 1 (model_state_base.py:492-527)"""
+        logger = logging.getLogger(__name__)
+        fcn_complete_step = f"comp_jacobian_fcn_state_prod complete for {res_fname}"
+        if solver_state.step_logged(fcn_complete_step):
+            logger.debug('"%s" logged, returning result', fcn_complete_step)
+            return type(self)(res_fname)
+        sigma = 1.0e-4 * self.norm()
+        sigma = np.where(sigma == 0.0, 1.0, sigma)
+        perturb_ms = self + sigma * direction
+        perturb_fcn_fname = os.path.join(
+            solver_state.get_workdir(), f"perturb_fcn_{os.path.basename(res_fname)}")
+        perturb_fcn = perturb_ms.comp_fcn(perturb_fcn_fname, solver_state)
+        caller = f"{_class_name(self)}.comp_jacobian_fcn_state_prod"
+        res = ((perturb_fcn - fcn) / sigma).dump(res_fname, caller)
+        solver_state.log_step(fcn_complete_step)
+        return res
+
+
+def lin_comb(res_type, coeff, fname_fcn, quantity):
+    """sum_j coeff[..., j, :] * state_j over the files <quantity>_00 ... (model_state_base.py:619-624);
+    a single fused kernel per tracer module"""
+    terms = [res_type(fname_fcn(quantity, j_val)) for j_val in range(coeff.shape[-2])]
+    mods = []
+    for ind, tms in enumerate(terms[0].tracer_modules):
+        vecs = [term.tracer_modules[ind].vec for term in terms]
+        mods.append(tms._like(tms.eng.lin_comb(vecs, coeff[ind])))
+    return terms[0]._new(mods)

@@ -313,21 +313,57 @@ class Iage(TracerModule):
         return ex
 
     def precond_matrix(self, time_range=(0.0, YEAR)):
-        """I - prod_k (I - dt J(t_k)), dt = T/3 (iage.py:78-90)"""
+        """I - prod_k (I - dt J(t_k)), dt = T/3 (iage.py:78-90), built with the same
+        scipy.sparse expressions as the reference (the result is extremely sensitive to
+        rounding, see `apply_precond_stable`)"""
         n = self.tc * self.model.nz * self.model.ny
         time_n = 3
-        dt = (time_range[1] - time_range[0]) / time_n
+        time_delta = (time_range[1] - time_range[0]) / time_n
         mat_id = sparse.identity(n)
         mat = sparse.identity(n)
-        for ind in range(time_n):
-            time = time_range[0] + (ind + 0.5) * dt
-            mat = mat @ (mat_id - dt * self.comp_jacobian(time))
-        return (mat_id - mat).tocsc()
+        for time_ind in range(time_n):
+            time = time_range[0] + (time_ind + 0.5) * time_delta
+            mat_tmp = time_delta * self.comp_jacobian(time)
+            mat = mat * (mat_id - mat_tmp)
+        return mat_id - mat
 
     def apply_precond(self, v, time_range=(0.0, YEAR)):
         """M^-1 v = spsolve(I - prod(I - dt J_k), v) - v (iage.py:91-93)"""
         res = sp_linalg.spsolve(self.precond_matrix(time_range), v)
         return res - v
+
+
+def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3):
+    """The SAME operator as `Iage.apply_precond`, M^-1 = (I - A_0 A_1 A_2)^-1 - I with
+    A_k = I - dt J(t_k), evaluated without forming the triple product: with
+    u_1 = A_0^-1 u_0, u_2 = A_1^-1 u_1, u_3 = A_2^-1 u_2 and u_0 - u_3 = v one gets the
+    time-periodic block system
+
+        [ A_0   0  -I ] [u_1]   [v]
+        [ -I  A_1   0 ] [u_2] = [0] ,     M^-1 v = -(u_3 + v)
+        [  0  -I  A_2 ] [u_3]   [0]
+
+    (exact-arithmetic identity: (I - A_0A_1A_2)^-1 v - v = -(I - G)^-1 v with
+    G = A_2^-1 A_1^-1 A_0^-1).  The block matrix is a diagonally dominant M-matrix, so
+    this form is backward stable, whereas the explicit product of the reference is
+    roundoff dominated beyond toy grids (tests/test_oracle_precond.py measures both).
+    The HIP preconditioner implements this form and is checked against it."""
+    n = v.size
+    dt = (time_range[1] - time_range[0]) / time_n
+    eye = sparse.identity(n, format="csr")
+    A = [eye - dt * module.comp_jacobian(time_range[0] + (k + 0.5) * dt)
+         for k in range(time_n)]
+    rows = []
+    for k in range(time_n):
+        row = [None] * time_n
+        row[k] = A[k]
+        row[(k - 1) % time_n] = -eye
+        rows.append(row)
+    big = sparse.bmat(rows, format="csc")
+    rhs = np.zeros(time_n * n)
+    rhs[:n] = v
+    u = sp_linalg.splu(big).solve(rhs)
+    return -(u[(time_n - 1) * n:] + v)
 
 
 def gen_init_iterate(model, knots_z=(55.0, 200.0), knots_v=(0.0, 2.0), tc=2):

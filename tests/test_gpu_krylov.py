@@ -1,0 +1,185 @@
+"""GPU parity of the preconditioner, the region-weighted algebra and the Krylov solver
+(through the ModelState / KrylovSolver mirrors -> C ABI -> HIP)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_iage, rel_err
+from oracle import krylov
+from oracle.model import apply_precond_stable
+
+pytestmark = pytest.mark.gpu
+
+BASE = os.path.join(os.path.dirname(__file__), "golden", "ref_baselines")
+
+
+def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    return iage_engine(Grid2d.default(nz, ny, vv, kh), **kw)
+
+
+def isclose_all(got, want, rtol=1.0e-7, atol=2.0e-9):
+    return bool(np.all(np.isclose(got, want, rtol=rtol, atol=atol)))
+
+
+@pytest.mark.parametrize("nz,ny,vv,kh", [(26, 26, 0.1, 1000.0), (20, 3, 0.0, 0.0), (70, 40, 0.1, 1000.0)])
+def test_precond_apply(nz, ny, vv, kh):
+    eng = make_engine(nz, ny, vv, kh)
+    _, tm = oracle_iage(nz, ny, vv, kh)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(2 * nz * ny)
+    got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    want = apply_precond_stable(tm, v)
+    assert rel_err(got, want) < 1e-9, rel_err(got, want)
+
+
+def test_precond_golden_within_reference_noise(golden_dir):
+    """against the reference formula's output: agreement is bounded by the reference's own
+    roundoff sensitivity (tests/test_oracle_precond.py), i.e. the CI tolerance 2e-3"""
+    g = np.load(f"{golden_dir}/precond_26x26.npz")
+    eng = make_engine(26, 26)
+    got = eng.download(eng.precond_apply(eng.upload(g["v"]))).reshape(-1)
+    P = 26 * 26
+    for tr in range(2):
+        s = slice(tr * P, (tr + 1) * P)
+        assert np.linalg.norm(got[s] - g["res"][s]) / np.linalg.norm(g["res"][s]) < 2.0e-3
+
+
+@pytest.mark.parametrize("nz,ny,column_regions", [(26, 26, False), (20, 7, True), (130, 9, True)])
+def test_region_algebra(nz, ny, column_regions):
+    eng = make_engine(nz, ny)
+    model, tm = oracle_iage(nz, ny)
+    weight = np.outer(model.depth.delta, model.ypos.delta)
+    mask = np.ones((nz, ny), dtype=np.int32)
+    if column_regions:
+        mask[:] = np.arange(1, ny + 1)[None, :]
+        mask[nz // 2:, 0] = 0  # some cells outside every region
+    eng.set_region(mask, weight)
+    reg = krylov.Regions(mask, weight)
+    mod = krylov.OracleModule(tm, reg)
+    rng = np.random.default_rng(4)
+    a, b = rng.standard_normal((2, 2 * nz * ny))
+    ad, bd = eng.upload(a), eng.upload(b)
+    assert rel_err(eng.dot(ad, bd), mod.dot(a, b)) < 1e-13
+    coef = rng.standard_normal(reg.nreg)
+    coef2 = rng.standard_normal(reg.nreg)
+    assert np.array_equal(eng.download(eng.scale(ad, coef)).reshape(-1), mod.scale(a, coef))
+    want = mod.scale(a, coef) + mod.scale(b, coef2)
+    assert np.array_equal(eng.download(eng.axpby(coef, ad, coef2, bd)).reshape(-1), want)
+    assert np.array_equal(eng.download(eng.diff_scale(ad, bd, coef)).reshape(-1), mod.scale(a - b, coef))
+    assert np.array_equal(eng.download(eng.apply_region_mask(ad.copy())).reshape(-1), mod.mask_out(a))
+    # lin_comb and modified Gram-Schmidt over a small basis
+    vecs = rng.standard_normal((4, 2 * nz * ny))
+    cf = rng.standard_normal((1, 4, reg.nreg))
+    want = krylov.lin_comb([mod], cf, [[v] for v in vecs])[0]
+    dv = [eng.upload(v) for v in vecs]
+    assert np.array_equal(eng.download(eng.lin_comb(dv, cf[0])).reshape(-1), want)
+    h_want, w_want = krylov.mod_gram_schmidt([mod], [a], [[v] for v in vecs])
+    wd = eng.upload(a)
+    h_got = eng.mgs(wd, dv)
+    assert rel_err(h_got, h_want[0]) < 1e-12
+    assert rel_err(eng.download(wd).reshape(-1), w_want[0]) < 1e-12
+
+
+def _read_state(fname):
+    from nk_ooc_amd import ncio
+
+    data, _ = ncio.read_file(fname, ["iage", "iage_slow_rest"])
+    return np.stack([data["iage"], data["iage_slow_rest"]]).reshape(-1)
+
+
+def _setup_run(tmp_path, nz, ny, extra_modelinfo=None, extra_solverinfo=None):
+    from nk_ooc_amd.model_config import ModelConfig
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+
+    cfg = make_config(str(tmp_path), nz, ny, extra_modelinfo=extra_modelinfo,
+                      extra_solverinfo=extra_solverinfo)
+    gen_grid_vars_file(cfg["modelinfo"])
+    ModelState.reset_class()
+    ModelState.model_config_obj = ModelConfig(cfg["modelinfo"])
+    return cfg, ModelState
+
+
+def test_krylov_column_regions_vs_reference_baselines(tmp_path):
+    """the ci_py_driver_2d_iage_column_regions case end to end on the GPU, compared with the
+    reference's committed files at the tolerances of its CI script"""
+    import json
+    import shutil
+
+    from nk_ooc_amd.krylov_solver import KrylovSolver
+
+    d = os.path.join(BASE, "ci_py_driver_2d_iage_column_regions")
+    cfg, ModelState = _setup_run(tmp_path, 20, 3, {"max_abs_vvel": "0.0", "horiz_mix_coeff": "0.0"})
+    iterate = ModelState(os.path.join(d, "init_iterate.nc"))
+    fcn = iterate.comp_fcn(os.path.join(str(tmp_path), "fcn_00.nc"), None)
+    solverinfo = dict(cfg["solverinfo"])
+    solverinfo["Krylov_workdir"] = os.path.join(str(tmp_path), "krylov_00")
+    solver = KrylovSolver(iterate, solverinfo, resume=False, rewind=False, hist_fname=None)
+    inc = solver.solve(os.path.join(str(tmp_path), "increment_00.nc"), fcn)
+    kdir = solverinfo["Krylov_workdir"]
+    assert isclose_all(_read_state(os.path.join(kdir, "precond_fcn_00.nc")),
+                       _read_state(os.path.join(d, "precond_fcn_00.nc")), rtol=2.0e-3)
+    assert isclose_all(_read_state(os.path.join(kdir, "basis_00.nc")),
+                       _read_state(os.path.join(d, "basis_00.nc")), atol=5.0e-5)
+    assert isclose_all(_read_state(os.path.join(kdir, "perturb_fcn_w_raw_00.nc")),
+                       _read_state(os.path.join(d, "perturb_fcn_w_raw_00.nc")), atol=5.0e-6)
+    assert isclose_all(_read_state(os.path.join(kdir, "krylov_res_00.nc")),
+                       _read_state(os.path.join(d, "krylov_res_00.nc")), rtol=1.9e-2)
+    # checkpoint trail
+    state = json.load(open(os.path.join(kdir, "Krylov_state.json")))
+    assert state["iteration"] in (1, 2)
+    assert "KrylovSolver._solve0" in state["step_log"]
+    assert f"00:comp_fcn complete for {kdir}/perturb_fcn_w_raw_00.nc" in state["step_log"]
+    assert f"00:comp_jacobian_fcn_state_prod complete for {kdir}/w_raw_00.nc" in state["step_log"]
+    assert np.asarray(state["beta"]["__ndarray__"]).shape == (1, 3)
+    hm = np.asarray(state["h_mat"]["__ndarray__"])
+    assert hm.shape == (1, state["iteration"] + 1, state["iteration"], 3)
+    for name in ("precond_00.nc", "w_raw_00.nc", "w_00.nc", "Krylov_stats.nc"):
+        assert os.path.exists(os.path.join(kdir, name)), name
+    # resume: a second solver over the same directory must not recompute anything
+    solver2 = KrylovSolver(iterate, solverinfo, resume=True, rewind=False, hist_fname=None)
+    assert solver2.get_iteration() == state["iteration"]
+    assert np.array_equal(inc.tracer_modules[0].get_tracer_vals_all().reshape(-1),
+                          _read_state(os.path.join(str(tmp_path), "increment_00.nc")))
+
+
+def test_krylov_26x26_vs_oracle(tmp_path):
+    """26x26, single region: GPU Krylov quantities against the oracle's Krylov loop run with
+    the same (stable) preconditioner.  Per-iteration quantities are compared; the FD-JVP
+    carries integrator noise (two free-running forward years differ by ~1e-6, divided by
+    sigma ~ 1e-4 |x|), hence the tolerances."""
+    from nk_ooc_amd.krylov_solver import KrylovSolver
+
+    cfg, ModelState = _setup_run(tmp_path, 26, 26, extra_solverinfo={"krylov_max_iter": "2", "krylov_rel_tol": "1.0e-8"})
+    model, tm = oracle_iage(26, 26)
+    weight = np.outer(model.depth.delta, model.ypos.delta)
+    mod = krylov.OracleModule(tm, krylov.Regions(np.ones((26, 26), dtype=np.int32), weight), precond="stable")
+    x_host = (np.stack([np.broadcast_to(np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])[:, None], (26, 26))] * 2)
+              + 0.1).reshape(-1)
+    fcn_host = mod.comp_fcn(x_host)
+    _, trace = krylov.krylov_solve([mod], [x_host], [fcn_host], rel_tol=1e-8, max_iter=2)
+
+    ModelState.write_files = False
+    try:
+        iterate = ModelState("zeros")
+        iterate.tracer_modules[0].eng.upload(x_host, out=iterate.tracer_modules[0].vec)
+        fcn = iterate.comp_fcn(os.path.join(str(tmp_path), "fcn_00.nc"), None)
+        got_fcn = fcn.tracer_modules[0].get_tracer_vals_all().reshape(-1)
+        assert np.allclose(got_fcn, fcn_host, rtol=1e-3, atol=1e-6)
+        solverinfo = dict(cfg["solverinfo"])
+        solverinfo["Krylov_workdir"] = os.path.join(str(tmp_path), "krylov_00")
+        solver = KrylovSolver(iterate, solverinfo, resume=False, rewind=False, hist_fname=None)
+        solver.solve(os.path.join(str(tmp_path), "increment_00.nc"), fcn)
+        st = solver._solver_state
+        beta = st.get_value_saved_state("beta")
+        h_mat = st.get_value_saved_state("h_mat")
+    finally:
+        ModelState.write_files = True
+    assert st.get_iteration() == 2
+    assert rel_err(beta, trace["beta"]) < 1e-4
+    assert h_mat.shape == trace["h_mat"][-1].shape == (1, 3, 2, 1)
+    assert rel_err(h_mat, trace["h_mat"][-1]) < 2e-2

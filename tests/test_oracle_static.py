@@ -1,0 +1,61 @@
+"""The oracle's grid / coefficient / tendency / Jacobian restatement against golden
+vectors generated from the genuine reference functions (tests/golden/gen_golden.py)."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from helpers import oracle_iage
+
+TAGS = ["26x26", "30x30", "70x40", "20x3_columns"]
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_static_fields_bitwise(golden_dir, tag):
+    g = np.load(f"{golden_dir}/static_{tag}.npz")
+    model, tm = oracle_iage(int(g["nz"]), int(g["ny"]), float(g["max_abs_vvel"]),
+                            float(g["horiz_mix_coeff"]))
+    for ax in (model.depth, model.ypos):
+        for nm in ("edges", "mid", "delta", "delta_r", "delta_mid", "delta_mid_r"):
+            assert np.array_equal(getattr(ax, nm), g[f"{ax.name}_{nm}"]), (ax.name, nm)
+    for nm in ("stream", "vvel", "wvel", "hmix_coeff"):
+        assert np.array_equal(getattr(model, nm), g[nm]), nm
+    for i, t in enumerate(g["times"]):
+        assert np.array_equal(model.bldepth(t), g["bldepth"][i])
+        assert np.array_equal(model.vmix_coeff(t), g["vmix_coeff"][i])
+        assert np.array_equal(tm.comp_tend(t, g["y"]), g["tend"][i])
+        jac = tm.comp_jacobian(t).tocsr()
+        want = sparse.csr_matrix((g[f"jac{i}_data"], g[f"jac{i}_indices"], g[f"jac{i}_indptr"]),
+                                 shape=jac.shape)
+        diff = jac - want
+        assert diff.nnz == 0 or abs(diff).max() == 0.0
+
+
+@pytest.mark.parametrize("tag", TAGS[:2])
+def test_remap_loop_form(golden_dir, tag):
+    """the vectorised conservative remap equals the literal loop restatement"""
+    g = np.load(f"{golden_dir}/static_{tag}.npz")
+    model, _ = oracle_iage(int(g["nz"]), int(g["ny"]))
+    for t in g["times"]:
+        bld = model.bldepth(t)
+        vec = model._remap_ramp(bld)
+        loop = np.stack([model.remap_ramp_loop(x) for x in bld], axis=1)
+        assert np.array_equal(vec, loop)
+
+
+def test_tend_is_affine_with_jacobian():
+    """comp_tend(y) = J y + s exactly for iage (reference probe in SURVEY 8c)"""
+    model, tm = oracle_iage(12, 9)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(2 * 12 * 9)
+    t = 0.37 * 365 * 86400.0
+    jac = tm.comp_jacobian(t)
+    src = tm.comp_tend(t, np.zeros_like(y))
+    assert np.max(np.abs(tm.comp_tend(t, y) - (jac @ y + src))) < 1e-15 * np.max(np.abs(jac @ y))
+
+
+def test_lstsq_known_answers(golden_dir):
+    from oracle.krylov import basis_coeffs
+
+    g = np.load(f"{golden_dir}/lstsq.npz")
+    for case in range(3):
+        assert np.array_equal(basis_coeffs(g[f"beta{case}"], g[f"h{case}"]), g[f"coeff{case}"])
