@@ -139,6 +139,12 @@ int nk2d_lin_comb(nk2d_ctx* ctx, nk2d_vec out, int32_t n, const nk2d_vec* vecs,
 int nk2d_mgs(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* h_out);
 int nk2d_apply_region_mask(nk2d_ctx* ctx, nk2d_vec v);
 
+/* Measurement plumbing (bench.py): time every every_n-th launch of the dominant kernel
+   (the line-relaxation sweep) with a HIP event pair on the context's stream, and count the
+   algorithmic bytes of all sweep launches.  every_n = 0 switches sampling off. */
+int nk2d_profile_reset(nk2d_ctx* ctx, int32_t every_n);
+int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* launches, double* bytes);
+
 /* block until every operation queued on the context's stream has finished */
 int nk2d_sync(nk2d_ctx* ctx);
 /* the context's HIP stream (hipStream_t as void*), for event timing by the caller */

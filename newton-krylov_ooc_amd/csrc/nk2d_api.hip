@@ -82,6 +82,39 @@ extern "C" int nk2d_sync(nk2d_ctx* c) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// sampled timing of the dominant kernel (line-relaxation sweep) with HIP events on the
+// context's own stream
+// ---------------------------------------------------------------------------------
+extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    const size_t want = every_n > 0 ? 2 * 8192 : 0;
+    while (c->prof_ev.size() < want) {
+        hipEvent_t e;
+        NK2D_CHECK(c, hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_every = every_n;
+    c->prof_used = 0;
+    c->prof_ms_sum = 0.0;
+    c->prof_cnt = 0;
+    c->sweep_launches = 0;
+    c->sweep_bytes = 0.0;
+    return 0;
+}
+
+extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, int64_t* launches, double* bytes) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_TRY(nk2d_profile_collect(c));
+    if (avg_us) *avg_us = c->prof_cnt > 0 ? 1000.0 * c->prof_ms_sum / (double)c->prof_cnt : 0.0;
+    if (samples) *samples = c->prof_cnt;
+    if (launches) *launches = c->sweep_launches;
+    if (bytes) *bytes = c->sweep_bytes;
+    return 0;
+}
+
 static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->d = *desc;
     c->nz = desc->nz; c->ny = desc->ny; c->tc = desc->tc;
@@ -192,6 +225,12 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->stage_elems = 0;
     c->precond = nullptr;
     c->st = nk2d_stats();
+    c->prof_every = 0;
+    c->prof_used = 0;
+    c->prof_ms_sum = 0.0;
+    c->prof_cnt = 0;
+    c->sweep_launches = 0;
+    c->sweep_bytes = 0.0;
     *out = c;  // returned even on failure so that nk2d_last_error can be read
     return create_impl(c, desc);
 }
@@ -207,6 +246,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF};
     for (double* b : bufs)
         if (b) hipFree(b);
+    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
     if (c->MASK) hipFree(c->MASK);
     if (c->hRED) hipHostFree(c->hRED);
     if (c->stream) hipStreamDestroy(c->stream);

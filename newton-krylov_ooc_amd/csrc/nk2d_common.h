@@ -77,6 +77,15 @@ struct nk2d_ctx {
 
     // counters of the running comp_fcn
     nk2d_stats st;
+
+    // sampled HIP-event timing of the line-relaxation sweep kernel (nk2d_profile_*)
+    int prof_every;
+    std::vector<hipEvent_t> prof_ev;  // start/stop pairs
+    size_t prof_used;                 // events in use (2 per sample)
+    double prof_ms_sum;
+    int64_t prof_cnt;
+    int64_t sweep_launches;           // since the last nk2d_profile_reset
+    double sweep_bytes;               // algorithmic bytes of those launches
 };
 
 #define NK2D_CHECK(ctx, call)                                                        \
@@ -301,6 +310,7 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
+int nk2d_profile_collect(nk2d_ctx* c);
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
 int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci);
 int nk2d_r_newton_update(nk2d_ctx* c, int buf);

@@ -458,10 +458,38 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
     A.first = first ? 1 : 0;
     if (A.ntasks == 0) return 0;
     DevP P = make_devp(c);
+    // algorithmic bytes of this launch: Jacobian planes once per ypos column, and per
+    // (system, tracer) column the right-hand side, the new iterate and (after the first
+    // sweep) the previous iterate of the neighbours, counted once
+    {
+        const double cells = (double)c->nz * c->ny;
+        const double vec_words = (first ? 2.0 : 3.0) * ((do_real ? 1.0 : 0.0) + (do_cplx ? 2.0 : 0.0)) * c->tc;
+        c->sweep_bytes += 8.0 * cells * ((first ? 3.0 : 5.0) + vec_words);
+        c->sweep_launches++;
+    }
+    const bool sample = c->prof_every > 0 && (c->sweep_launches % c->prof_every) == 0 &&
+                        c->prof_used + 2 <= c->prof_ev.size();
+    if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_sweep<EE>, dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
+    if (sample) {
+        NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
+        c->prof_used += 2;
+    }
     c->st.nlaunch++;
     c->st.nsweeps++;
+    return 0;
+}
+
+// fold the finished event pairs into the running average (stream must be idle)
+int nk2d_profile_collect(nk2d_ctx* c) {
+    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+        float ms = 0.f;
+        NK2D_CHECK(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+        c->prof_ms_sum += ms;
+        c->prof_cnt++;
+    }
+    c->prof_used = 0;
     return 0;
 }
 

@@ -357,6 +357,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         NK2D_CHECK(c, hipMemsetAsync(fx, 0, sizeof(double) * c->nv, c->stream));
     }
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_TRY(nk2d_profile_collect(c));
     c->st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = c->st;
     return 0;

@@ -186,6 +186,19 @@ class ModuleEngine:
         sched = rec[: recn.value].copy() if record else None
         return out, stats.as_dict(), sched
 
+    # ---- sampled timing of the dominant kernel ----------------------------------------
+    def profile_reset(self, every_n):
+        self._chk(self._lib.nk2d_profile_reset(self._ctx, int(every_n)))
+
+    def profile_read(self):
+        avg = ctypes.c_double()
+        samples, launches = ctypes.c_int64(), ctypes.c_int64()
+        nbytes = ctypes.c_double()
+        self._chk(self._lib.nk2d_profile_read(self._ctx, ctypes.byref(avg), ctypes.byref(samples),
+                                              ctypes.byref(launches), ctypes.byref(nbytes)))
+        return {"avg_us": avg.value, "samples": samples.value, "launches": launches.value,
+                "bytes": nbytes.value}
+
     # ---- preconditioner -----------------------------------------------------------
     def precond_setup(self):
         self._chk(self._lib.nk2d_precond_setup(self._ctx))
