@@ -143,7 +143,15 @@ int nk2d_apply_region_mask(nk2d_ctx* ctx, nk2d_vec v);
    (the line-relaxation sweep) with a HIP event pair on the context's stream, and count the
    algorithmic bytes of all sweep launches.  every_n = 0 switches sampling off. */
 int nk2d_profile_reset(nk2d_ctx* ctx, int32_t every_n);
-int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* launches, double* bytes);
+/* avg_us: mean elapsed time of the sampled event pairs; overhead_us: what an EMPTY event
+   pair reads on this stream (subtract it to get the kernel's own duration) */
+int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
+                      double* overhead_us);
+
+/* run-time options: "lin_tol" (relative accuracy of the inner line-relaxation solves),
+   "device_ctl" (1: take the Newton convergence decisions on the device and read back once
+   per step attempt instead of once per Newton iteration) */
+int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);
 
 /* block until every operation queued on the context's stream has finished */
 int nk2d_sync(nk2d_ctx* ctx);

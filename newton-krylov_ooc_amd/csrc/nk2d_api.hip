@@ -76,6 +76,17 @@ extern "C" const char* nk2d_last_error(const nk2d_ctx* ctx) { return ctx ? ctx->
 
 extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
+    const std::string key(name ? name : "");
+    if (key == "device_ctl") { c->device_ctl = value != 0.0; return 0; }
+    if (key == "lin_tol") {
+        if (!(value > 0.0 && value < 1.0)) return nk2d_fail(c, "nk2d_set_option: lin_tol must be in (0, 1)");
+        c->d.lin_tol = value;
+        return 0;
+    }
+    return nk2d_fail(c, "nk2d_set_option: unknown option " + key);
+}
+
 extern "C" int nk2d_sync(nk2d_ctx* c) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
@@ -95,6 +106,23 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
         NK2D_CHECK(c, hipEventCreate(&e));
         c->prof_ev.push_back(e);
     }
+    // calibrate: what an event pair reads with nothing between the two records
+    c->prof_overhead_ms = 0.0;
+    if (every_n > 0) {
+        const int ncal = 64;
+        for (int i = 0; i < ncal; ++i) {
+            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i], c->stream));
+            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i + 1], c->stream));
+        }
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        double sum = 0.0;
+        for (int i = 0; i < ncal; ++i) {
+            float ms = 0.f;
+            NK2D_CHECK(c, hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+            sum += ms;
+        }
+        c->prof_overhead_ms = sum / ncal;
+    }
     c->prof_every = every_n;
     c->prof_used = 0;
     c->prof_ms_sum = 0.0;
@@ -104,11 +132,13 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     return 0;
 }
 
-extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, int64_t* launches, double* bytes) {
+extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
+                                 double* overhead_us) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     NK2D_TRY(nk2d_profile_collect(c));
     if (avg_us) *avg_us = c->prof_cnt > 0 ? 1000.0 * c->prof_ms_sum / (double)c->prof_cnt : 0.0;
+    if (overhead_us) *overhead_us = 1000.0 * c->prof_overhead_ms;
     if (samples) *samples = c->prof_cnt;
     if (launches) *launches = c->sweep_launches;
     if (bytes) *bytes = c->sweep_bytes;
@@ -168,6 +198,11 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
+    NK2D_TRY(dev_alloc(c, &c->DCTL, (size_t)8));
+    NK2D_TRY(dev_alloc(c, &c->ICTL, (size_t)8));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hCTL, 128));
+    c->cur_guard = nullptr;
+    c->device_ctl = 0;
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
@@ -228,6 +263,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->prof_every = 0;
     c->prof_used = 0;
     c->prof_ms_sum = 0.0;
+    c->prof_overhead_ms = 0.0;
     c->prof_cnt = 0;
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
@@ -237,19 +273,22 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
 
 extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->dev);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->dev);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     nk2d_precond_free(c);
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF};
     for (double* b : bufs)
-        if (b) hipFree(b);
-    for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
-    if (c->MASK) hipFree(c->MASK);
-    if (c->hRED) hipHostFree(c->hRED);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (b) (void)hipFree(b);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->MASK) (void)hipFree(c->MASK);
+    if (c->hRED) (void)hipHostFree(c->hRED);
+    if (c->hCTL) (void)hipHostFree(c->hCTL);
+    if (c->DCTL) (void)hipFree(c->DCTL);
+    if (c->ICTL) (void)hipFree(c->ICTL);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

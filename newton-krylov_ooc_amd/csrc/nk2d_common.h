@@ -59,6 +59,14 @@ struct nk2d_ctx {
     // Radau work vectors (nv each unless noted)
     double *Y, *YOLD, *F, *Z /*3nv*/, *ZP /*3nv*/, *W /*3nv*/;
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
+    // device-side Newton control block (see nk2d_kernels.hip, k_reduce_newton):
+    //   DCTL: [0] dW_norm_old [1] rate [2] dW_norm [3] err_sum [4] newton_tol [5] 3n [6] n
+    //   ICTL: [0] k [1] has_old [2] has_rate [3] done [4] converged [5] skip_err [6] n_iter
+    double* DCTL;
+    int* ICTL;
+    double* hCTL;           // pinned mirror: 8 doubles followed by 8 ints
+    const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
+    int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
     double* RED;     // reduced scalars (device)
@@ -83,6 +91,7 @@ struct nk2d_ctx {
     std::vector<hipEvent_t> prof_ev;  // start/stop pairs
     size_t prof_used;                 // events in use (2 per sample)
     double prof_ms_sum;
+    double prof_overhead_ms;          // elapsed time of an EMPTY event pair (calibration)
     int64_t prof_cnt;
     int64_t sweep_launches;           // since the last nk2d_profile_reset
     double sweep_bytes;               // algorithmic bytes of those launches
@@ -320,6 +329,10 @@ int nk2d_r_err_norm(nk2d_ctx* c, const double* err);
 int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys);
 int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out);
 int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out);
+int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total);
+int nk2d_r_reduce_newton(nk2d_ctx* c);
+int nk2d_r_reduce_err(nk2d_ctx* c);
+int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8);
 // nk2d_radau.hip
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,
                     int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n);

@@ -16,6 +16,7 @@ struct DevP {
     const double *VV, *KH, *WT, *WB, *DZR, *ZM0, *ZM1, *DM, *DMR, *DYR, *BLDMAX;
     double surf[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
     double atol, rtol;
+    const int* guard;  // guarded kernels return at once when *guard != 0
 };
 
 static DevP make_devp(const nk2d_ctx* c) {
@@ -27,6 +28,7 @@ static DevP make_devp(const nk2d_ctx* c) {
     for (int i = 0; i < NK2D_MAX_TRACERS; ++i) { p.surf[i] = c->d.surf_rate[i]; p.decay[i] = c->d.decay_rate[i]; }
     p.csrc = c->d.const_src;
     p.atol = c->d.atol; p.rtol = c->d.rtol;
+    p.guard = c->cur_guard;
     return p;
 }
 
@@ -44,6 +46,9 @@ __constant__ double cP[3][3] = {
     {-1.382142733160748, 10.296258113743303, -8.914115380582556},
     {0.3333333333333333, -2.6666666666666665, 3.3333333333333335}};
 __constant__ double cE[3] = {-10.048809399827414, 1.382142733160748, -0.3333333333333333};
+
+#define GUARD_RETURN(g) \
+    if ((g) != nullptr && *(g) != 0) return;
 
 #define TASK_PROLOGUE(ntasks)                                              \
     const int lane = threadIdx.x & 63;                                     \
@@ -375,6 +380,7 @@ struct SweepArgs {
 
 template <int E>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
+    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(A.ntasks)
     const bool is_c = task >= A.nreal;
     const int col = is_c ? task - A.nreal : task;
@@ -543,6 +549,94 @@ int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
 }
 
 // ---------------------------------------------------------------------------------
+// device-side control of the simplified Newton iteration (radau.py:113-133): the final
+// reduction of the ||dW / scale|| partials also takes SciPy's convergence / divergence
+// decisions, so that the host can queue all NEWTON_MAXITER iterations and the error
+// estimate without reading anything back; later kernels test the `done` / `skip_err`
+// flags at entry and return at once.
+// ---------------------------------------------------------------------------------
+__device__ double block_sum(const double* __restrict__ part, int ntasks, double* sh) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ntasks; i += NK2D_BLOCK) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+__global__ void k_ctl_reset(double* __restrict__ d, int* __restrict__ ic, double tol, double n_total) {
+    if (threadIdx.x == 0) {
+        d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 0.0; d[4] = tol; d[5] = 3.0 * n_total; d[6] = n_total;
+        ic[0] = 0; ic[1] = 0; ic[2] = 0; ic[3] = 0; ic[4] = 0; ic[5] = 1; ic[6] = 0;
+    }
+}
+
+__global__ void k_reduce_newton(const double* __restrict__ part, int ntasks, double* __restrict__ d, int* __restrict__ ic) {
+    __shared__ double sh[NK2D_BLOCK];
+    if (ic[3] != 0) return;  // already decided
+    const double sum = block_sum(part, ntasks, sh);
+    if (threadIdx.x != 0) return;
+    const int k = ic[0];
+    const double tol = d[4];
+    const double dW_norm = sqrt(sum) / sqrt(d[5]);
+    d[2] = dW_norm;
+    bool has_rate = ic[2] != 0;
+    double rate = d[1];
+    if (!(dW_norm == dW_norm)) { ic[3] = 1; ic[6] = k + 1; return; }  // NaN: diverged
+    if (ic[1] != 0) { rate = dW_norm / d[0]; has_rate = true; d[1] = rate; ic[2] = 1; }
+    if (has_rate) {
+        double pw = 1.0;
+        for (int i = 0; i < 6 - k; ++i) pw *= rate;  // rate ** (NEWTON_MAXITER - k)
+        if (rate >= 1.0 || pw / (1.0 - rate) * dW_norm > tol) { ic[3] = 1; ic[6] = k + 1; return; }
+    }
+    if (dW_norm == 0.0 || (has_rate && rate / (1.0 - rate) * dW_norm < tol)) {
+        ic[3] = 1; ic[4] = 1; ic[5] = 0; ic[6] = k + 1;
+        return;
+    }
+    d[0] = dW_norm;
+    ic[1] = 1;
+    ic[0] = k + 1;
+    if (k + 1 >= 6) { ic[3] = 1; ic[6] = 6; }
+}
+
+__global__ void k_reduce_err(const double* __restrict__ part, int ntasks, double* __restrict__ d, const int* __restrict__ ic) {
+    __shared__ double sh[NK2D_BLOCK];
+    if (ic[5] != 0) return;
+    const double sum = block_sum(part, ntasks, sh);
+    if (threadIdx.x == 0) d[3] = sum;
+}
+
+int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total) {
+    hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(64), 0, c->stream, c->DCTL, c->ICTL, newton_tol, n_total);
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_reduce_newton(nk2d_ctx* c) {
+    hipLaunchKernelGGL(k_reduce_newton, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, c->PART, c->ncol, c->DCTL, c->ICTL);
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_reduce_err(nk2d_ctx* c) {
+    hipLaunchKernelGGL(k_reduce_err, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, c->PART, c->ncol, c->DCTL, c->ICTL);
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8) {
+    NK2D_CHECK(c, hipMemcpyAsync(c->hCTL, c->DCTL, 64, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->hCTL + 8, c->ICTL, 32, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(dctl8, c->hCTL, 64);
+    std::memcpy(ictl8, c->hCTL + 8, 32);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // Radau IIA elementwise kernels (scipy/integrate/_ivp/radau.py)
 // ---------------------------------------------------------------------------------
 // Z0 from the previous step's collocation polynomial, W = TI Z0 (radau.py:445-448,95)
@@ -596,6 +690,7 @@ struct StageArgs {
 
 template <int E>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_stage(DevP P, StageArgs A) {
+    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
@@ -645,6 +740,7 @@ template <int E>
 __global__ void k_newton_update(DevP P, const double* __restrict__ y, const double* __restrict__ xr,
                                 const double* __restrict__ xcr, const double* __restrict__ xci, double* __restrict__ w,
                                 double* __restrict__ z, size_t nv, double* __restrict__ part) {
+    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     double yy[E], d0[E], d1[E], d2[E], w0[E], w1[E], w2[E];
     load_col<E>(y, task, lane, yy);
@@ -681,7 +777,8 @@ __global__ void k_newton_update(DevP P, const double* __restrict__ y, const doub
 // error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
 template <int E>
 __global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
-                          double* __restrict__ out) {
+                          double* __restrict__ out, const int* __restrict__ guard) {
+    GUARD_RETURN(guard)
     TASK_PROLOGUE(ncol)
     double ff[E], z0[E], z1[E], z2[E];
     load_col<E>(f, task, lane, ff);
@@ -737,6 +834,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
 template <int E>
 __global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
                            const double* __restrict__ err, double* __restrict__ part) {
+    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     double yy[E], z2[E], er[E];
     load_col<E>(y, task, lane, yy);
@@ -844,7 +942,7 @@ int nk2d_r_newton_update(nk2d_ctx* c, int buf) {
 }
 int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
-                                               c->ncol, c->F, c->Z, c->nv, h, c->BR));
+                                               c->ncol, c->F, c->Z, c->nv, h, c->BR, c->cur_guard));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;

@@ -190,7 +190,7 @@ void nk2d_precond_free(nk2d_ctx* c) {
     if (!pc) return;
     double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV};
     for (double* b : bufs)
-        if (b) hipFree(b);
+        if (b) (void)hipFree(b);
     delete pc;
     c->precond = nullptr;
 }

@@ -43,6 +43,7 @@ struct Ctl {
     double dense_t_old, dense_h;
     double newton_tol, max_step;
     int m_real, m_cplx;  // sweeps per solve for the current h_lu
+    bool device_ctl;     // Newton decisions on the device (no per-iteration read-back)
     double n_total;      // number of unknowns (tc*nz*ny)
 };
 
@@ -111,8 +112,24 @@ int stage_planes(Ctl& s, double t, double h) {
     return nk2d_k_vmix(s.c, 3, times, out);
 }
 
-// simplified Newton iterations on the collocation system (radau.py:48-136).
-// force_iters >= 0: run exactly that many iterations without any test (replay).
+// Replay: exactly n_iters simplified-Newton iterations, no tests, nothing read back.
+int newton_fixed(Ctl& s, double h, int n_iters) {
+    nk2d_ctx* c = s.c;
+    const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+    for (int k = 0; k < n_iters; ++k) {
+        NK2D_TRY(nk2d_r_stage(c, mreal, mcr, mci));
+        c->st.nfev += 3;
+        int buf = 0;
+        NK2D_TRY(solve_systems(s, true, true, &buf));
+        NK2D_TRY(nk2d_r_newton_update(c, buf));
+        c->st.nnewton++;
+    }
+    return 0;
+}
+
+// simplified Newton iterations on the collocation system (radau.py:48-136), decisions on
+// the host: one scalar read-back per iteration.  force_iters is unused here (replay has
+// newton_fixed) but kept for symmetry.
 int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, double* rate_out, bool* have_rate) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
@@ -146,6 +163,45 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     else *n_iter = k + 1;
     *rate_out = rate;
     *have_rate = has_rate;
+    return 0;
+}
+
+// One step attempt queued without any host round trip (radau.py:445-483): Z0 from the
+// dense output, up to NEWTON_MAXITER simplified-Newton iterations whose convergence /
+// divergence tests run on the device (k_reduce_newton), and -- if the iteration converged --
+// the error estimate.  Kernels after the decision return at entry.  ONE read-back at the
+// end delivers (converged, n_iter, rate, sum((error/scale)^2)).
+int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* rate, bool* have_rate,
+            double* err_sum, int* err_buf) {
+    nk2d_ctx* c = s.c;
+    const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+    c->cur_guard = nullptr;
+    NK2D_TRY(predict(s, t, h));
+    NK2D_TRY(nk2d_r_ctl_reset(c, s.newton_tol, s.n_total));
+    c->cur_guard = c->ICTL + 3;  // done
+    for (int k = 0; k < NEWTON_MAXITER; ++k) {
+        NK2D_TRY(nk2d_r_stage(c, mreal, mcr, mci));
+        int buf = 0;
+        NK2D_TRY(solve_systems(s, true, true, &buf));
+        NK2D_TRY(nk2d_r_newton_update(c, buf));
+        NK2D_TRY(nk2d_r_reduce_newton(c));
+    }
+    c->cur_guard = c->ICTL + 5;  // skip_err (cleared by a converged Newton iteration)
+    NK2D_TRY(nk2d_r_err_rhs(c, h));
+    NK2D_TRY(solve_systems(s, true, false, err_buf));
+    NK2D_TRY(nk2d_r_err_norm(c, c->XR[*err_buf]));
+    NK2D_TRY(nk2d_r_reduce_err(c));
+    c->cur_guard = nullptr;
+    double d[8];
+    int ic[8];
+    NK2D_TRY(nk2d_r_ctl_read(c, d, ic));
+    *converged = ic[4] != 0;
+    *n_iter = ic[6];
+    *rate = d[1];
+    *have_rate = ic[2] != 0;
+    *err_sum = d[3];
+    c->st.nfev += 3 * (int64_t)ic[6];
+    c->st.nnewton += ic[6];
     return 0;
 }
 
@@ -219,10 +275,16 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             h_abs = std::fabs(h);
             NK2D_TRY(stage_planes(s, t, h));
             bool converged = false;
+            double err_sum = 0.0;
+            int buf = 0;
             while (!converged) {
-                NK2D_TRY(predict(s, t, h));
                 if (!s.have_lu) set_lu(s, h);
-                NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate));
+                if (s.device_ctl) {
+                    NK2D_TRY(attempt(s, t, h, &converged, &n_iter, &rate, &have_rate, &err_sum, &buf));
+                } else {
+                    NK2D_TRY(predict(s, t, h));
+                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate));
+                }
                 if (!converged) {
                     if (s.current_jac) break;
                     NK2D_TRY(refresh_jac(s, t, true));  // KV[3] holds the plane at the current t
@@ -236,13 +298,15 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 s.have_lu = false;
                 continue;
             }
-            // error estimate (radau.py:477-487)
-            NK2D_TRY(nk2d_r_err_rhs(c, h));
-            int buf = 0;
-            NK2D_TRY(solve_systems(s, true, false, &buf));
-            NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
-            double sum = 0;
-            NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
+            // error estimate (radau.py:477-487); with device control its first pass was queued
+            // together with the attempt
+            double sum = err_sum;
+            if (!s.device_ctl) {
+                NK2D_TRY(nk2d_r_err_rhs(c, h));
+                NK2D_TRY(solve_systems(s, true, false, &buf));
+                NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
+                NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
+            }
             err = rms_from_sum(sum, s.n_total);
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             if (rejected && err > 1) {
@@ -315,8 +379,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n) {
         if (!have || h_lu != h_lu_cur) { set_lu(s, h_lu); h_lu_cur = h_lu; have = true; }
         NK2D_TRY(stage_planes(s, t, h));
         NK2D_TRY(predict(s, t, h));
-        bool conv; int ni; double rate; bool hr;
-        NK2D_TRY(newton(s, h, n_iter, &conv, &ni, &rate, &hr));
+        NK2D_TRY(newton_fixed(s, h, n_iter));
         NK2D_TRY(commit_step(s, t, t_new));
     }
     return 0;
@@ -340,6 +403,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.have_lu = false; s.have_dense = false;
     s.h_lu = 0; s.dense_t_old = 0; s.dense_h = 0;
     s.m_real = s.m_cplx = 1;
+    s.device_ctl = c->device_ctl != 0;
     NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
     if (s.t1 > s.t) {
         // f = fun(t0, y0);  J = jac(t0, y0)

@@ -135,6 +135,9 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_vec_download(self._ctx, vec.ptr, _dp(host)))
         return host
 
+    def set_option(self, name, value):
+        self._chk(self._lib.nk2d_set_option(self._ctx, name.encode(), float(value)))
+
     def sync(self):
         self._chk(self._lib.nk2d_sync(self._ctx))
 
@@ -193,11 +196,12 @@ class ModuleEngine:
     def profile_read(self):
         avg = ctypes.c_double()
         samples, launches = ctypes.c_int64(), ctypes.c_int64()
-        nbytes = ctypes.c_double()
+        nbytes, ovh = ctypes.c_double(), ctypes.c_double()
         self._chk(self._lib.nk2d_profile_read(self._ctx, ctypes.byref(avg), ctypes.byref(samples),
-                                              ctypes.byref(launches), ctypes.byref(nbytes)))
+                                              ctypes.byref(launches), ctypes.byref(nbytes),
+                                              ctypes.byref(ovh)))
         return {"avg_us": avg.value, "samples": samples.value, "launches": launches.value,
-                "bytes": nbytes.value}
+                "bytes": nbytes.value, "event_overhead_us": ovh.value}
 
     # ---- preconditioner -----------------------------------------------------------
     def precond_setup(self):

@@ -1,0 +1,34 @@
+"""N > 1 path on the CPU: world_size-2 gloo run of the module-per-rank Krylov loop
+(nk_ooc_amd.dist): modules are partitioned over ranks and only the stopping test is a
+collective (reference: `converged(...).all()` over all modules, krylov_solver.py:159)."""
+import json
+import os
+import subprocess
+import sys
+
+from nk_ooc_amd.dist import partition_modules
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_modules():
+    names = ["iage", "phosphorus", "forced_a", "forced_b", "forced_c"]
+    parts = partition_modules(names, 2)
+    assert parts == [["iage", "forced_a", "forced_c"], ["phosphorus", "forced_b"]]
+    assert sorted(sum(partition_modules(names, 4), [])) == sorted(names)
+    assert partition_modules(names, 8)[5:] == [[], [], []]
+
+
+def test_world_size_2_gloo(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = [json.load(open(tmp_path / f"result{r}.json")) for r in range(2)]
+    assert out[0]["modules"] == ["iage"] and out[1]["modules"] == ["forced_a"]
+    # rank 0 alone would have stopped after 1 iteration; the global AND keeps it going
+    assert out[0]["iters"] == 3 and out[1]["iters"] == 3
+    for o in out:
+        assert o["resid"] < 0.2 * o["fcn_norm"]
