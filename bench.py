@@ -179,7 +179,7 @@ def main():
                 },
                 "roofline": {
                     "bound": "hbm",
-                    "kernel": f"k_sweep<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}>",
+                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}>",
                     "achieved": achieved,
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",

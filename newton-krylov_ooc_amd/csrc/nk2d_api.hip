@@ -79,6 +79,12 @@ extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     const std::string key(name ? name : "");
     if (key == "device_ctl") { c->device_ctl = value != 0.0; return 0; }
+    if (key == "sweep_wpb") {
+        const int w = (int)value;
+        if (w != 1 && w != 2 && w != 4) return nk2d_fail(c, "nk2d_set_option: sweep_wpb must be 1, 2 or 4");
+        c->sweep_wpb = w;
+        return 0;
+    }
     if (key == "lin_tol") {
         if (!(value > 0.0 && value < 1.0)) return nk2d_fail(c, "nk2d_set_option: lin_tol must be in (0, 1)");
         c->d.lin_tol = value;
@@ -194,6 +200,12 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
         NK2D_TRY(dev_alloc(c, &c->XCR[i], c->nv));
         NK2D_TRY(dev_alloc(c, &c->XCI[i], c->nv));
     }
+    NK2D_TRY(dev_alloc(c, &c->FR_INV, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FC_INVR, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FC_INVI, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FR_TAB, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FC_TABR, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FC_TABI, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->TMP, c->nv));
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
@@ -203,6 +215,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hCTL, 128));
     c->cur_guard = nullptr;
     c->device_ctl = 0;
+    c->sweep_wpb = 4;
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
@@ -279,7 +292,8 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
-                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF};
+                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF,
+                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -443,6 +457,7 @@ extern "C" int nk2d_shifted_solve(nk2d_ctx* c, double t_jac, double h, double mu
     NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
     const bool cplxsys = mu_im != 0.0;
     const int m = nk2d_sweeps_for(c, mu_re / h);
+    NK2D_TRY(nk2d_k_factor(c, !cplxsys, cplxsys, mu_re / h, mu_re / h, mu_im / h));
     int src = 0;
     for (int it = 0; it < m; ++it) {
         NK2D_TRY(nk2d_k_sweep(c, !cplxsys, cplxsys, it == 0, mu_re / h, mu_re / h, mu_im / h, (const double*)b_re,

@@ -59,6 +59,9 @@ struct nk2d_ctx {
     // Radau work vectors (nv each unless noted)
     double *Y, *YOLD, *F, *Z /*3nv*/, *ZP /*3nv*/, *W /*3nv*/;
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
+    // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
+    double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
+    double *FR_TAB, *FC_TABR, *FC_TABI;   // ncol * NK2D_TAB * 64 each
     // device-side Newton control block (see nk2d_kernels.hip, k_reduce_newton):
     //   DCTL: [0] dW_norm_old [1] rate [2] dW_norm [3] err_sum [4] newton_tol [5] 3n [6] n
     //   ICTL: [0] k [1] has_old [2] has_rate [3] done [4] converged [5] skip_err [6] n_iter
@@ -66,6 +69,7 @@ struct nk2d_ctx {
     int* ICTL;
     double* hCTL;           // pinned mirror: 8 doubles followed by 8 ints
     const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
+    int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
@@ -174,9 +178,21 @@ __device__ __forceinline__ double t_nfmar(double a, double b, double s) { return
 __device__ __forceinline__ cplx t_nfmar(cplx a, cplx b, double s) {
     return c_make(__builtin_fma(-b.re, s, a.re), __builtin_fma(-b.im, s, a.im));
 }
-__device__ __forceinline__ double t_recip(double a) { return 1.0 / a; }
+// reciprocal for the pivots of diagonally dominant systems (finite, far from 0 and inf):
+// hardware estimate + two Newton steps, ~1 ulp, a third of the instructions of an IEEE divide
+__device__ __forceinline__ double fast_rcp(double a) {
+#ifdef NK2D_IEEE_DIV
+    return 1.0 / a;
+#else
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+    return r;
+#endif
+}
+__device__ __forceinline__ double t_recip(double a) { return fast_rcp(a); }
 __device__ __forceinline__ cplx t_recip(cplx a) {
-    double n = 1.0 / __builtin_fma(a.re, a.re, a.im * a.im);
+    double n = fast_rcp(__builtin_fma(a.re, a.re, a.im * a.im));
     return c_make(a.re * n, -a.im * n);
 }
 
@@ -301,6 +317,121 @@ __device__ __forceinline__ void tridiag_wave(const double (&a)[E], const double 
     r[E - 1] = xl;
 }
 
+// ---------------------------------------------------------------------------------
+// Cached form of the same solve.  The matrix-only part of `tridiag_wave` (pivot
+// reciprocals, the coupling g to the next lane's first row, the parallel-cyclic-reduction
+// multipliers of the 64 block-end unknowns and the final pivot) depends only on
+// (shift, Jacobian planes), i.e. on SciPy's "LU" event, while a relaxation solve runs
+// sweeps x Newton iterations x steps right-hand sides through it.  `tridiag_factor`
+// computes that part once; `tridiag_apply` then needs no division and only two shuffles
+// of the right-hand side per PCR level (instead of eight values).
+// Table layout per lane: K1[6], K2[6], IB, G  (NK2D_TAB = 14 values of T).
+// ---------------------------------------------------------------------------------
+#define NK2D_TAB 14
+
+template <int E, typename T>
+__device__ __forceinline__ void tridiag_factor(const double (&a)[E], const double (&c)[E], const T (&d)[E],
+                                               T (&inv)[E], T (&tab)[NK2D_TAB], int lane) {
+    T al[E], be[E];
+    T dlast = d[0];
+    inv[0] = t_recip(d[0]);
+    al[0] = t_from_real(a[0], T());
+#pragma unroll
+    for (int i = 1; i < E; ++i) {
+        T m = t_mulr(inv[i - 1], a[i]);
+        T dd = t_nfmar(d[i], m, c[i - 1]);
+        dlast = dd;
+        inv[i] = t_recip(dd);
+        al[i] = t_neg(t_mul(m, al[i - 1]));
+    }
+    T A, B, C, G;
+    if constexpr (E >= 2) {
+        be[E - 1] = t_zero(T());
+        be[E - 2] = t_from_real(c[E - 2], T());
+#pragma unroll
+        for (int i = E - 3; i >= 0; --i) {
+            T m = t_mulr(inv[i + 1], c[i]);
+            al[i] = t_nfma(al[i], m, al[i + 1]);
+            be[i] = t_neg(t_mul(m, be[i + 1]));
+        }
+        T n_al = shfl_down_t(al[0], 1), n_inv = shfl_down_t(inv[0], 1), n_be = shfl_down_t(be[0], 1);
+        G = t_mulr(n_inv, c[E - 1]);
+        A = al[E - 1];
+        B = t_nfma(dlast, G, n_al);
+        C = t_neg(t_mul(G, n_be));
+    } else {
+        G = t_zero(T());
+        A = t_from_real(a[0], T());
+        B = d[0];
+        C = t_from_real(c[0], T());
+    }
+    int lv = 0;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1, ++lv) {
+        T iB = t_recip(B);
+        T Am = shfl_up_t(A, s), iBm = shfl_up_t(iB, s), Cm = shfl_up_t(C, s);
+        T Ap = shfl_down_t(A, s), iBp = shfl_down_t(iB, s), Cp = shfl_down_t(C, s);
+        const bool hm = lane >= s, hp = lane + s < 64;
+        T k1 = hm ? t_mul(A, iBm) : t_zero(T());
+        T k2 = hp ? t_mul(C, iBp) : t_zero(T());
+        if (!hm) { Am = t_zero(T()); Cm = t_zero(T()); }
+        if (!hp) { Ap = t_zero(T()); Cp = t_zero(T()); }
+        tab[lv] = k1;
+        tab[6 + lv] = k2;
+        B = t_nfma(t_nfma(B, Cm, k1), Ap, k2);
+        A = t_neg(t_mul(Am, k1));
+        C = t_neg(t_mul(Cp, k2));
+    }
+    tab[12] = t_recip(B);
+    tab[13] = G;
+}
+
+template <int E, typename T>
+__device__ __forceinline__ void tridiag_apply(const double (&a)[E], const double (&c)[E], const T (&inv)[E],
+                                              const T (&tab)[NK2D_TAB], T (&r)[E], int lane) {
+    T al[E], be[E];
+    al[0] = t_from_real(a[0], T());
+#pragma unroll
+    for (int i = 1; i < E; ++i) {
+        T m = t_mulr(inv[i - 1], a[i]);
+        r[i] = t_nfma(r[i], m, r[i - 1]);
+        al[i] = t_neg(t_mul(m, al[i - 1]));
+    }
+    T R;
+    if constexpr (E >= 2) {
+        be[E - 1] = t_zero(T());
+        be[E - 2] = t_from_real(c[E - 2], T());
+#pragma unroll
+        for (int i = E - 3; i >= 0; --i) {
+            T m = t_mulr(inv[i + 1], c[i]);
+            r[i] = t_nfma(r[i], m, r[i + 1]);
+            al[i] = t_nfma(al[i], m, al[i + 1]);
+            be[i] = t_neg(t_mul(m, be[i + 1]));
+        }
+        T n_r = shfl_down_t(r[0], 1);
+        R = t_nfma(r[E - 1], tab[13], n_r);
+    } else {
+        R = r[0];
+    }
+    int lv = 0;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1, ++lv) {
+        T Rm = shfl_up_t(R, s), Rp = shfl_down_t(R, s);  // multipliers are 0 where no partner
+        R = t_nfma(t_nfma(R, Rm, tab[lv]), Rp, tab[6 + lv]);
+    }
+    T xl = t_mul(R, tab[12]);
+    T xp = shfl_up_t(xl, 1);
+    if (lane == 0) xp = t_zero(T());
+    if constexpr (E >= 2) {
+#pragma unroll
+        for (int i = 0; i < E - 1; ++i) {
+            T v = t_nfma(t_nfma(r[i], al[i], xp), be[i], xl);
+            r[i] = t_mul(inv[i], v);
+        }
+    }
+    r[E - 1] = xl;
+}
+
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------
@@ -316,6 +447,7 @@ int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f);
 int nk2d_k_jac(nk2d_ctx* c, const double* kv);
 int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre, double ccr, double cci,
                  const double* br, const double* bcr, const double* bci, int src);
+int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci);
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
@@ -323,6 +455,8 @@ int nk2d_profile_collect(nk2d_ctx* c);
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
 int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci);
 int nk2d_r_newton_update(nk2d_ctx* c, int buf);
+int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
+                        double mci, int src);
 int nk2d_r_err_rhs(nk2d_ctx* c, double h);
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h);
 int nk2d_r_err_norm(nk2d_ctx* c, const double* err);

@@ -52,7 +52,7 @@ __constant__ double cE[3] = {-10.048809399827414, 1.382142733160748, -0.33333333
 
 #define TASK_PROLOGUE(ntasks)                                              \
     const int lane = threadIdx.x & 63;                                     \
-    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6); \
+    const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
     if (task >= (ntasks)) return;
 
 // ---------------------------------------------------------------------------------
@@ -374,22 +374,34 @@ struct SweepArgs {
     const double *br, *bcr, *bci;
     const double *xr_old, *xcr_old, *xci_old;
     double *xr_new, *xcr_new, *xci_new;
+    // cached factorisation (k_factor)
+    double *fr_inv, *fc_invr, *fc_invi, *fr_tab, *fc_tabr, *fc_tabi;
     double cre, ccr, cci;
     int nreal, ntasks, first;
 };
 
 template <int E>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
-    GUARD_RETURN(P.guard)
+__device__ __forceinline__ void load_tab(const double* __restrict__ tab, int col, int lane, double (&t)[NK2D_TAB]) {
+    const double* p = tab + (size_t)col * (NK2D_TAB * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < NK2D_TAB; ++i) t[i] = p[i * 64];
+}
+
+// pivots and PCR tables of every column's tridiagonal T_j = tridiag(-JL, c - JC + extra, -JU)
+// for the real and/or the complex shift; one launch per SciPy "LU" event
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     TASK_PROLOGUE(A.ntasks)
-    const bool is_c = task >= A.nreal;
-    const int col = is_c ? task - A.nreal : task;
-    const int tr = col / P.ny, j = col - tr * P.ny;
-    double jl[E], ju[E], jc[E], a[E], cc[E];
+    // the (system, tracer) variants of one ypos column sit in adjacent waves of a block, so
+    // that their identical Jacobian-plane loads hit in the CU's L1
+    const int nvar = A.ntasks / P.ny, j = task / nvar, var = task - j * nvar;
+    const bool is_c = var >= A.nreal / P.ny;
+    const int tr = is_c ? var - A.nreal / P.ny : var;
+    const int col = tr * P.ny + j;
+    double jl[E], ju[E], jc[E], a[E], cc[E], dre[E];
     load_col<E>(A.JL, j, lane, jl);
     load_col<E>(A.JU, j, lane, ju);
     load_col<E>(A.JC, j, lane, jc);
-    double dre[E];
     const double shift_re = is_c ? A.ccr : A.cre;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -401,6 +413,47 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
         if (k == 0) d = d + P.surf[tr];
         dre[e] = valid ? d : 1.0;
     }
+    if (!is_c) {
+        double inv[E], tab[NK2D_TAB];
+        tridiag_factor<E, double>(a, cc, dre, inv, tab, lane);
+        store_col<E>(A.fr_inv, col, lane, inv);
+        double* p = A.fr_tab + (size_t)col * (NK2D_TAB * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
+    } else {
+        cplx d[E], inv[E], tab[NK2D_TAB];
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = c_make(dre[e], ((lane * E + e) < P.nz) ? A.cci : 0.0);
+        tridiag_factor<E, cplx>(a, cc, d, inv, tab, lane);
+        double re[E], im[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { re[e] = inv[e].re; im[e] = inv[e].im; }
+        store_col<E>(A.fc_invr, col, lane, re);
+        store_col<E>(A.fc_invi, col, lane, im);
+        double* pr = A.fc_tabr + (size_t)col * (NK2D_TAB * 64) + lane;
+        double* pi = A.fc_tabi + (size_t)col * (NK2D_TAB * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; }
+    }
+}
+
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(A.ntasks)
+    const int nvar = A.ntasks / P.ny, j = task / nvar, var = task - j * nvar;
+    const bool is_c = var >= A.nreal / P.ny;
+    const int tr = is_c ? var - A.nreal / P.ny : var;
+    const int col = tr * P.ny + j;
+    double jl[E], ju[E], a[E], cc[E];
+    load_col<E>(A.JL, j, lane, jl);
+    load_col<E>(A.JU, j, lane, ju);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool valid = (lane * E + e) < P.nz;
+        a[e] = valid ? -jl[e] : 0.0;
+        cc[e] = valid ? -ju[e] : 0.0;
+    }
     const int cs_col = (j > 0) ? col - 1 : col, cn_col = (j < P.ny - 1) ? col + 1 : col;
     double js[E], jn[E];
     if (!A.first) {
@@ -408,8 +461,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
         load_col<E>(A.JN, j, lane, jn);
     }
     if (!is_c) {
-        double r[E];
+        double r[E], inv[E], tab[NK2D_TAB];
         load_col<E>(A.br, col, lane, r);
+        load_col<E>(A.fr_inv, col, lane, inv);
+        load_tab<E>(A.fr_tab, col, lane, tab);
         if (!A.first) {
             double xs[E], xn[E];
             load_col<E>(A.xr_old, cs_col, lane, xs);
@@ -417,13 +472,23 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
 #pragma unroll
             for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], r[e]));
         }
-        tridiag_wave<E, double>(a, cc, dre, r, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = ((lane * E + e) < P.nz) ? r[e] : 0.0;
+        tridiag_apply<E, double>(a, cc, inv, tab, r, lane);
         store_col<E>(A.xr_new, col, lane, r);
     } else {
-        cplx r[E], d[E];
-        double rr[E], ri[E];
+        cplx r[E], inv[E], tab[NK2D_TAB];
+        double rr[E], ri[E], t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
         load_col<E>(A.bcr, col, lane, rr);
         load_col<E>(A.bci, col, lane, ri);
+        load_col<E>(A.fc_invr, col, lane, t0);
+        load_col<E>(A.fc_invi, col, lane, t1);
+        load_tab<E>(A.fc_tabr, col, lane, tr0);
+        load_tab<E>(A.fc_tabi, col, lane, ti0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) inv[e] = c_make(t0[e], t1[e]);
+#pragma unroll
+        for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
         if (!A.first) {
             double xs[E], xn[E];
             load_col<E>(A.xcr_old, cs_col, lane, xs);
@@ -438,10 +503,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool valid = (lane * E + e) < P.nz;
-            r[e] = c_make(rr[e], ri[e]);
-            d[e] = c_make(dre[e], valid ? A.cci : 0.0);
+            r[e] = c_make(valid ? rr[e] : 0.0, valid ? ri[e] : 0.0);
         }
-        tridiag_wave<E, cplx>(a, cc, d, r, lane);
+        tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
 #pragma unroll
         for (int e = 0; e < E; ++e) { rr[e] = r[e].re; ri[e] = r[e].im; }
         store_col<E>(A.xcr_new, col, lane, rr);
@@ -449,12 +513,34 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
     }
 }
 
+static void fill_factor_args(const nk2d_ctx* c, SweepArgs& A) {
+    A.JL = c->JL; A.JU = c->JU; A.JS = c->JS; A.JN = c->JN; A.JC = c->JC;
+    A.fr_inv = c->FR_INV; A.fc_invr = c->FC_INVR; A.fc_invi = c->FC_INVI;
+    A.fr_tab = c->FR_TAB; A.fc_tabr = c->FC_TABR; A.fc_tabi = c->FC_TABI;
+}
+
+int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci) {
+    SweepArgs A = {};
+    fill_factor_args(c, A);
+    A.cre = cre; A.ccr = ccr; A.cci = cci;
+    A.nreal = do_real ? c->ncol : 0;
+    A.ntasks = A.nreal + (do_cplx ? c->ncol : 0);
+    A.first = 0;
+    if (A.ntasks == 0) return 0;
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_factor<EE>, dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
 // src = index of the ping-pong buffer holding the previous iterate; the new iterate
 // goes to buffer 1-src.
 int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre, double ccr, double cci,
                  const double* br, const double* bcr, const double* bci, int src) {
-    SweepArgs A;
-    A.JL = c->JL; A.JU = c->JU; A.JS = c->JS; A.JN = c->JN; A.JC = c->JC;
+    SweepArgs A = {};
+    fill_factor_args(c, A);
     A.br = br; A.bcr = bcr; A.bci = bci;
     A.xr_old = c->XR[src]; A.xcr_old = c->XCR[src]; A.xci_old = c->XCI[src];
     A.xr_new = c->XR[1 - src]; A.xcr_new = c->XCR[1 - src]; A.xci_new = c->XCI[1 - src];
@@ -464,19 +550,10 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
     A.first = first ? 1 : 0;
     if (A.ntasks == 0) return 0;
     DevP P = make_devp(c);
-    // algorithmic bytes of this launch: Jacobian planes once per ypos column, and per
-    // (system, tracer) column the right-hand side, the new iterate and (after the first
-    // sweep) the previous iterate of the neighbours, counted once
-    {
-        const double cells = (double)c->nz * c->ny;
-        const double vec_words = (first ? 2.0 : 3.0) * ((do_real ? 1.0 : 0.0) + (do_cplx ? 2.0 : 0.0)) * c->tc;
-        c->sweep_bytes += 8.0 * cells * ((first ? 3.0 : 5.0) + vec_words);
-        c->sweep_launches++;
-    }
-    const bool sample = c->prof_every > 0 && (c->sweep_launches % c->prof_every) == 0 &&
-                        c->prof_used + 2 <= c->prof_ev.size();
+    const bool sample = false;  // the profiled kernel is k_newton_fused
     if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_sweep<EE>, dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    const int wpb = c->sweep_wpb;  // waves per block of the sweep kernel
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_sweep<EE>, dim3((A.ntasks + wpb - 1) / wpb), dim3(64 * wpb), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
     if (sample) {
         NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
@@ -774,6 +851,173 @@ __global__ void k_newton_update(DevP P, const double* __restrict__ y, const doub
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Fused simplified-Newton iteration.  One wave owns one (tracer, ypos) column and runs,
+// depending on the flags, the pieces of a Newton iteration that need no data from other
+// columns between them:
+//   do_stage  : stage tendencies + transformed residuals (k_stage) -> right-hand sides
+//   (always)  : one line-relaxation sweep of the real AND the complex system of the column
+//               (first: no lateral terms)
+//   do_update : W += dW, Z = T W, ||dW/scale||^2 partial (k_newton_update)
+// With m sweeps per solve a Newton iteration is m launches (stage fused into the first,
+// update into the last) instead of m + 2.
+// ---------------------------------------------------------------------------------
+struct FusedArgs {
+    StageArgs st;
+    SweepArgs sw;
+    double* part;
+    int do_stage, do_update;
+};
+
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    double fr[E], fcr[E], fci[E];
+    if (A.do_stage) {
+        ColCoef<E> cf;
+        load_coef<E>(P, j, lane, cf);
+        double y0[E], ys[E], yn[E];
+        load_col<E>(A.st.y, task, lane, y0);
+        load_col<E>(A.st.y, cs_col, lane, ys);
+        load_col<E>(A.st.y, cn_col, lane, yn);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double c[E], cs[E], cn[E], kv[E], f[E];
+            load_col<E>(A.st.z + i * A.st.nv, task, lane, c);
+            load_col<E>(A.st.z + i * A.st.nv, cs_col, lane, cs);
+            load_col<E>(A.st.z + i * A.st.nv, cn_col, lane, cn);
+            load_col<E>(A.st.kv[i], j, lane, kv);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
+            tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                fr[e] = fr[e] + f[e] * cTI[0][i];
+                fcr[e] = fcr[e] + f[e] * cTI[1][i];
+                fci[e] = fci[e] + f[e] * cTI[2][i];
+            }
+        }
+        double w0[E], w1[E], w2[E];
+        load_col<E>(A.st.w, task, lane, w0);
+        load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+        load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            fr[e] = fr[e] - A.st.mreal * w0[e];
+            fcr[e] = fcr[e] - (A.st.mcr * w1[e] - A.st.mci * w2[e]);
+            fci[e] = fci[e] - (A.st.mcr * w2[e] + A.st.mci * w1[e]);
+        }
+        if (!A.do_update) {  // later sweeps read the right-hand sides back
+            store_col<E>(A.st.br, task, lane, fr);
+            store_col<E>(A.st.bcr, task, lane, fcr);
+            store_col<E>(A.st.bci, task, lane, fci);
+        }
+    } else {
+        load_col<E>(A.sw.br, task, lane, fr);
+        load_col<E>(A.sw.bcr, task, lane, fcr);
+        load_col<E>(A.sw.bci, task, lane, fci);
+    }
+    double a[E], cc[E];
+    {
+        double jl[E], ju[E];
+        load_col<E>(A.sw.JL, j, lane, jl);
+        load_col<E>(A.sw.JU, j, lane, ju);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane * E + e) < P.nz;
+            a[e] = valid ? -jl[e] : 0.0;
+            cc[e] = valid ? -ju[e] : 0.0;
+        }
+    }
+    if (!A.sw.first) {
+        double js[E], jn[E], xs[E], xn[E];
+        load_col<E>(A.sw.JS, j, lane, js);
+        load_col<E>(A.sw.JN, j, lane, jn);
+        load_col<E>(A.sw.xr_old, cs_col, lane, xs);
+        load_col<E>(A.sw.xr_old, cn_col, lane, xn);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e]));
+        load_col<E>(A.sw.xcr_old, cs_col, lane, xs);
+        load_col<E>(A.sw.xcr_old, cn_col, lane, xn);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e]));
+        load_col<E>(A.sw.xci_old, cs_col, lane, xs);
+        load_col<E>(A.sw.xci_old, cn_col, lane, xn);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
+    }
+    // real system
+    {
+        double inv[E], tab[NK2D_TAB];
+        load_col<E>(A.sw.fr_inv, task, lane, inv);
+        load_tab<E>(A.sw.fr_tab, task, lane, tab);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fr[e] = ((lane * E + e) < P.nz) ? fr[e] : 0.0;
+        tridiag_apply<E, double>(a, cc, inv, tab, fr, lane);
+    }
+    // complex system
+    {
+        cplx r[E], inv[E], tab[NK2D_TAB];
+        double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
+        load_col<E>(A.sw.fc_invr, task, lane, t0);
+        load_col<E>(A.sw.fc_invi, task, lane, t1);
+        load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
+        load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane * E + e) < P.nz;
+            inv[e] = c_make(t0[e], t1[e]);
+            r[e] = c_make(valid ? fcr[e] : 0.0, valid ? fci[e] : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
+        tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
+    }
+    if (!A.do_update) {
+        store_col<E>(A.sw.xr_new, task, lane, fr);
+        store_col<E>(A.sw.xcr_new, task, lane, fcr);
+        store_col<E>(A.sw.xci_new, task, lane, fci);
+        return;
+    }
+    // dW = (fr, fcr, fci): norm partial, W += dW, Z = T W
+    double yy[E], w0[E], w1[E], w2[E];
+    load_col<E>(A.st.y, task, lane, yy);
+    load_col<E>(A.st.w, task, lane, w0);
+    load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+    load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double sc = P.atol + fabs(yy[e]) * P.rtol;
+        const double d0 = fr[e] / sc, d1 = fcr[e] / sc, d2 = fci[e] / sc;
+        acc += (d0 * d0 + d1 * d1) + d2 * d2;
+        w0[e] = w0[e] + fr[e];
+        w1[e] = w1[e] + fcr[e];
+        w2[e] = w2[e] + fci[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) A.part[task] = acc;
+    double* wout = const_cast<double*>(A.st.w);
+    double* zout = const_cast<double*>(A.st.z);
+    store_col<E>(wout, task, lane, w0);
+    store_col<E>(wout + A.st.nv, task, lane, w1);
+    store_col<E>(wout + 2 * A.st.nv, task, lane, w2);
+    double zz[E];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+        store_col<E>(zout + r * A.st.nv, task, lane, zz);
+    }
+}
+
 // error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
 template <int E>
 __global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
@@ -932,6 +1176,58 @@ int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci) {
     c->st.nlaunch++;
     return 0;
 }
+// one launch of the fused Newton iteration; src = ping-pong buffer with the previous
+// sweep's iterate, the new iterate goes to 1-src unless do_update consumes it
+int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
+                        double mci, int src) {
+    FusedArgs A = {};
+    A.st.y = c->Y; A.st.z = c->Z; A.st.w = c->W;
+    A.st.kv[0] = c->KV[0]; A.st.kv[1] = c->KV[1]; A.st.kv[2] = c->KV[2];
+    A.st.br = c->BR; A.st.bcr = c->BCR; A.st.bci = c->BCI;
+    A.st.nv = c->nv; A.st.mreal = mreal; A.st.mcr = mcr; A.st.mci = mci;
+    fill_factor_args(c, A.sw);
+    A.sw.br = c->BR; A.sw.bcr = c->BCR; A.sw.bci = c->BCI;
+    A.sw.xr_old = c->XR[src]; A.sw.xcr_old = c->XCR[src]; A.sw.xci_old = c->XCI[src];
+    A.sw.xr_new = c->XR[1 - src]; A.sw.xcr_new = c->XCR[1 - src]; A.sw.xci_new = c->XCI[1 - src];
+    A.sw.first = first ? 1 : 0;
+    A.part = c->PART;
+    A.do_stage = do_stage ? 1 : 0;
+    A.do_update = do_update ? 1 : 0;
+    DevP P = make_devp(c);
+    {
+        // algorithmic (unique) bytes of this launch, P = nz*ny cells, N = tc*P values:
+        //   stage : read y, Z[3], W[3] (7N), kappa_v at 3 times + 4 static planes (7P),
+        //           write the 3 right-hand sides (3N) unless the update consumes them
+        //   sweep : Jacobian planes JL, JU (+JS, JN after the first sweep), pivot reciprocals
+        //           (real N + complex 2N), PCR tables (3 * 14/E * N), right-hand sides (3N, unless
+        //           just computed), previous iterate (3N, after the first sweep), new iterate (3N,
+        //           unless the update consumes it)
+        //   update: y (N, unless the stage read it), W read + write (6N), Z write (3N)
+        const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
+        double words = 0.0;
+        if (do_stage) words += 7.0 * N + 7.0 * Pc + (do_update ? 0.0 : 3.0 * N);
+        words += (first ? 2.0 : 4.0) * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N;
+        if (!do_stage) words += 3.0 * N;
+        if (!first) words += 3.0 * N;
+        if (!do_update) words += 3.0 * N;
+        if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;
+        c->sweep_bytes += 8.0 * words;
+        c->sweep_launches++;
+    }
+    const bool sample = c->prof_every > 0 && (c->sweep_launches % c->prof_every) == 0 &&
+                        c->prof_used + 2 <= c->prof_ev.size();
+    if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_newton_fused<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_CHECK(c, hipGetLastError());
+    if (sample) {
+        NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
+        c->prof_used += 2;
+    }
+    c->st.nlaunch++;
+    c->st.nsweeps++;
+    return 0;
+}
+
 int nk2d_r_newton_update(nk2d_ctx* c, int buf) {
     DevP P = make_devp(c);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_newton_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,

@@ -26,7 +26,6 @@
 
 namespace {
 
-const double S6 = 2.449489742783178;
 const double RC[3] = {0.15505102572168222, 0.6449489742783178, 1.0};
 const double MU_REAL = 3.637834252744496;
 const double MU_CR = 2.6810828736277523, MU_CI = -3.050430199247411;
@@ -63,12 +62,15 @@ int refresh_jac(Ctl& s, double t, bool kv_in_slot3) {
     return 0;
 }
 
-void set_lu(Ctl& s, double h) {
+// SciPy's two factorisations of (mu/h) I - J: here the per-column pivot reciprocals and
+// PCR tables of the line solves (k_factor) and the sweep counts from the contraction bound
+int set_lu(Ctl& s, double h) {
     s.h_lu = h;
     s.have_lu = true;
     s.m_real = nk2d_sweeps_for(s.c, MU_REAL / h);
     s.m_cplx = nk2d_sweeps_for(s.c, MU_CR / h);
     s.c->st.nlu += 2;
+    return nk2d_k_factor(s.c, true, true, MU_REAL / h, MU_CR / h, MU_CI / h);
 }
 
 // x = ((mu/h_lu) I - J)^-1 b for the real and/or the complex system; result in
@@ -112,16 +114,27 @@ int stage_planes(Ctl& s, double t, double h) {
     return nk2d_k_vmix(s.c, 3, times, out);
 }
 
+// one simplified-Newton iteration: stage residuals, m line sweeps of both systems, update
+// (fused: m launches)
+int newton_iteration(Ctl& s, double mreal, double mcr, double mci) {
+    nk2d_ctx* c = s.c;
+    const int m = std::max(s.m_real, s.m_cplx);
+    int src = 0;
+    for (int it = 0; it < m; ++it) {
+        NK2D_TRY(nk2d_r_newton_fused(c, it == 0, it == 0, it == m - 1, mreal, mcr, mci, src));
+        src = 1 - src;
+    }
+    c->st.nsolve += 2;
+    return 0;
+}
+
 // Replay: exactly n_iters simplified-Newton iterations, no tests, nothing read back.
 int newton_fixed(Ctl& s, double h, int n_iters) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
     for (int k = 0; k < n_iters; ++k) {
-        NK2D_TRY(nk2d_r_stage(c, mreal, mcr, mci));
+        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
         c->st.nfev += 3;
-        int buf = 0;
-        NK2D_TRY(solve_systems(s, true, true, &buf));
-        NK2D_TRY(nk2d_r_newton_update(c, buf));
         c->st.nnewton++;
     }
     return 0;
@@ -139,11 +152,8 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     const int kmax = force_iters >= 0 ? force_iters : NEWTON_MAXITER;
     int k = -1;
     for (k = 0; k < kmax; ++k) {
-        NK2D_TRY(nk2d_r_stage(c, mreal, mcr, mci));
+        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
         c->st.nfev += 3;
-        int buf = 0;
-        NK2D_TRY(solve_systems(s, true, true, &buf));
-        NK2D_TRY(nk2d_r_newton_update(c, buf));
         c->st.nnewton++;
         if (force_iters >= 0) continue;
         double sum = 0.0;
@@ -180,10 +190,7 @@ int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* ra
     NK2D_TRY(nk2d_r_ctl_reset(c, s.newton_tol, s.n_total));
     c->cur_guard = c->ICTL + 3;  // done
     for (int k = 0; k < NEWTON_MAXITER; ++k) {
-        NK2D_TRY(nk2d_r_stage(c, mreal, mcr, mci));
-        int buf = 0;
-        NK2D_TRY(solve_systems(s, true, true, &buf));
-        NK2D_TRY(nk2d_r_newton_update(c, buf));
+        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
         NK2D_TRY(nk2d_r_reduce_newton(c));
     }
     c->cur_guard = c->ICTL + 5;  // skip_err (cleared by a converged Newton iteration)
@@ -278,7 +285,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             double err_sum = 0.0;
             int buf = 0;
             while (!converged) {
-                if (!s.have_lu) set_lu(s, h);
+                if (!s.have_lu) NK2D_TRY(set_lu(s, h));
                 if (s.device_ctl) {
                     NK2D_TRY(attempt(s, t, h, &converged, &n_iter, &rate, &have_rate, &err_sum, &buf));
                 } else {
@@ -376,7 +383,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n) {
             c->st.njev++;
             have = false;
         }
-        if (!have || h_lu != h_lu_cur) { set_lu(s, h_lu); h_lu_cur = h_lu; have = true; }
+        if (!have || h_lu != h_lu_cur) { NK2D_TRY(set_lu(s, h_lu)); h_lu_cur = h_lu; have = true; }
         NK2D_TRY(stage_planes(s, t, h));
         NK2D_TRY(predict(s, t, h));
         NK2D_TRY(newton_fixed(s, h, n_iter));

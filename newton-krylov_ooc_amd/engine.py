@@ -50,7 +50,7 @@ class ModuleEngine:
 
     def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, device_id=0,
                  time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
-                 lin_tol=1.0e-13):
+                 lin_tol=1.0e-4):
         self._lib = _lib.load()
         self._ctx = None
         self.grid = grid

@@ -12,11 +12,11 @@ YEAR = 365.0 * 86400.0
 GRIDS = [(26, 26), (70, 40), (130, 37), (20, 3)]
 
 
-def make_engine(nz, ny, vv=0.1, kh=1000.0):
+def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
     from nk_ooc_amd.engine import iage_engine
     from nk_ooc_amd.grid import Grid2d
 
-    return iage_engine(Grid2d.default(nz, ny, vv, kh))
+    return iage_engine(Grid2d.default(nz, ny, vv, kh), **kw)
 
 
 @pytest.mark.parametrize("nz,ny", GRIDS)
@@ -79,7 +79,7 @@ def test_jacobian_diags(nz, ny, vv, kh):
 def test_shifted_solve(nz, ny, hfrac):
     from oracle import radau
 
-    eng = make_engine(nz, ny)
+    eng = make_engine(nz, ny, lin_tol=1.0e-13)  # the solver itself, to full accuracy
     _, tm = oracle_iage(nz, ny)
     t_jac = 0.3 * YEAR
     J = tm.comp_jacobian(t_jac).tocsc()

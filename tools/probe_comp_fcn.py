@@ -5,10 +5,13 @@ sys.path.insert(0, ".")
 from nk_ooc_amd.engine import iage_engine
 from nk_ooc_amd.grid import Grid2d
 
+import os
 sizes = [int(a) for a in sys.argv[1:]] or [26, 104, 416]
+DEVCTL = float(os.environ.get("NK2D_DEVICE_CTL", "0"))
 for n in sizes:
     grid = Grid2d.default(n, n)
     eng = iage_engine(grid)
+    eng.set_option("device_ctl", DEVCTL)
     col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
     x = eng.upload(y0)
