@@ -155,6 +155,12 @@ def main():
             # empty-pair reading taken on the same stream is subtracted
             kernel_us = max(prof["avg_us"] - prof["event_overhead_us"], 1e-3)
             achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+            traffic = None
+            pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")
+            if os.path.exists(pmc_fname):
+                # HBM-side bytes per launch of the same kernel from separate rocprofv3 --pmc
+                # passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); see the file
+                traffic = json.load(open(pmc_fname))["traffic_bytes_per_launch_upper"]
             out = {
                 "metric": "GMRES JVPs/sec, py_driver_2d iage",
                 "value": total_jvps / elapsed,
@@ -184,7 +190,7 @@ def main():
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic,
                     "avg_launch_us": kernel_us,
                     "event_pair_raw_us": prof["avg_us"],
                     "event_pair_empty_us": prof["event_overhead_us"],
