@@ -1,126 +1,169 @@
-"""Left-preconditioned GMRES on the device-resident model state.
+"""GMRES inner solver with an HBM-resident Krylov space.
 
-Mirror of the reference's `KrylovSolver` (`nk_ooc/krylov_solver.py:13-181`): same
-constructor and `solve(res_fname, fcn)` surface, same algorithm (Saad alg. 9.4, x0 = 0,
-no restart, one Hessenberg per (tracer module, region), least squares by
-`np.linalg.lstsq`), same checkpoint trail (`Krylov_state.json` with `beta` and `h_mat`,
-step strings, `<quantity>_NN.nc` files) and the same log lines.  The vectors never
-leave HBM between iterations: re-opens of `basis_NN` / `w_NN` / `precond_fcn_00` are
-served from device snapshots, the j+1 Gram-Schmidt projections and each `lin_comb` run
-as fused launches (`nk2d_mgs`, `nk2d_lin_comb`).
+Drop-in for the reference's `KrylovSolver` (`nk_ooc/krylov_solver.py:13-181`): same
+constructor and `solve(res_fname, fcn)` surface, same mathematics (left-preconditioned
+GMRES, Saad alg. 9.4, zero initial guess, no restart, an independent Hessenberg per
+(tracer module, region), coefficients from `np.linalg.lstsq`), same stopping rule, same
+checkpoint trail: `Krylov_state.json` (`beta`, `h_mat`, step strings), one NetCDF3 file per
+vector (`precond_fcn_00`, `basis_NN`, `w_raw_NN`, `w_NN`, `perturb_fcn_w_raw_NN`,
+`krylov_res_NN`), `Krylov_stats.nc`, and the `beta` / `KrylovCoeff` / `precond_resid` log lines.
+
+Where it differs is the data flow.  The reference is out-of-core: every use of a basis
+vector re-opens its file (j+1 reads in Gram-Schmidt, j+1 and j+2 more in the two
+`lin_comb`s of each iteration).  Here the Arnoldi vectors V_0..V_j and the preconditioned
+products W_0..W_j are kept as device-resident `ModelState`s for the life of the solve;
+files are only written (at the reference's points), and read back only when a solve is
+resumed from its checkpoint.  Each iteration is then
+
+    w_raw = J v_j        one perturbed forward year per tracer module (nk2d_comp_fcn)
+    w     = M^-1 w_raw   streamed block-Thomas apply             (nk2d_precond_apply)
+    h     = MGS(w; V)    j+1 fused dot/axpy pairs, no host sync between them (nk2d_mgs)
+    x_j, r_j             two single-launch linear combinations    (nk2d_lin_comb)
 """
 
 import logging
 
 import numpy as np
 
-from . import model_state
 from .solver_base import SolverBase
-from .solver_state import action_step_log_wrap
+
+
+def least_squares_coeffs(beta, hess):
+    """c = argmin || beta e_1 - H c ||_2 for every (tracer module, region).
+    hess has shape [ntm, j+2, j+1, nreg] (the reference's `h_mat` layout)."""
+    ntm, nrow, ncol, nreg = hess.shape
+    coeff = np.zeros((ntm, ncol, nreg))
+    for im in range(ntm):
+        for ir in range(nreg):
+            target = np.zeros(nrow)
+            target[0] = beta[im, ir]
+            coeff[im, :, ir] = np.linalg.lstsq(hess[im, :, :, ir], target, rcond=None)[0]
+    return coeff
+
+
+# name used by the reference's callers / tests
+comp_krylov_basis_coeffs = least_squares_coeffs
 
 
 class KrylovSolver(SolverBase):
-    """approximate solution of  A x = -fcn,  A = Jacobian of comp_fcn at iterate"""
+    """approximate solve of  J dx = -fcn  with J the Jacobian of comp_fcn at `iterate`"""
+
+    STATS_VARS = {
+        "precond_rhs_norm": {
+            "category": "per_tracer_module",
+            "dimensions": ("region",),
+            "attrs": {"long_name": "norm of {tracer_module_name} preconditioned rhs",
+                      "units": "{tracer_module_units}"},
+        },
+        "precond_resid_norm": {
+            "category": "per_tracer_module",
+            "dimensions": ("iteration", "region"),
+            "attrs": {"long_name": "norm of {tracer_module_name} preconditioned residual",
+                      "units": "{tracer_module_units}"},
+        },
+    }
 
     def __init__(self, iterate, solverinfo, resume, rewind, hist_fname):
         super().__init__("Krylov", solverinfo, iterate.model_config_obj.region_cnt, resume, rewind)
         self._iterate = iterate
-        self._def_solver_stats_vars(self.gen_stats_vars_metadata(), self._iterate.tracer_modules)
-        iterate.gen_precond_jacobian(
-            hist_fname, precond_fname=self._fname("precond", iteration=0),
-            solver_state=self._solver_state)
+        self._state_cls = type(iterate)
+        self._tag = f"{type(self).__module__}.{type(self).__name__}"
+        self._V = {}   # Arnoldi vectors, resident
+        self._W = {}   # preconditioned Jacobian-vector products (before orthogonalisation)
+        self._r0 = None  # M^-1 fcn
+        self._def_solver_stats_vars(self.gen_stats_vars_metadata(), iterate.tracer_modules)
+        iterate.gen_precond_jacobian(hist_fname, precond_fname=self._fname("precond", iteration=0),
+                                     solver_state=self._solver_state)
         self.max_iter = (int(self._solverinfo["krylov_max_iter"])
                          if "krylov_max_iter" in self._solverinfo else None)
 
-    @staticmethod
-    def gen_stats_vars_metadata():
-        return {
-            "precond_rhs_norm": {
-                "category": "per_tracer_module",
-                "dimensions": ("region",),
-                "attrs": {"long_name": "norm of {tracer_module_name} preconditioned rhs",
-                          "units": "{tracer_module_units}"},
-            },
-            "precond_resid_norm": {
-                "category": "per_tracer_module",
-                "dimensions": ("iteration", "region"),
-                "attrs": {"long_name": "norm of {tracer_module_name} preconditioned residual",
-                          "units": "{tracer_module_units}"},
-            },
-        }
+    @classmethod
+    def gen_stats_vars_metadata(cls):
+        return {key: dict(val, attrs=dict(val["attrs"])) for key, val in cls.STATS_VARS.items()}
 
+    # ---- resident Krylov space (files are the fallback after a resume) ----------------
+    def _resident(self, store, quantity, index):
+        if index not in store:
+            store[index] = self._state_cls(self._fname(quantity, index))
+        return store[index]
+
+    def _basis(self, index):
+        return self._resident(self._V, "basis", index)
+
+    def _prod(self, index):
+        return self._resident(self._W, "w", index)
+
+    def _precond_fcn(self):
+        if self._r0 is None:
+            self._r0 = self._state_cls(self._fname("precond_fcn", 0))
+        return self._r0
+
+    # ---- pieces of one solve ---------------------------------------------------------------
     def converged(self, beta, precond_resid_norm):
-        rel_tol = self._get_rel_tol()
-        return (self.get_iteration() >= self._get_min_iter()) & (precond_resid_norm < rel_tol * beta)
+        """elementwise over (tracer module, region); the caller requires all of them"""
+        enough = self.get_iteration() >= self._get_min_iter()
+        return enough & (precond_resid_norm < self._get_rel_tol() * beta)
 
-    @action_step_log_wrap(step="KrylovSolver._solve0", per_iteration=False)
-    def _solve0(self, fcn, solver_state):
-        """r0 = M^-1 (rhs - A x0) = -M^-1 fcn; v0 = r0 / beta"""
-        precond_fcn = fcn.apply_precond_jacobian(
-            self._fname("precond", 0), self._fname("precond_fcn"), self._solver_state)
-        beta = precond_fcn.norm()
+    def _start(self, fcn):
+        """first Arnoldi vector v_0 = -M^-1 fcn / beta (once per solve, step-logged)"""
+        state = self._solver_state
+        if state.step_logged("KrylovSolver._solve0", per_iteration=False):
+            return
+        r0 = fcn.apply_precond_jacobian(self._fname("precond", 0), self._fname("precond_fcn"), state)
+        beta = r0.norm()
         fcn.log_vals("beta", beta)
         self._put_solver_stats_vars_iteration_independent(precond_rhs_norm=beta)
-        caller = f"{type(self).__module__}.{type(self).__name__}._solve0"
-        (-precond_fcn / beta).dump(self._fname("basis"), caller)
-        self._solver_state.set_value_saved_state("beta", beta)
+        v0 = (-r0 / beta).dump(self._fname("basis"), f"{self._tag}._solve0")
+        self._r0, self._V[0] = r0, v0
+        state.set_value_saved_state("beta", beta)
+        state.log_step("KrylovSolver._solve0", per_iteration=False)
+
+    def _hessenberg(self, j, ntm, nreg):
+        hess = np.zeros((ntm, j + 2, j + 1, nreg))
+        if j > 0:
+            hess[:, :-1, :-1, :] = self._solver_state.get_value_saved_state("h_mat")
+        return hess
+
+    def _arnoldi_step(self, fcn, j):
+        """extend the space by one vector; returns (h_mat, normalised new direction)"""
+        state = self._solver_state
+        w_raw = self._iterate.comp_jacobian_fcn_state_prod(fcn, self._basis(j), self._fname("w_raw"), state)
+        w = w_raw.apply_precond_jacobian(self._fname("precond", 0), self._fname("w"), state)
+        self._W[j] = w.copy()  # the residual below needs w before orthogonalisation
+        hess = self._hessenberg(j, len(fcn.tracer_modules), fcn.model_config_obj.region_cnt)
+        hess[:, :-1, -1, :] = w.mgs_against([self._basis(i) for i in range(j + 1)])
+        hess[:, -1, -1, :] = w.norm()
+        w /= hess[:, -1, -1, :]
+        state.set_value_saved_state("h_mat", hess)
+        return hess, w
 
     def solve(self, res_fname, fcn):
         logger = logging.getLogger(__name__)
-        self._solve0(fcn, solver_state=self._solver_state)
-        caller = f"{type(self).__module__}.{type(self).__name__}.solve"
-        state_type = type(self._iterate)
+        state = self._solver_state
+        self._start(fcn)
+        caller = f"{self._tag}.solve"
         while True:
-            j_val = self.get_iteration()
-            h_mat = np.zeros((len(fcn.tracer_modules), j_val + 2, j_val + 1,
-                              fcn.model_config_obj.region_cnt))
-            if j_val > 0:
-                h_mat[:, :-1, :-1, :] = self._solver_state.get_value_saved_state("h_mat")
-            basis_j = state_type(self._fname("basis"))
-            w_raw = self._iterate.comp_jacobian_fcn_state_prod(
-                fcn, basis_j, self._fname("w_raw"), self._solver_state)
-            w_j = w_raw.apply_precond_jacobian(
-                self._fname("precond", 0), self._fname("w"), self._solver_state)
-            h_mat[:, :-1, -1, :] = w_j.mod_gram_schmidt(j_val + 1, self._fname, "basis")
-            h_mat[:, -1, -1, :] = w_j.norm()
-            w_j /= h_mat[:, -1, -1, :]
-            self._solver_state.set_value_saved_state("h_mat", h_mat)
-
-            beta = self._solver_state.get_value_saved_state("beta")
-            coeff = comp_krylov_basis_coeffs(beta, h_mat)
+            j = self.get_iteration()
+            hess, v_next = self._arnoldi_step(fcn, j)
+            beta = state.get_value_saved_state("beta")
+            coeff = least_squares_coeffs(beta, hess)
             self._iterate.log_vals("KrylovCoeff", coeff)
 
-            res = model_state.lin_comb(state_type, coeff, self._fname, "basis")
-            res.dump(self._fname("krylov_res", j_val), caller)
+            # iterate x_j = V c and its preconditioned residual  W c + M^-1 fcn
+            approx = self._state_cls.lin_comb_of(coeff, [self._basis(i) for i in range(j + 1)])
+            approx.dump(self._fname("krylov_res", j), caller)
+            resid = self._state_cls.lin_comb_of(coeff, [self._prod(i) for i in range(j + 1)])
+            resid += self._precond_fcn()
+            resid_norm = resid.norm()
+            self._iterate.log_vals("precond_resid", resid_norm)
+            self._put_solver_stats_vars(precond_resid_norm=resid_norm)
 
-            precond_resid = model_state.lin_comb(state_type, coeff, self._fname, "w")
-            precond_resid += state_type(self._fname("precond_fcn", 0))
-            precond_resid_norm = precond_resid.norm()
-            self._iterate.log_vals("precond_resid", precond_resid_norm)
-            self._put_solver_stats_vars(precond_resid_norm=precond_resid_norm)
-
-            self._solver_state.inc_iteration()
-
-            if self.converged(beta, precond_resid_norm).all():
+            state.inc_iteration()
+            if self.converged(beta, resid_norm).all():
                 logger.info("Krylov convergence criterion satisfied")
                 break
             if self.max_iter is not None and self.get_iteration() >= self.max_iter:
                 logger.info("Krylov iteration limit reached")
                 break
-
-            w_j.dump(self._fname("basis"), caller)
-
-        return res.dump(res_fname, caller)
-
-
-def comp_krylov_basis_coeffs(beta, h_mat):
-    """argmin_c || beta e_1 - H c ||_2 for every (tracer module, region)"""
-    ntm, nrow, ncol, nreg = h_mat.shape
-    coeff = np.zeros((ntm, ncol, nreg))
-    rhs = np.zeros(nrow)
-    for module_ind in range(ntm):
-        for region_ind in range(nreg):
-            rhs[0] = beta[module_ind, region_ind]
-            coeff[module_ind, :, region_ind] = np.linalg.lstsq(
-                h_mat[module_ind, :, :, region_ind], rhs, rcond=None)[0]
-    return coeff
+            self._V[j + 1] = v_next.dump(self._fname("basis"), caller)
+        return approx.dump(res_fname, caller)

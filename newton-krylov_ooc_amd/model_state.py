@@ -325,14 +325,27 @@ class ModelState:
     def norm(self):
         return np.sqrt(self.dot_prod(self))
 
-    def mod_gram_schmidt(self, basis_cnt, fname_fcn, quantity):
-        """in-place modified Gram-Schmidt against basis files 0..basis_cnt-1
-        (model_state_base.py:365-377); the projections run back to back on the device"""
-        basis = [type(self)(fname_fcn(quantity, i_val)) for i_val in range(basis_cnt)]
-        h_val = np.empty((len(self.tracer_modules), basis_cnt, self.model_config_obj.region_cnt))
+    def mgs_against(self, basis):
+        """in-place modified Gram-Schmidt of self against the given (resident) states;
+        returns the projection coefficients [ntm, len(basis), nreg].  Per tracer module the
+        len(basis) dot / axpy pairs run back to back on the device (nk2d_mgs)."""
+        h_val = np.empty((len(self.tracer_modules), len(basis), self.model_config_obj.region_cnt))
         for ind, tms in enumerate(self.tracer_modules):
             h_val[ind] = tms.eng.mgs(tms.vec, [b.tracer_modules[ind].vec for b in basis])
         return h_val
+
+    def mod_gram_schmidt(self, basis_cnt, fname_fcn, quantity):
+        """file-name flavour of `mgs_against` (reference signature, model_state_base.py:365-377)"""
+        return self.mgs_against([type(self)(fname_fcn(quantity, i_val)) for i_val in range(basis_cnt)])
+
+    @classmethod
+    def lin_comb_of(cls, coeff, states):
+        """sum_j coeff[:, j, :] * states[j], accumulated in order, one launch per module"""
+        mods = []
+        for ind, tms in enumerate(states[0].tracer_modules):
+            vecs = [state.tracer_modules[ind].vec for state in states]
+            mods.append(tms._like(tms.eng.lin_comb(vecs, coeff[ind])))
+        return states[0]._new(mods)
 
     # ---- arithmetic -------------------------------------------------------------------------------
     def _binary(self, other, op):
@@ -490,11 +503,7 @@ class ModelState:
 
 
 def lin_comb(res_type, coeff, fname_fcn, quantity):
-    """sum_j coeff[..., j, :] * state_j over the files <quantity>_00 ... (model_state_base.py:619-624);
-    a single fused kernel per tracer module"""
-    terms = [res_type(fname_fcn(quantity, j_val)) for j_val in range(coeff.shape[-2])]
-    mods = []
-    for ind, tms in enumerate(terms[0].tracer_modules):
-        vecs = [term.tracer_modules[ind].vec for term in terms]
-        mods.append(tms._like(tms.eng.lin_comb(vecs, coeff[ind])))
-    return terms[0]._new(mods)
+    """file-name flavour of `ModelState.lin_comb_of` (reference signature,
+    model_state_base.py:619-624)"""
+    return res_type.lin_comb_of(
+        coeff, [res_type(fname_fcn(quantity, j_val)) for j_val in range(coeff.shape[-2])])
