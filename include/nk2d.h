@@ -71,9 +71,11 @@ typedef struct nk2d_desc {
     double vmix_log_shallow;   /* ln(10)    */
     double vmix_log_deep;      /* ln(5e-4)  */
     double vmix_half_width;    /* 20 m      */
-    /* module sources: tend[tr][0][:] -= surf_rate[tr]*c[tr][0][:]; tend += const_src;
-       tend -= decay_rate[tr]*c everywhere */
+    /* module sources (iage.py:31-39, forced.py:114-139):
+       tend[tr][0][:] += surf_rate[tr]*(surf_target[tr] - c[tr][0][:]);
+       tend -= decay_rate[tr]*c everywhere; tend += const_src */
     double surf_rate[NK2D_MAX_TRACERS];
+    double surf_target[NK2D_MAX_TRACERS];
     double decay_rate[NK2D_MAX_TRACERS];
     double const_src;
     double t0, t1;             /* time_range, seconds */

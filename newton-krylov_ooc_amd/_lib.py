@@ -40,6 +40,7 @@ class Desc(ctypes.Structure):
         ("vmix_log_deep", ctypes.c_double),
         ("vmix_half_width", ctypes.c_double),
         ("surf_rate", ctypes.c_double * MAX_TRACERS),
+        ("surf_target", ctypes.c_double * MAX_TRACERS),
         ("decay_rate", ctypes.c_double * MAX_TRACERS),
         ("const_src", ctypes.c_double),
         ("t0", ctypes.c_double),

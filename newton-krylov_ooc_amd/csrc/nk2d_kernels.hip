@@ -14,7 +14,7 @@
 struct DevP {
     int nz, ny, tc, ncol;
     const double *VV, *KH, *WT, *WB, *DZR, *ZM0, *ZM1, *DM, *DMR, *DYR, *BLDMAX;
-    double surf[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
+    double surf[NK2D_MAX_TRACERS], starget[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
     double atol, rtol;
     const int* guard;  // guarded kernels return at once when *guard != 0
 };
@@ -25,7 +25,9 @@ static DevP make_devp(const nk2d_ctx* c) {
     p.VV = c->VV; p.KH = c->KH; p.WT = c->WT; p.WB = c->WB; p.DZR = c->DZR;
     p.ZM0 = c->ZM0; p.ZM1 = c->ZM1; p.DM = c->DM; p.DMR = c->DMR; p.DYR = c->DYR;
     p.BLDMAX = c->BLDMAX;
-    for (int i = 0; i < NK2D_MAX_TRACERS; ++i) { p.surf[i] = c->d.surf_rate[i]; p.decay[i] = c->d.decay_rate[i]; }
+    for (int i = 0; i < NK2D_MAX_TRACERS; ++i) {
+        p.surf[i] = c->d.surf_rate[i]; p.starget[i] = c->d.surf_target[i]; p.decay[i] = c->d.decay_rate[i];
+    }
     p.csrc = c->d.const_src;
     p.atol = c->d.atol; p.rtol = c->d.rtol;
     p.guard = c->cur_guard;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, co
     shift_prev<E>(c, cprev, lane, 0.0);
     shift_next<E>(c, cnext, lane, 0.0);
     shift_prev<E>(kv, kvprev, lane, 0.0);
-    const double surf = P.surf[tr], decay = P.decay[tr];
+    const double surf = P.surf[tr], starget = P.starget[tr], decay = P.decay[tr];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = lane * E + e;
@@ -280,10 +282,10 @@ __device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, co
         const double hT = kvprev[e] * (c[e] - cprev[e]);
         const double hB = kv[e] * (cnext[e] - c[e]);
         t = t + cf.dzr[e] * (hB - hT);
-        // module sources (iage.py:31-39)
-        if (k == 0) t = t - surf * c[e];
-        if (decay != 0.0) t = t - decay * c[e];
-        t = t + P.csrc;
+        // module sources (iage.py:31-39, forced.py:114-139)
+        if (k == 0 && surf != 0.0) t = t + surf * (starget - c[e]);
+        if (decay != 0.0) t = t + (-decay * c[e]);
+        if (P.csrc != 0.0) t = t + P.csrc;
         out[e] = (k < P.nz) ? t : 0.0;
     }
 }

@@ -48,9 +48,10 @@ class DevVec:
 class ModuleEngine:
     """HIP engine for one tracer module on one (depth, ypos) grid"""
 
-    def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, device_id=0,
+    def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, surf_target=(),
+                 device_id=0,
                  time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
-                 lin_tol=1.0e-4):
+                 lin_tol=1.0e-7):
         self._lib = _lib.load()
         self._ctx = None
         self.grid = grid
@@ -75,7 +76,9 @@ class ModuleEngine:
         desc.vmix_half_width = 20.0
         surf = list(surf_rate) + [0.0] * (_lib.MAX_TRACERS - len(surf_rate))
         decay = list(decay_rate) + [0.0] * (_lib.MAX_TRACERS - len(decay_rate))
+        target = list(surf_target) + [0.0] * (_lib.MAX_TRACERS - len(surf_target))
         desc.surf_rate = (ctypes.c_double * _lib.MAX_TRACERS)(*surf)
+        desc.surf_target = (ctypes.c_double * _lib.MAX_TRACERS)(*target)
         desc.decay_rate = (ctypes.c_double * _lib.MAX_TRACERS)(*decay)
         desc.const_src = float(const_src)
         desc.t0, desc.t1 = float(time_range[0]), float(time_range[1])
@@ -272,3 +275,26 @@ def iage_engine(grid, device_id=0, **kwargs):
     slow = 0.01
     return ModuleEngine(grid, tc=2, surf_rate=(rate, slow * rate),
                         const_src=1.0 / (365.0 * 86400.0), device_id=device_id, **kwargs)
+
+
+def forced_engine(grid, modelinfo, device_id=0, **kwargs):
+    """engine of a `forced_{suff}` tracer module (one tracer) for the state-independent
+    option combinations of forced.py:57-139: surface restoring none / const, source-minus-sink
+    none / const / decay.  The file-driven options need the forcing readers of the Newton
+    driver row and are not on the Krylov hot path yet."""
+    restore_opt = modelinfo["forced_surf_restore_opt"]
+    sms_opt = modelinfo["forced_sms_opt"]
+    if restore_opt not in ("none", "const") or sms_opt not in ("none", "const", "decay"):
+        raise NotImplementedError(
+            f"forced module with surf_restore_opt={restore_opt}, sms_opt={sms_opt} has no HIP engine yet")
+    if restore_opt == "none" and sms_opt != "decay":
+        raise ValueError("forced_sms_opt must be decay if forced_surf_restore_opt == none")
+    surf_rate, surf_target = 0.0, 0.0
+    if restore_opt == "const":
+        rate_10m = float(modelinfo.get("forced_surf_restore_rate_10m", 24.0 / 86400.0))
+        surf_rate = 10.0 / grid.depth.delta[0] * rate_10m
+        surf_target = float(modelinfo["forced_surf_restore_const"])
+    decay = float(modelinfo["forced_sms_decay_rate"]) if sms_opt == "decay" else 0.0
+    const_src = float(modelinfo["forced_sms_const"]) if sms_opt == "const" else 0.0
+    return ModuleEngine(grid, tc=1, surf_rate=(surf_rate,), surf_target=(surf_target,),
+                        decay_rate=(decay,), const_src=const_src, device_id=device_id, **kwargs)

@@ -22,7 +22,7 @@ import subprocess
 import numpy as np
 
 from . import ncio
-from .engine import ModuleEngine, iage_engine
+from .engine import ModuleEngine, forced_engine, iage_engine
 from .grid import Grid2d, SpatialAxis
 
 YEAR = 365.0 * 86400.0
@@ -169,6 +169,8 @@ def _module_engine(name, module_def, grid, device_id, modelinfo):
         kwargs["lin_tol"] = float(modelinfo["lin_tol"])
     if py_mod_name == "iage":
         return iage_engine(grid, device_id=device_id, **kwargs)
+    if py_mod_name == "forced":
+        return forced_engine(grid, modelinfo, device_id=device_id, **kwargs)
     raise NotImplementedError(
         f"tracer module {name} (py_mod_name={py_mod_name}) has no HIP engine yet")
 

@@ -333,6 +333,48 @@ class Iage(TracerModule):
         return res - v
 
 
+class Forced(TracerModule):
+    """forced_{suff} module, one tracer, state-independent option combinations
+    (reference `py_driver_2d/forced.py:57-139,141-190`): surface restoring to a constant
+    (or none), source-minus-sink constant / first-order decay (or none)"""
+
+    tc = 1
+
+    def __init__(self, model, surf_restore_opt="none", surf_restore_const=0.0, sms_opt="decay",
+                 sms_decay_rate=0.0, sms_const=0.0, surf_restore_rate_10m=24.0 / 86400.0):
+        super().__init__(model)
+        if surf_restore_opt not in ("none", "const") or sms_opt not in ("none", "const", "decay"):
+            raise NotImplementedError("file-driven forced options are outside the oracle")
+        self.surf_restore_opt = surf_restore_opt
+        self.sms_opt = sms_opt
+        self.surf_restore_rate = 10.0 / model.depth.delta[0] * surf_restore_rate_10m
+        self.surf_restore_const = surf_restore_const
+        self.sms_decay_rate = sms_decay_rate
+        self.sms_const = sms_const
+
+    def _add_sources(self, time, c, tend):
+        if self.surf_restore_opt != "none":
+            tend[0, 0, :] += self.surf_restore_rate * (self.surf_restore_const - c[0, 0, :])
+        if self.sms_opt == "const":
+            tend[0, :] += self.sms_const
+        if self.sms_opt == "decay":
+            tend[0, :] += -self.sms_decay_rate * c[0, :]
+        return tend
+
+    def diag_extra(self, tr):
+        ex = np.zeros((self.model.nz, self.model.ny))
+        if self.surf_restore_opt != "none":
+            ex[0, :] += -self.surf_restore_rate
+        if self.sms_opt == "decay":
+            ex += -self.sms_decay_rate
+        return ex
+
+    # same three-step product formula as iage (forced.py:192-241; the Jacobian of these
+    # option combinations does not depend on the tracer values read from the precond file)
+    precond_matrix = Iage.precond_matrix
+    apply_precond = Iage.apply_precond
+
+
 def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3):
     """The SAME operator as `Iage.apply_precond`, M^-1 = (I - A_0 A_1 A_2)^-1 - I with
     A_k = I - dt J(t_k), evaluated without forming the triple product: with

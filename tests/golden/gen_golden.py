@@ -168,6 +168,63 @@ def gen_precond(tag, nz, ny, vv, kh, seed):
     print("wrote precond", tag)
 
 
+def ref_forced(nz, ny, params):
+    """reference `forced` tracer module (one tracer) with the given option dict"""
+    from nk_ooc.py_driver_2d.advection import Advection
+    from nk_ooc.py_driver_2d.forced import forced
+    from nk_ooc.py_driver_2d.horiz_mix import HorizMix
+    from nk_ooc.py_driver_2d.vert_mix import VertMix
+
+    depth, ypos = ref_axes(nz, ny)
+    modelinfo = {"max_abs_vvel": "0.1", "horiz_mix_coeff": "1000.0"}
+    processes = {"advection": Advection(depth, ypos, modelinfo),
+                 "horiz_mix": HorizMix(depth, ypos, modelinfo),
+                 "vert_mix": VertMix(depth, ypos)}
+    tm = object.__new__(forced)
+    tm.name = "forced_x"
+    tm.tracer_cnt = 1
+    tm.depth = depth
+    tm.ypos = ypos
+    full = dict(params)
+    if full["surf_restore_opt"] != "none":
+        full["surf_restore_rate"] = 10.0 / depth.delta[0] * (24.0 / 86400.0)
+    forced.params = full
+    return depth, ypos, processes, tm
+
+
+def gen_forced(tag, nz, ny, params, seed, with_fcn=False):
+    from scipy import integrate
+
+    depth, ypos, processes, tm = ref_forced(nz, ny, params)
+    year = 365.0 * 86400.0
+    times = [0.0, 0.3 * year, 0.66 * year]
+    rng = np.random.default_rng(seed)
+    y = rng.standard_normal(nz * ny)
+    out = {"nz": nz, "ny": ny, "times": np.asarray(times), "y": y,
+           "surf_restore_opt": params["surf_restore_opt"], "sms_opt": params["sms_opt"],
+           "surf_restore_const": params.get("surf_restore_const", 0.0),
+           "sms_decay_rate": params.get("sms_decay_rate", 0.0),
+           "sms_const": params.get("sms_const", 0.0)}
+    out["tend"] = np.stack([tm.comp_tend(t, y, processes).copy() for t in times])
+    for i, t in enumerate(times):
+        jac = tm.comp_jacobian(t, y, processes).tocsr()
+        jac.sum_duplicates()
+        jac.sort_indices()
+        out[f"jac{i}_data"], out[f"jac{i}_indices"], out[f"jac{i}_indptr"] = jac.data, jac.indices, jac.indptr
+    if with_fcn:
+        # init_iterate_vals [1.0] of the forced_{suff} definition plus seeded structure: from
+        # the exactly uniform state the reference's own map amplifies 1e-15 noise to 1e-3
+        # (stale-Jacobian Newton on roundoff-level modes), which no parity test can use
+        y0 = np.ones(nz * ny) + 0.2 * np.random.default_rng(seed + 100).standard_normal(nz * ny)
+        time_range = (0.0, year)
+        sol = integrate.solve_ivp(
+            tm.comp_tend, time_range, y0, "Radau", np.array(time_range), max_step=year * 0.01,
+            atol=1.0e-6, rtol=1.0e-6, args=(processes,), jac=tm.comp_jacobian)
+        out.update(y0=y0, fcn=sol.y[:, -1] - y0, nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu)
+    np.savez_compressed(os.path.join(HERE, f"forced_{tag}.npz"), **out)
+    print("wrote forced", tag)
+
+
 def gen_lstsq(seed):
     """_comp_krylov_basis_coeffs known answers (krylov_solver.py:168-181)"""
     from nk_ooc.krylov_solver import _comp_krylov_basis_coeffs
@@ -198,6 +255,10 @@ def main():
     gen_precond("26x26", 26, 26, 0.1, 1000.0, 4)
     gen_precond("20x3_columns", 20, 3, 0.0, 0.0, 5)
     gen_lstsq(6)
+    gen_forced("decay_22x9", 22, 9, {"surf_restore_opt": "none", "sms_opt": "decay",
+                                     "sms_decay_rate": 1.0e-8}, 7, with_fcn=True)
+    gen_forced("restore_const_22x9", 22, 9, {"surf_restore_opt": "const", "surf_restore_const": 1.5,
+                                             "sms_opt": "const", "sms_const": -2.0e-9}, 8)
     gen_comp_fcn("20x3_columns", 20, 3, 0.0, 0.0)
     gen_comp_fcn("26x26", 26, 26, 0.1, 1000.0)
     gen_comp_fcn("26x26_bumpy", 26, 26, 0.1, 1000.0, init="bumpy")

@@ -1,0 +1,102 @@
+"""GPU parity of the `forced` tracer module (one tracer; decay / constant restoring
+variants, reference py_driver_2d/forced.py) and of a two-module (iage + forced) Krylov solve."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from oracle import krylov, radau
+from oracle.grid import default_axes
+from oracle.model import Forced, Iage, Py2dModel, apply_precond_stable
+
+pytestmark = pytest.mark.gpu
+YEAR = 365.0 * 86400.0
+
+
+def _modelinfo(g):
+    info = {"forced_surf_restore_opt": str(g["surf_restore_opt"]), "forced_sms_opt": str(g["sms_opt"])}
+    if info["forced_surf_restore_opt"] == "const":
+        info["forced_surf_restore_const"] = repr(float(g["surf_restore_const"]))
+    if info["forced_sms_opt"] == "decay":
+        info["forced_sms_decay_rate"] = repr(float(g["sms_decay_rate"]))
+    if info["forced_sms_opt"] == "const":
+        info["forced_sms_const"] = repr(float(g["sms_const"]))
+    return info
+
+
+@pytest.mark.parametrize("tag", ["decay_22x9", "restore_const_22x9"])
+def test_forced_kernels(golden_dir, tag):
+    from nk_ooc_amd.engine import forced_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    g = np.load(f"{golden_dir}/forced_{tag}.npz")
+    nz, ny = int(g["nz"]), int(g["ny"])
+    eng = forced_engine(Grid2d.default(nz, ny), _modelinfo(g))
+    depth, ypos = default_axes(nz, ny)
+    tm = Forced(Py2dModel(depth, ypos), str(g["surf_restore_opt"]), float(g["surf_restore_const"]),
+                str(g["sms_opt"]), float(g["sms_decay_rate"]), float(g["sms_const"]))
+    yd = eng.upload(g["y"])
+    for i, t in enumerate(g["times"]):
+        assert rel_err(eng.download(eng.tend(t, yd)).reshape(-1), g["tend"][i]) < 1e-13
+        diags = eng.jacobian_diags(t)
+        up, south, center, north, dn = tm.model.jac_diags(t)
+        assert np.max(np.abs(diags[2, 0] - (center + tm.diag_extra(0)))) < 1e-14 * np.max(np.abs(center))
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(nz * ny)
+    got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert rel_err(got, apply_precond_stable(tm, v)) < 1e-9
+    if "fcn" in g:
+        want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
+        fx, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=np.array(solver.schedule))
+        assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
+        fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]))
+        assert np.allclose(eng.download(fx).reshape(-1), g["fcn"], rtol=1e-3, atol=1e-6)
+        assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
+
+
+def test_two_module_krylov(tmp_path):
+    """tracer_module_names = iage,forced_{suff}:dye with the decay options: two engines
+    (two HIP streams), Hessenberg / beta of shape [2, ...]; compared with the oracle"""
+    from nk_ooc_amd.krylov_solver import KrylovSolver
+    from nk_ooc_amd.model_config import ModelConfig
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+
+    nz, ny = 22, 9
+    extra = {"forced_surf_restore_opt": "none", "forced_sms_opt": "decay", "forced_sms_decay_rate": "1.0e-8"}
+    cfg = make_config(str(tmp_path), nz, ny, tracer_module_names="iage,forced_{suff}:dye",
+                      extra_modelinfo=extra, extra_solverinfo={"krylov_max_iter": "2", "krylov_rel_tol": "1e-9"})
+    gen_grid_vars_file(cfg["modelinfo"])
+    ModelState.reset_class()
+    ModelState.model_config_obj = ModelConfig(cfg["modelinfo"])
+    ModelState.write_files = True
+    iterate = ModelState("gen_init_iterate")
+    assert [tms.name for tms in iterate.tracer_modules] == ["iage", "forced_dye"]
+    fcn = iterate.comp_fcn(os.path.join(str(tmp_path), "fcn_00.nc"), None)
+    solverinfo = dict(cfg["solverinfo"], krylov_workdir=os.path.join(str(tmp_path), "krylov_00"))
+    solver = KrylovSolver(iterate, solverinfo, False, False, None)
+    solver.solve(os.path.join(str(tmp_path), "increment_00.nc"), fcn)
+    beta = solver._solver_state.get_value_saved_state("beta")
+    h_mat = solver._solver_state.get_value_saved_state("h_mat")
+    assert beta.shape == (2, 1) and h_mat.shape == (2, 3, 2, 1)
+    # oracle with the same two modules
+    depth, ypos = default_axes(nz, ny)
+    model = Py2dModel(depth, ypos)
+    weight = np.outer(depth.delta, ypos.delta)
+    regions = krylov.Regions(np.ones((nz, ny), dtype=np.int32), weight)
+    mods = [krylov.OracleModule(Iage(model), regions, precond="stable"),
+            krylov.OracleModule(Forced(model, "none", 0.0, "decay", 1.0e-8), regions, precond="stable")]
+    x = [iterate.tracer_modules[i].get_tracer_vals_all().reshape(-1) for i in range(2)]
+    f = [m.comp_fcn(v) for m, v in zip(mods, x)]
+    for i in range(2):
+        assert np.allclose(fcn.tracer_modules[i].get_tracer_vals_all().reshape(-1), f[i], rtol=1e-3, atol=1e-6)
+    _, trace = krylov.krylov_solve(mods, x, f, rel_tol=1e-9, max_iter=2)
+    assert rel_err(beta, trace["beta"]) < 1e-4
+    assert rel_err(h_mat, trace["h_mat"][-1]) < 2e-2
+    # the saved-state file holds both modules' tracers
+    from nk_ooc_amd import ncio
+
+    data, _ = ncio.read_file(os.path.join(str(tmp_path), "increment_00.nc"))
+    assert {"iage", "iage_slow_rest", "dye"} <= set(data)
+    ModelState.reset_class()

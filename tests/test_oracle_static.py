@@ -59,3 +59,27 @@ def test_lstsq_known_answers(golden_dir):
     g = np.load(f"{golden_dir}/lstsq.npz")
     for case in range(3):
         assert np.array_equal(basis_coeffs(g[f"beta{case}"], g[f"h{case}"]), g[f"coeff{case}"])
+
+
+@pytest.mark.parametrize("tag", ["decay_22x9", "restore_const_22x9"])
+def test_forced_module_bitwise(golden_dir, tag):
+    """`forced` tracer module (decay analogue of BASELINE.json's dye_decay), reference
+    py_driver_2d/forced.py:114-190"""
+    from oracle import radau
+    from oracle.grid import default_axes
+    from oracle.model import Forced, Py2dModel
+
+    g = np.load(f"{golden_dir}/forced_{tag}.npz")
+    depth, ypos = default_axes(int(g["nz"]), int(g["ny"]))
+    tm = Forced(Py2dModel(depth, ypos), str(g["surf_restore_opt"]), float(g["surf_restore_const"]),
+                str(g["sms_opt"]), float(g["sms_decay_rate"]), float(g["sms_const"]))
+    for i, t in enumerate(g["times"]):
+        assert np.array_equal(tm.comp_tend(t, g["y"]), g["tend"][i])
+        jac = tm.comp_jacobian(t).tocsr()
+        want = sparse.csr_matrix((g[f"jac{i}_data"], g[f"jac{i}_indices"], g[f"jac{i}_indptr"]), shape=jac.shape)
+        diff = jac - want
+        assert diff.nnz == 0 or abs(diff).max() == 0.0
+    if "fcn" in g:
+        res, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
+        assert np.array_equal(res, g["fcn"])
+        assert (solver.stats.nfev, solver.stats.njev, solver.stats.nlu) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]))
