@@ -126,6 +126,13 @@ int nk2d_comp_fcn(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats,
                   const double* replay, int64_t replay_n,
                   double* record, int64_t record_cap, int64_t* record_n);
 
+/* the same forward year with dense output: the solution at the n_eval increasing times t_eval
+   (within [t0, t1]) is written to host_hist [n_eval][tc][nz][ny], evaluated from each step's
+   collocation polynomial as solve_ivp(t_eval=...) does (the 61-sample history of
+   py_driver_2d/model_state.py:80-83) */
+int nk2d_comp_fcn_hist(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, int32_t n_eval,
+                       const double* t_eval, double* host_hist);
+
 /* preconditioner  M^-1 v = (I - prod_k (I - dt J(t_k)))^-1 v - v */
 int nk2d_precond_setup(nk2d_ctx* ctx);
 int nk2d_precond_apply(nk2d_ctx* ctx, nk2d_vec v, nk2d_vec out);

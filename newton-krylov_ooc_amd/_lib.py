@@ -95,6 +95,7 @@ SIGNATURES = {
     "nk2d_shifted_solve": (_ci, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, c_int32_p]),
     "nk2d_comp_fcn": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), c_double_p, _i64,
                             c_double_p, _i64, c_int64_p]),
+    "nk2d_comp_fcn_hist": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), _i32, c_double_p, c_double_p]),
     "nk2d_precond_setup": (_ci, [_vp]),
     "nk2d_precond_apply": (_ci, [_vp, _vp, _vp]),
     "nk2d_dot": (_ci, [_vp, _vp, _vp, c_double_p]),

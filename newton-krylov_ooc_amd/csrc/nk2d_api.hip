@@ -215,6 +215,10 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hCTL, 128));
     c->cur_guard = nullptr;
     c->device_ctl = 0;
+    c->hist_n = 0;
+    c->hist_next = 0;
+    c->hist_t = nullptr;
+    c->hist_host = nullptr;
     c->sweep_wpb = 4;
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     c->rcoef_elems = 0;
@@ -480,6 +484,46 @@ extern "C" int nk2d_comp_fcn(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* s
     NK2D_CHECK(c, hipSetDevice(c->dev));
     if (record_n) *record_n = 0;
     return nk2d_radau_year(c, x, fx, stats, replay, replay_n, record, record_cap, record_n);
+}
+
+// samples of the solution at t_eval (scipy ivp.py:707-723: every t_eval <= t not yet emitted is
+// evaluated with the dense output of the step just taken)
+int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first) {
+    const size_t n = (size_t)c->tc * c->nz * c->ny;
+    while (c->hist_next < c->hist_n && c->hist_t[c->hist_next] <= t_new) {
+        const double te = c->hist_t[c->hist_next];
+        const double x = (te - t_old) / (t_new - t_old);
+        NK2D_TRY(nk2d_r_dense(c, x, c->TMP));
+        NK2D_TRY(ensure_stage(c, n));
+        NK2D_TRY(nk2d_k_unpack_state(c, c->TMP, c->STAGE));
+        NK2D_CHECK(c, hipMemcpyAsync(c->hist_host + (size_t)c->hist_next * n, c->STAGE, sizeof(double) * n,
+                                     hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        c->hist_next++;
+    }
+    (void)first;
+    return 0;
+}
+
+extern "C" int nk2d_comp_fcn_hist(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, int32_t n_eval,
+                                  const double* t_eval, double* host_hist) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    for (int i = 1; i < n_eval; ++i)
+        if (!(t_eval[i] > t_eval[i - 1])) return nk2d_fail(c, "nk2d_comp_fcn_hist: t_eval must be increasing");
+    if (n_eval > 0 && (t_eval[0] < c->d.t0 || t_eval[n_eval - 1] > c->d.t1))
+        return nk2d_fail(c, "nk2d_comp_fcn_hist: t_eval outside the time range");
+    c->hist_n = n_eval;
+    c->hist_next = 0;
+    c->hist_t = t_eval;
+    c->hist_host = host_hist;
+    const int rc = nk2d_radau_year(c, x, fx, stats, nullptr, 0, nullptr, 0, nullptr);
+    const bool complete = c->hist_next == n_eval;
+    c->hist_n = 0;
+    c->hist_t = nullptr;
+    c->hist_host = nullptr;
+    if (rc != 0) return rc;
+    if (!complete) return nk2d_fail(c, "nk2d_comp_fcn_hist: not every t_eval sample was produced");
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------

@@ -87,6 +87,11 @@ struct nk2d_ctx {
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
 
+    // optional dense-output sampling of the running comp_fcn (history files)
+    int hist_n, hist_next;
+    const double* hist_t;
+    double* hist_host;   // [hist_n][tc][nz][ny]
+
     // counters of the running comp_fcn
     nk2d_stats st;
 
@@ -463,11 +468,13 @@ int nk2d_r_err_norm(nk2d_ctx* c, const double* err);
 int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys);
 int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out);
 int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out);
+int nk2d_r_dense(nk2d_ctx* c, double x, double* out);
 int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total);
 int nk2d_r_reduce_newton(nk2d_ctx* c);
 int nk2d_r_reduce_err(nk2d_ctx* c);
 int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8);
 // nk2d_radau.hip
+int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first);
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,
                     int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n);
 // nk2d_precond.hip

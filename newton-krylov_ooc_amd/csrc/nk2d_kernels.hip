@@ -1158,6 +1158,36 @@ __global__ void k_final(int ncol, int ny, const double* __restrict__ yold, const
     store_col<E>(out, task, lane, yo);
 }
 
+// dense output y(t) = y_old + Q [x, x^2, x^3], Q = Z^T P  (radau.py:557-570), for t_eval samples
+template <int E>
+__global__ void k_dense(int ncol, const double* __restrict__ yold, const double* __restrict__ zp, size_t nv, double x,
+                        double* __restrict__ out) {
+    TASK_PROLOGUE(ncol)
+    double yo[E], z0[E], z1[E], z2[E];
+    load_col<E>(yold, task, lane, yo);
+    load_col<E>(zp, task, lane, z0);
+    load_col<E>(zp + nv, task, lane, z1);
+    load_col<E>(zp + 2 * nv, task, lane, z2);
+    const double p1 = x, p2 = p1 * x, p3 = p2 * x;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double q[3];
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+        double v = (q[0] * p1 + q[1] * p2) + q[2] * p3;
+        yo[e] = v + yo[e];
+    }
+    store_col<E>(out, task, lane, yo);
+}
+
+int nk2d_r_dense(nk2d_ctx* c, double x, double* out) {
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_dense<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                              c->ncol, c->YOLD, c->ZP, c->nv, x, out));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
 // --- host wrappers used by the Radau driver --------------------------------------
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_predict<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,

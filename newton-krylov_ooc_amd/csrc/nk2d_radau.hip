@@ -348,6 +348,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
         NK2D_TRY(commit_step(s, t, t_new));
+        if (c->hist_n > 0) NK2D_TRY(nk2d_hist_sample(c, t, t_new, nrec == 1));
         if (t + h == t_new) std::swap(c->KV[3], c->KV[2]);  // stage-3 plane is the plane at t_new
         else NK2D_TRY(eval_kv(c, t_new, 3));
         NK2D_TRY(nk2d_k_tend(c, c->Y, c->KV[3], c->F));

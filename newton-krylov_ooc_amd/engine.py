@@ -206,6 +206,16 @@ class ModuleEngine:
         return {"avg_us": avg.value, "samples": samples.value, "launches": launches.value,
                 "bytes": nbytes.value, "event_overhead_us": ovh.value}
 
+    def comp_fcn_hist(self, x, t_eval, out=None):
+        """forward year with dense output: returns (fx, stats, hist [len(t_eval), tc, nz, ny])"""
+        out = self.new_vec() if out is None else out
+        t_eval = np.ascontiguousarray(t_eval, dtype=np.float64)
+        hist = np.empty((len(t_eval),) + self.shape)
+        stats = _lib.Stats()
+        self._chk(self._lib.nk2d_comp_fcn_hist(self._ctx, x.ptr, out.ptr, ctypes.byref(stats),
+                                               len(t_eval), _dp(t_eval), _dp(hist)))
+        return out, stats.as_dict(), hist
+
     # ---- preconditioner -----------------------------------------------------------
     def precond_setup(self):
         self._chk(self._lib.nk2d_precond_setup(self._ctx))

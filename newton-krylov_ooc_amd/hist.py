@@ -1,0 +1,127 @@
+"""History file of one forward model year (61 dense-output samples).
+
+The Newton driver asks `comp_fcn` for a history file; the reference writes it in
+`nk_ooc/py_driver_2d/model_state.py:141-233` with the per-process variables of
+`advection.py:78-109`, `horiz_mix.py:73-98`, `vert_mix.py:103-138` and the tracer-like
+variables of `py_driver_2d/tracer_module_state.py:110-260`.  The samples themselves come from
+the device integrator's dense output (`nk2d_comp_fcn_hist`); the reductions below are the
+reference's, on the host, once per file.
+"""
+
+import numpy as np
+from scipy.io import netcdf_file
+
+from . import ncio
+from .grid import BLDEPTH_MIN, bldepth_time_knots
+
+
+def time_mean_weights(ntime):
+    """trapezoid in time: t = 0 and t = end are both in the file"""
+    weights = np.full(ntime, 1.0 / (ntime - 1))
+    weights[0] *= 0.5
+    weights[-1] *= 0.5
+    return weights
+
+
+def bldepth(grid, time):
+    tvals, fvals = bldepth_time_knots()
+    frac = np.interp(time, tvals, fvals)
+    return BLDEPTH_MIN + (grid.bldepth_max - BLDEPTH_MIN) * frac
+
+
+def _units_product(*units):
+    return " ".join(f"({unit})" for unit in units)
+
+
+def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):
+    """module_hists: list of (tracer metadata dict name -> attrs, hist [ntime, tc, nz, ny]);
+    vmix_coeff_fcn(t) -> (nz-1, ny) mixing coefficient / dz_mid"""
+    depth, ypos = grid.depth, grid.ypos
+    dname, yname = depth.axisname, ypos.axisname
+    dedge, yedge = depth.dump_names["edges"], ypos.dump_names["edges"]
+    ntime = len(time)
+    weights = time_mean_weights(ntime)
+    with netcdf_file(fname, "w", version=2) as fptr:
+        fptr.history = ncio.history_stamp(f"{__name__}._gen_hist")
+        fptr.createDimension("time", None)
+        for axis in (depth, ypos):
+            for dimname, dimlen in axis.dump_dimensions().items():
+                if dimname not in fptr.dimensions:
+                    fptr.createDimension(dimname, dimlen)
+
+        def defvar(name, dims, attrs):
+            var = fptr.createVariable(name, ">f8", dims)
+            for key, val in attrs.items():
+                setattr(var, key, val)
+            if name != "time" and "time" in dims:
+                var.cell_methods = "time: point"
+            return var
+
+        defvar("time", ("time",), {"long_name": "time", "units": "seconds since 0001-01-01",
+                                   "calendar": "noleap"})
+        for axis in (depth, ypos):
+            for name, metadata in axis.dump_vars_metadata().items():
+                defvar(name, metadata["dimensions"], metadata["attrs"])
+        defvar("stream", (dedge, yedge), {"long_name": "velocity streamfunction", "units": "m^2 / s"})
+        defvar("vvel", (dname, yedge), {"long_name": "velocity in ypos direction", "units": "m / s"})
+        defvar("wvel", (dedge, yname), {"long_name": "velocity in depth direction", "units": "m / s"})
+        defvar("horiz_mixing_coeff", (dname, yedge),
+               {"long_name": "horizontal mixing coefficient", "units": "m^2 / s"})
+        defvar("bldepth", ("time", yname), {"long_name": "boundary layer depth", "units": "m"})
+        defvar("vert_mixing_coeff", ("time", dedge, yname),
+               {"long_name": "vertical mixing coefficient", "units": "m^2 / s"})
+        for tracers, _ in module_hists:
+            for tname, attrs in tracers.items():
+                units = attrs.get("units", "1")
+                for suffix, dims, label, unit in (
+                    ("", ("time", dname, yname), "", units),
+                    ("_time_mean", (dname, yname), ", time mean", units),
+                    ("_time_anom", ("time", dname, yname), ", time anomaly", units),
+                    ("_time_std", (dname, yname), ", time std dev", units),
+                    ("_time_delta", (dname, yname), ", end state minus start state", units),
+                    ("_depth_int", ("time", yname), ", depth integral", _units_product(units, depth.units)),
+                    ("_ypos_mean", ("time", dname), ", ypos mean", units),
+                    ("_depth_ypos_int", ("time",), ", depth-ypos integral",
+                     _units_product(units, depth.units, ypos.units)),
+                ):
+                    var_attrs = dict(attrs)
+                    var_attrs["long_name"] = attrs.get("long_name", tname) + label
+                    var_attrs["units"] = unit
+                    defvar(tname + suffix, dims, var_attrs)
+
+        # ---- values
+        fptr.variables["time"][:] = time
+        for axis in (depth, ypos):
+            for name, vals in axis.dump_vals_dict().items():
+                fptr.variables[name][:] = vals
+        fptr.variables["stream"][:] = grid.stream
+        fptr.variables["vvel"][:] = grid.vvel
+        fptr.variables["wvel"][:] = grid.wvel
+        hmix = np.empty((len(depth), len(ypos) + 1))
+        hmix[:, 1:-1] = grid.hmix_coeff * ypos.delta_mid
+        hmix[:, 0] = hmix[:, 1]      # edge values copied to avoid missing values
+        hmix[:, -1] = hmix[:, -2]
+        fptr.variables["horiz_mixing_coeff"][:] = hmix
+        bld = np.stack([bldepth(grid, t) for t in time])
+        fptr.variables["bldepth"][:] = bld
+        vmix = np.empty((ntime, len(depth) + 1, len(ypos)))
+        for ind, t in enumerate(time):
+            vmix[ind, 1:-1, :] = vmix_coeff_fcn(t) * depth.delta_mid[:, np.newaxis]
+        vmix[:, 0, :] = vmix[:, 1, :]
+        vmix[:, -1, :] = vmix[:, -2, :]
+        fptr.variables["vert_mixing_coeff"][:] = vmix
+        yspan = ypos.edges.max() - ypos.edges.min()
+        for tracers, hist in module_hists:
+            for ind, tname in enumerate(tracers):
+                vals = hist[:, ind]                       # (time, depth, ypos)
+                mean = np.einsum("i,i...", weights, vals)
+                anom = vals - mean
+                fptr.variables[tname][:] = vals
+                fptr.variables[tname + "_time_mean"][:] = mean
+                fptr.variables[tname + "_time_anom"][:] = anom
+                fptr.variables[tname + "_time_std"][:] = np.sqrt(np.einsum("i,i...", weights, anom ** 2))
+                fptr.variables[tname + "_time_delta"][:] = vals[-1] - vals[0]
+                fptr.variables[tname + "_depth_int"][:] = (depth.delta[:, np.newaxis] * vals).sum(axis=-2)
+                ypos_int = (ypos.delta * vals).sum(axis=-1)
+                fptr.variables[tname + "_ypos_mean"][:] = ypos_int / yspan
+                fptr.variables[tname + "_depth_ypos_int"][:] = (depth.delta * ypos_int).sum(axis=-1)

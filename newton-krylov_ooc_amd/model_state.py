@@ -21,6 +21,7 @@ import subprocess
 
 import numpy as np
 
+from . import hist as hist_mod
 from . import ncio
 from .engine import ModuleEngine, forced_engine, iage_engine
 from .grid import Grid2d, SpatialAxis
@@ -420,15 +421,21 @@ class ModelState:
         if solver_state is not None and solver_state.step_logged(fcn_complete_step):
             logger.debug('"%s" logged, returning result', fcn_complete_step)
             return type(self)(res_fname)
-        if hist_fname is not None:
-            raise NotImplementedError(
-                "history (dense output) files are written by the Newton driver row, "
-                "not by the Krylov hot path")
-        mods, stats = [], []
+        mods, stats, hists = [], [], []
+        t_eval = np.linspace(self.time_range[0], self.time_range[1], 61)
         for tms in self.tracer_modules:
-            fx, st, _ = tms.eng.comp_fcn(tms.vec)
+            if hist_fname is None:
+                fx, st, _ = tms.eng.comp_fcn(tms.vec)
+            else:
+                fx, st, hist = tms.eng.comp_fcn_hist(tms.vec, t_eval)
+                tracers = {name: dict(meta.get("attrs", {}))
+                           for name, meta in tms._tracer_module_def["tracers"].items()}
+                hists.append((tracers, hist))
             mods.append(tms._like(fx))
             stats.append(st)
+        if hist_fname is not None and self.write_files:
+            hist_mod.write_hist_file(hist_fname, self._grid, t_eval, hists,
+                                     self.tracer_modules[0].eng.vmix_coeff)
         type(self).last_stats = stats
         res_ms = self._new(mods)
         # zero_extra_tracers: no shadow tracers in the py_driver_2d modules handled here;
@@ -451,23 +458,56 @@ class ModelState:
         return self
 
     # ---- preconditioner ------------------------------------------------------------------------------------
+    def hist_vars_for_precond_list(self):
+        """history variables the preconditioners in use need (model_state_base.py:379-389)"""
+        defs = self.model_config_obj.precond_matrix_defs
+        names = []
+        for tms in self.tracer_modules:
+            for metadata in tms._tracer_module_def["tracers"].values():
+                if "precond_matrix" in metadata and metadata["precond_matrix"] not in names:
+                    names.append(metadata["precond_matrix"])
+        res = []
+        for matrix_name in names + ["base"]:
+            for varname in defs[matrix_name]["hist_to_precond_varnames"]:
+                if varname not in res:
+                    res.append(varname)
+        return res
+
     def gen_precond_jacobian(self, hist_fname, precond_fname, solver_state):
-        """file(s) the preconditioner reads (model_state_base.py:404-481).  The iage
-        preconditioner needs nothing from it; the file carries the `time` axis of the
-        history file as in the reference."""
+        """file(s) the preconditioner reads: the listed history variables, optionally reduced
+        over time (`:mean`, `:log_mean`) (model_state_base.py:404-481).  Without a history file
+        (Krylov solver used on its own) only the `time` axis is written."""
         step = f"ModelStateBase.gen_precond_jacobian {precond_fname}"
         if solver_state is not None and solver_state.step_logged(step, per_iteration=False):
             return
         if self.write_files:
+            time_attrs = {"long_name": "time", "units": "seconds since 0001-01-01", "calendar": "noleap"}
+            dims, variables = {}, {}
+            history = ncio.history_stamp(f"{_class_name(self)}.gen_precond_jacobian")
             if hist_fname is not None and os.path.exists(hist_fname):
-                data, _ = ncio.read_file(hist_fname, ["time"])
-                time = data["time"]
+                wanted = self.hist_vars_for_precond_list()
+                data, attrs = ncio.read_file(hist_fname, [name.partition(":")[0] for name in wanted])
+                if "history" in attrs:
+                    history = "\n".join([history, attrs["history"]])
+                var_dims = ncio.read_var_dims(hist_fname, list(data))
+                for spec in wanted:
+                    name, _, time_op = spec.partition(":")
+                    vals, vdims = data[name], list(var_dims[name])
+                    vattrs = ncio.read_var_attrs(hist_fname, name)
+                    if time_op == "mean":
+                        vals, vdims, name = vals.mean(axis=0), vdims[1:], f"{name}_mean"
+                    elif time_op == "log_mean":
+                        vals, vdims, name = np.exp(np.log(vals).mean(axis=0)), vdims[1:], f"{name}_log_mean"
+                    if "time" not in vdims:
+                        vattrs.pop("cell_methods", None)
+                    for dimname, dimlen in zip(vdims, vals.shape):
+                        dims.setdefault(dimname, dimlen)
+                    variables[name] = (tuple(vdims), ">f8", vattrs, vals)
             else:
                 time = np.linspace(self.time_range[0], self.time_range[1], 61)
-            attrs = {"long_name": "time", "units": "seconds since 0001-01-01", "calendar": "noleap"}
-            history = ncio.history_stamp(f"{_class_name(self)}.gen_precond_jacobian")
-            ncio.write_vars_file(precond_fname, {"time": len(time)},
-                                 {"time": (("time",), ">f8", attrs, time)}, history)
+                dims["time"] = len(time)
+                variables["time"] = (("time",), ">f8", time_attrs, time)
+            ncio.write_vars_file(precond_fname, dims, variables, history)
         if solver_state is not None:
             solver_state.log_step(step, per_iteration=False)
 
@@ -502,6 +542,104 @@ class ModelState:
         res = ((perturb_fcn - fcn) / sigma).dump(res_fname, caller)
         solver_state.log_step(fcn_complete_step)
         return res
+
+
+    # ---- what the Newton solver needs beyond the Krylov path ------------------------------------------
+    def shadow_tracers_on(self):
+        return False  # no py_driver_2d tracer module declares shadow tracers
+
+    def copy_shadow_tracers_to_real_tracers(self):
+        return self
+
+    def copy_real_tracers_to_shadow_tracers(self):
+        return self
+
+    def apply_limiter(self, base):
+        """scale self (an increment) so that base + scalef * self respects the tracer bounds,
+        per region; returns scalef [ntm, nreg] (tracer_module_state_base.py:112-151 with
+        utils.py:562-600).  Host side: once per Newton iteration, not on the hot path."""
+        nreg = self.model_config_obj.region_cnt
+        scalef = np.ones((len(self.tracer_modules), nreg))
+        for ind, tms in enumerate(self.tracer_modules):
+            module_def = tms._tracer_module_def
+            bounded = "bounds" in module_def or any("bounds" in m for m in module_def["tracers"].values())
+            if not bounded:
+                continue
+            inc = tms.get_tracer_vals_all()
+            ref = base.tracer_modules[ind].get_tracer_vals_all()
+            for tr, (tname, metadata) in enumerate(module_def["tracers"].items()):
+                lob, upb = None, None
+                for src in (module_def, metadata):
+                    if "bounds" in src:
+                        lob = src["bounds"].get("lob", lob)
+                        upb = src["bounds"].get("upb", upb)
+                mask = self.model_config_obj.grid_vars[metadata["region_mask_varname"]]["region_mask"]
+                for bound, sign in ((lob, -1.0), (upb, 1.0)):
+                    if bound is None:
+                        continue
+                    viol = sign * (ref[tr] + inc[tr] - bound) > 0.0
+                    if not viol.any():
+                        continue
+                    if (sign * (ref[tr] - bound) > 0.0).any():
+                        raise ValueError("base < lob" if sign < 0 else "base > upb")
+                    ratio = np.ones(ref[tr].shape)
+                    np.divide(bound - ref[tr], inc[tr], out=ratio, where=viol)
+                    for reg in range(nreg):
+                        cand = np.amin(ratio, initial=np.inf, where=mask == reg + 1)
+                        scalef[ind, reg] = min(scalef[ind, reg], cand)
+            if (scalef[ind] < 1.0).any():
+                tms.log_vals("applying scalef", scalef[ind])
+                tms *= scalef[ind]
+        return scalef
+
+    # model-specific statistics read from a history file (model_state_base.py:138-177,
+    # py_driver_2d/tracer_module_state.py:280-341)
+    def def_stats_vars(self, stats_file, hist_fname, solver_state):
+        step = "ModelStateBase.def_stats_vars"
+        if solver_state is not None and solver_state.step_logged(step, per_iteration=False):
+            return
+        dims, vars_metadata = {}, {}
+        for axis in (self.depth, self.ypos):
+            dims.update(axis.dump_dimensions())
+            vars_metadata.update(axis.dump_vars_metadata())
+        for tms in self.tracer_modules:
+            for tname in tms.tracer_names:
+                attrs = ncio.read_var_attrs(hist_fname, tname)
+                attrs.pop("cell_methods", None)
+                vars_metadata[tname] = {
+                    "dimensions": ("iteration", self.depth.axisname, self.ypos.axisname), "attrs": attrs}
+                vars_metadata[f"{tname}_mean_{self.ypos.axisname}"] = {
+                    "dimensions": ("iteration", self.depth.axisname), "attrs": attrs}
+        stats_file.def_dimensions(dims)
+        stats_file.def_vars(vars_metadata)
+        if solver_state is not None:
+            solver_state.log_step(step, per_iteration=False)
+
+    def put_stats_vars_iteration_invariant(self, stats_file, hist_fname, solver_state):
+        step = "ModelStateBase.put_stats_vars_iteration_invariant"
+        if solver_state is not None and solver_state.step_logged(step, per_iteration=False):
+            return
+        vals = {}
+        for axis in (self.depth, self.ypos):
+            vals.update(axis.dump_vals_dict())
+        stats_file.put_vars_iteration_invariant(vals)
+        if solver_state is not None:
+            solver_state.log_step(step, per_iteration=False)
+
+    def put_stats_vars(self, stats_file, hist_fname, solver_state):
+        step = "ModelStateBase.put_stats_vars"
+        if solver_state is not None and solver_state.step_logged(step):
+            return
+        names = [tname for tms in self.tracer_modules for tname in tms.tracer_names]
+        data, _ = ncio.read_file(hist_fname, names)
+        weights = hist_mod.time_mean_weights(next(iter(data.values())).shape[0])
+        ypos_weights = self.ypos.delta / self.ypos.delta.sum()
+        vals = {}
+        for tname in names:
+            vals[tname] = np.einsum("i,i...", weights, data[tname])
+            vals[f"{tname}_mean_{self.ypos.axisname}"] = np.einsum("j,...j", ypos_weights, vals[tname])
+        stats_file.put_vars(solver_state.get_iteration(), vals)
+        solver_state.log_step(step)
 
 
 def lin_comb(res_type, coeff, fname_fcn, quantity):

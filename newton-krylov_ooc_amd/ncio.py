@@ -38,6 +38,11 @@ def read_var_attrs(fname, varname):
         return {k: _decode(v) for k, v in fptr.variables[varname]._attributes.items()}
 
 
+def read_var_dims(fname, varnames):
+    with netcdf_file(fname, "r", mmap=False) as fptr:
+        return {name: tuple(fptr.variables[name].dimensions) for name in varnames}
+
+
 def history_stamp(creator, caller=None):
     datestamp = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
     msg = f"{datestamp}: created by {creator}"

@@ -1,0 +1,82 @@
+"""Driver of the Newton-Krylov solve (reference `nk_ooc/nk_driver.py:38-67`).
+
+    python -m nk_ooc_amd.nk_driver --workdir DIR [--cfg_fnames a.cfg,b.cfg] [--resume] [--rewind]
+                                   [--depth_nlevs N --ypos_nlevs N] [--tracer_module_names ...]
+
+Reads the same cfg files as the reference, configures the model, and iterates
+`NewtonSolver.step()` until `converged().all()`.  `reinvoke` is forced off (the reference's
+`--persist`): the process keeps the GPU contexts alive instead of exiting after every forward
+year; `--resume` continues from the JSON checkpoints exactly as the reference does.
+"""
+
+import argparse
+import logging
+import os
+import sys
+
+from .model_config import ModelConfig, read_cfg_files
+from .model_state import ModelState
+from .newton_solver import NewtonSolver
+from .setup_solver import default_cfg_fnames
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Newton-Krylov solver, MI355X path")
+    parser.add_argument("--cfg_fnames", default=default_cfg_fnames())
+    parser.add_argument("--workdir", default=None)
+    parser.add_argument("--tracer_module_names", default=None)
+    parser.add_argument("--depth_nlevs", default=None)
+    parser.add_argument("--ypos_nlevs", default=None)
+    parser.add_argument("--newton_max_iter", default=None)
+    parser.add_argument("--newton_rel_tol", default=None)
+    parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--rewind", action="store_true")
+    return parser.parse_args(argv)
+
+
+def config_from_args(args):
+    overrides = {"DEFAULT": {}, "modelinfo": {"reinvoke": "False"}, "solverinfo": {}}
+    if args.workdir is not None:
+        overrides["DEFAULT"]["workdir"] = args.workdir
+    for key in ("tracer_module_names", "depth_nlevs", "ypos_nlevs"):
+        if getattr(args, key) is not None:
+            overrides["modelinfo"][key] = getattr(args, key)
+    for key in ("newton_max_iter", "newton_rel_tol"):
+        if getattr(args, key) is not None:
+            overrides["solverinfo"][key] = getattr(args, key)
+    return read_cfg_files(args.cfg_fnames, overrides=overrides, write_cfg_out=True)
+
+
+def run(config, resume=False, rewind=False, model_state_class=ModelState):
+    """Newton iterations to convergence; returns the NewtonSolver"""
+    logger = logging.getLogger(__name__)
+    if os.path.exists("KILL"):
+        logger.warning("KILL file detected, exiting")
+        raise SystemExit
+    model_state_class.reset_class()
+    model_state_class.model_config_obj = ModelConfig(config["modelinfo"])
+    solver = NewtonSolver(model_state_class, solverinfo=config["solverinfo"], resume=resume, rewind=rewind)
+    while True:
+        if solver.converged().all():
+            logger.info("Newton convergence criterion satisfied")
+            solver.log()
+            break
+        solver.step()
+    return solver
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config = config_from_args(args)
+    solverinfo = config["solverinfo"]
+    os.makedirs(solverinfo["workdir"], exist_ok=True)
+    logging.basicConfig(
+        level=getattr(logging, solverinfo.get("logging_level", "INFO")),
+        format="%(asctime)s:%(process)s:%(filename)s:%(funcName)s:%(message)s",
+        handlers=[logging.FileHandler(solverinfo["logging_fname"], mode="a"), logging.StreamHandler(sys.stdout)],
+    )
+    run(config, resume=args.resume, rewind=args.rewind)
+
+
+if __name__ == "__main__":
+    main()

@@ -74,7 +74,8 @@ def setup(config, fp_cnt=1, init_iterate_opt="gen_init_iterate"):
     os.makedirs(gen_dir, exist_ok=True)
     for fp_iter in range(fp_cnt):
         init_iterate.dump(os.path.join(gen_dir, f"init_iterate_{fp_iter:04}.nc"), caller)
-        fcn = init_iterate.comp_fcn(os.path.join(gen_dir, f"fcn_{fp_iter:04}.nc"), None)
+        fcn = init_iterate.comp_fcn(os.path.join(gen_dir, f"fcn_{fp_iter:04}.nc"), None,
+                                    os.path.join(gen_dir, f"hist_{fp_iter:04}.nc"))
         init_iterate += fcn
     init_iterate_fname = solverinfo["init_iterate_fname"]
     os.makedirs(os.path.dirname(init_iterate_fname), exist_ok=True)

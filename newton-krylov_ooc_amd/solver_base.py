@@ -44,54 +44,82 @@ class SolverBase:
         key = f"{self._solver_name}_min_iter".lower()
         return int(self._solverinfo[key]) if key in self._solverinfo else 0
 
-    # ---- per-tracer-module statistics ------------------------------------------------
+    # ---- solver statistics (<Solver>_stats.nc) ------------------------------------------
+    # categories as in the reference: "per_tracer_module" (one variable per module),
+    # "model_state" (mean and norm of a model state, per module), "tracer_module_independent"
     def _def_solver_stats_vars(self, stats_vars_dict, tracer_modules):
-        """define `<key>_<module>` variables for the per_tracer_module statistics"""
         vars_def = {}
         for key, metadata in stats_vars_dict.items():
             dims = metadata["dimensions"]
             if "iteration" in dims and dims[0] != "iteration":
                 raise ValueError("iteration must be first dimension, if present")
-            if metadata["category"] != "per_tracer_module":
-                raise ValueError(f"unknown category {metadata['category']}")
-            names = []
-            for tms in tracer_modules:
-                repl = {"tracer_module_name": tms.name, "tracer_module_units": tms.units}
+            category = metadata["category"]
+            entry = {"category": category, "dimensions": dims}
+
+            def module_var(tms, method=None):
+                repl = {"tracer_module_name": tms.name, "tracer_module_units": tms.units,
+                        "method": method}
                 attrs = {k: v.format(**repl) for k, v in metadata["attrs"].items()}
                 if attrs.get("units") == "None":
                     attrs["units"] = None
-                vars_def[f"{key}_{tms.name}"] = {"dimensions": dims, "attrs": attrs}
-                names.append(f"{key}_{tms.name}")
-            self._stats_vars[key] = {"dimensions": dims, "names": names}
+                return {"dimensions": dims, "attrs": attrs,
+                        "datatype": metadata.get("datatype", "f8")}
+
+            if category == "per_tracer_module":
+                entry["names"] = []
+                for tms in tracer_modules:
+                    vars_def[f"{key}_{tms.name}"] = module_var(tms)
+                    entry["names"].append(f"{key}_{tms.name}")
+            elif category == "model_state":
+                entry["names"] = {"mean": [], "norm": []}
+                for method in ("mean", "norm"):
+                    for tms in tracer_modules:
+                        vars_def[f"{key}_{method}_{tms.name}"] = module_var(tms, method)
+                        entry["names"][method].append(f"{key}_{method}_{tms.name}")
+            elif category == "tracer_module_independent":
+                vars_def[key] = {"dimensions": dims, "attrs": dict(metadata["attrs"]),
+                                 "datatype": metadata.get("datatype", "f8")}
+            else:
+                raise ValueError(f"unknown category {category}")
+            self._stats_vars[key] = entry
         step = f"define {self._solver_name} solver stats file vars"
         if not self._solver_state.step_logged(step, per_iteration=False):
             self._stats_file.def_vars(vars_def)
         self._solver_state.log_step(step, per_iteration=False)
 
+    def _stats_vals(self, key, vals):
+        entry = self._stats_vars[key]
+        if entry["category"] == "per_tracer_module":
+            return {name: vals[ind] for ind, name in enumerate(entry["names"])}
+        if entry["category"] == "model_state":
+            out = {}
+            for method in ("mean", "norm"):
+                reduced = vals.mean() if method == "mean" else vals.norm()
+                for ind, name in enumerate(entry["names"][method]):
+                    out[name] = reduced[ind]
+            return out
+        return {key: vals}
+
     def _put_solver_stats_vars_iteration_independent(self, **kwargs):
         vals_dict = {}
         for key, vals in kwargs.items():
-            meta = self._stats_vars[key]
-            if "iteration" in meta["dimensions"]:
+            if "iteration" in self._stats_vars[key]["dimensions"]:
                 raise ValueError("use _put_solver_stats_vars for vars with the iteration dimension")
             step = f"write {key} vals to stats file"
             if self._solver_state.step_logged(step, per_iteration=False):
                 continue
-            for ind, name in enumerate(meta["names"]):
-                vals_dict[name] = vals[ind]
+            vals_dict.update(self._stats_vals(key, vals))
             self._solver_state.log_step(step, per_iteration=False)
         self._stats_file.put_vars_iteration_invariant(vals_dict)
 
     def _put_solver_stats_vars(self, **kwargs):
         vals_dict = {}
         for key, vals in kwargs.items():
-            meta = self._stats_vars[key]
-            if "iteration" not in meta["dimensions"]:
+            if "iteration" not in self._stats_vars[key]["dimensions"]:
                 raise ValueError("use _put_solver_stats_vars_iteration_independent")
             step = f"write {key} vals to stats file"
             if self._solver_state.step_logged(step):
                 continue
-            for ind, name in enumerate(meta["names"]):
-                vals_dict[name] = vals[ind]
+            vals_dict.update(self._stats_vals(key, vals))
             self._solver_state.log_step(step)
         self._stats_file.put_vars(self.get_iteration(), vals_dict)

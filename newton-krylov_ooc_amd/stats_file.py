@@ -56,6 +56,10 @@ class StatsFile:
                 for key, val in attrs.items():
                     if val is not None:
                         setattr(var, key, val)
+                # a record variable added after records exist must be as long as the others
+                if metadata["dimensions"] and metadata["dimensions"][0] == "iteration":
+                    for rec in range(fptr.variables["iteration"].shape[0]):
+                        var[rec] = attrs["_FillValue"]
 
     def put_vars_iteration_invariant(self, name_vals_dict):
         if not name_vals_dict:
