@@ -56,16 +56,21 @@ void build_front(nk2d_ctx* c, const std::vector<double>& dzr, const std::vector<
             const double q = (h_s + h_n) - (a_s + a_n) - 2.0 * (a_up + a_dn);
             if (s > 0.0) pts.emplace_back(q, s);
         }
-    std::sort(pts.begin(), pts.end());
-    c->front_q.clear();
-    c->front_s.clear();
-    double smax = -1.0;
-    for (auto& p : pts)
-        if (p.second > smax) {
-            smax = p.second;
-            c->front_q.push_back(p.first);
-            c->front_s.push_back(p.second);
+    // tabulate rho(c) for c = c0 * 10^(k * dlog)
+    c->rho_c0 = 1.0e-10;
+    c->rho_dlog = 1.0 / 64.0;
+    const int ntab = 64 * 15;
+    c->rho_tab.assign(ntab, 0.0);
+    for (int k = 0; k < ntab; ++k) {
+        const double shift = c->rho_c0 * std::pow(10.0, k * c->rho_dlog);
+        double rho = 0.0;
+        for (const auto& p : pts) {
+            const double den = shift + p.first;
+            const double r = (den > 0.0) ? p.second / den : 1.0e30;
+            if (r > rho) rho = r;
         }
+        c->rho_tab[k] = rho;
+    }
 }
 
 }  // namespace
@@ -78,7 +83,12 @@ extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 
 extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     const std::string key(name ? name : "");
-    if (key == "device_ctl") { c->device_ctl = value != 0.0; return 0; }
+    if (key == "device_ctl") {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: device_ctl must be 0, 1 or 2");
+        c->device_ctl = (int)value;
+        return 0;
+    }
+    if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
     if (key == "sweep_wpb") {
         const int w = (int)value;
         if (w != 1 && w != 2 && w != 4) return nk2d_fail(c, "nk2d_set_option: sweep_wpb must be 1, 2 or 4");
@@ -213,8 +223,11 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->DCTL, (size_t)8));
     NK2D_TRY(dev_alloc(c, &c->ICTL, (size_t)8));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hCTL, 128));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hSNAP, 8 * 128));
+    for (int i = 0; i < 8; ++i) NK2D_CHECK(c, hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming));
     c->cur_guard = nullptr;
     c->device_ctl = 0;
+    c->jac_fresh = 0;
     c->hist_n = 0;
     c->hist_next = 0;
     c->hist_t = nullptr;
@@ -278,6 +291,8 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->precond = nullptr;
     c->st = nk2d_stats();
     c->prof_every = 0;
+    c->hSNAP = nullptr;
+    c->hCTL = nullptr;
     c->prof_used = 0;
     c->prof_ms_sum = 0.0;
     c->prof_overhead_ms = 0.0;
@@ -304,6 +319,10 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hCTL) (void)hipHostFree(c->hCTL);
+    if (c->hSNAP) {
+        (void)hipHostFree(c->hSNAP);
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->snap_ev[i]);
+    }
     if (c->DCTL) (void)hipFree(c->DCTL);
     if (c->ICTL) (void)hipFree(c->ICTL);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -68,8 +68,11 @@ struct nk2d_ctx {
     double* DCTL;
     int* ICTL;
     double* hCTL;           // pinned mirror: 8 doubles followed by 8 ints
+    double* hSNAP;          // pinned snapshots of the control block, one per Newton iteration
+    hipEvent_t snap_ev[8];
     const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
     int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
+    int jac_fresh;          // 1: re-evaluate the Jacobian at every step start (see nk2d_set_option)
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
@@ -82,8 +85,11 @@ struct nk2d_ctx {
     double* RCOEF;
     size_t rcoef_elems;
 
-    // host copies for the line-relaxation contraction bound
-    std::vector<double> front_q, front_s;
+    // line-relaxation contraction bound rho(c) = max_i s_i / (c + q_i), tabulated at create
+    // on a log grid of shifts c (rho is decreasing in c: the entry at the grid point below c
+    // is a valid, at most ~4 % pessimistic bound)
+    std::vector<double> rho_tab;
+    double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
 
@@ -473,6 +479,8 @@ int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total);
 int nk2d_r_reduce_newton(nk2d_ctx* c);
 int nk2d_r_reduce_err(nk2d_ctx* c);
 int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8);
+int nk2d_r_ctl_snapshot(nk2d_ctx* c, int slot);
+int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8);
 // nk2d_radau.hip
 int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first);
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,

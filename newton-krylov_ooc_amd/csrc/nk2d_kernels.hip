@@ -578,16 +578,14 @@ int nk2d_profile_collect(nk2d_ctx* c) {
     return 0;
 }
 
-// contraction bound of the line relaxation: rho <= max_i s_i / (c + q_i)
+// sweeps needed for the relative accuracy lin_tol from the tabulated contraction bound
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real) {
-    double rho = 0.0;
-    const size_t n = c->front_q.size();
-    for (size_t i = 0; i < n; ++i) {
-        const double den = c_real + c->front_q[i];
-        if (!(den > 0.0)) return 400;
-        const double r = c->front_s[i] / den;
-        if (r > rho) rho = r;
-    }
+    if (c->rho_tab.empty()) return 1;
+    double pos = std::log10(c_real / c->rho_c0) / c->rho_dlog;
+    int k = (int)std::floor(pos);
+    if (k < 0) return 400;
+    if (k >= (int)c->rho_tab.size()) k = (int)c->rho_tab.size() - 1;
+    const double rho = c->rho_tab[k];  // grid point below c_real: rho(c_real) <= rho_tab[k]
     if (rho <= 0.0) return 1;  // no horizontal coupling: the line solve is exact
     if (rho >= 0.999) return 400;
     int m = (int)std::ceil(std::log(c->d.lin_tol) / std::log(rho));
@@ -712,6 +710,23 @@ int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8) {
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     std::memcpy(dctl8, c->hCTL, 64);
     std::memcpy(ictl8, c->hCTL + 8, 32);
+    return 0;
+}
+
+// copy of the control block into pinned slot `slot`, in stream order, plus an event the host
+// can wait on while later (speculative) work is already queued
+int nk2d_r_ctl_snapshot(nk2d_ctx* c, int slot) {
+    double* dst = c->hSNAP + (size_t)slot * 16;
+    NK2D_CHECK(c, hipMemcpyAsync(dst, c->DCTL, 64, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(dst + 8, c->ICTL, 32, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipEventRecord(c->snap_ev[slot], c->stream));
+    return 0;
+}
+int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8) {
+    NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[slot]));
+    const double* src = c->hSNAP + (size_t)slot * 16;
+    std::memcpy(dctl8, src, 64);
+    std::memcpy(ictl8, src + 8, 32);
     return 0;
 }
 

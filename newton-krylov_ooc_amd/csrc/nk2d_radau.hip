@@ -42,7 +42,7 @@ struct Ctl {
     double dense_t_old, dense_h;
     double newton_tol, max_step;
     int m_real, m_cplx;  // sweeps per solve for the current h_lu
-    bool device_ctl;     // Newton decisions on the device (no per-iteration read-back)
+    int device_ctl;      // 0 host decisions, 1 device decisions + one read-back per attempt, 2 pipelined
     double n_total;      // number of unknowns (tc*nz*ny)
 };
 
@@ -212,6 +212,54 @@ int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* ra
     return 0;
 }
 
+// Pipelined variant: the decisions stay on the device, but the host follows them one Newton
+// iteration behind -- iteration k+1 is queued (guarded by the `done` flag) BEFORE the host waits
+// for the verdict on iteration k, so the wake-up latency of the read-back is hidden behind
+// GPU work and at most one iteration's worth of launches returns at entry.
+int attempt_pipelined(Ctl& s, double t, double h, bool* converged, int* n_iter, double* rate, bool* have_rate) {
+    nk2d_ctx* c = s.c;
+    const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+    c->cur_guard = nullptr;
+    NK2D_TRY(predict(s, t, h));
+    NK2D_TRY(nk2d_r_ctl_reset(c, s.newton_tol, s.n_total));
+    c->cur_guard = c->ICTL + 3;  // done
+    double d[8];
+    int ic[8] = {0};
+    double spec_bytes = 0.0;
+    int64_t spec_launches = 0;
+    auto queue_iteration = [&](int k) -> int {
+        const double b0 = c->sweep_bytes;
+        const int64_t l0 = c->sweep_launches;
+        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
+        NK2D_TRY(nk2d_r_reduce_newton(c));
+        NK2D_TRY(nk2d_r_ctl_snapshot(c, k));
+        spec_bytes = c->sweep_bytes - b0;
+        spec_launches = c->sweep_launches - l0;
+        return 0;
+    };
+    NK2D_TRY(queue_iteration(0));
+    for (int k = 0; k < NEWTON_MAXITER; ++k) {
+        const bool queued_next = k + 1 < NEWTON_MAXITER;
+        if (queued_next) NK2D_TRY(queue_iteration(k + 1));
+        NK2D_TRY(nk2d_r_ctl_wait(c, k, d, ic));
+        if (ic[3] != 0) {
+            if (queued_next) {  // the iteration queued ahead returns at entry: not executed work
+                c->sweep_bytes -= spec_bytes;
+                c->st.nsolve -= 2;
+            }
+            break;
+        }
+    }
+    c->cur_guard = nullptr;
+    *converged = ic[4] != 0;
+    *n_iter = ic[6];
+    *rate = d[1];
+    *have_rate = ic[2] != 0;
+    c->st.nfev += 3 * (int64_t)ic[6];
+    c->st.nnewton += ic[6];
+    return 0;
+}
+
 double predict_factor(double h_abs, bool has_h_old, double h_abs_old, double err, bool has_err_old, double err_old) {
     double mult = 1.0;
     if (has_err_old && has_h_old && err != 0.0) mult = h_abs / h_abs_old * std::pow(err_old / err, 0.25);
@@ -269,6 +317,14 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         if (s.h_abs > s.max_step) { h_abs = s.max_step; has_h_old = has_err_old = false; }
         else if (s.h_abs < min_step) { h_abs = min_step; has_h_old = has_err_old = false; }
         else { h_abs = s.h_abs; h_abs_old = s.h_abs_old; err_old = s.err_old; has_h_old = s.has_old_h; has_err_old = s.has_old_err; }
+        if (c->jac_fresh && !s.current_jac) {
+            // evaluating J costs two small launches here (SciPy pays a Python double loop and two
+            // SuperLU factorisations, hence its reuse heuristics): never start a step on a stale J
+            NK2D_TRY(refresh_jac(s, t, true));
+            c->st.njev++;
+            s.current_jac = true;
+            s.have_lu = false;
+        }
         bool rejected = false, accepted = false;
         double h = 0, t_new = 0, err = 0, safety = 0, rate = 0;
         bool have_rate = false;
@@ -286,8 +342,10 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             int buf = 0;
             while (!converged) {
                 if (!s.have_lu) NK2D_TRY(set_lu(s, h));
-                if (s.device_ctl) {
+                if (s.device_ctl == 1) {
                     NK2D_TRY(attempt(s, t, h, &converged, &n_iter, &rate, &have_rate, &err_sum, &buf));
+                } else if (s.device_ctl == 2) {
+                    NK2D_TRY(attempt_pipelined(s, t, h, &converged, &n_iter, &rate, &have_rate));
                 } else {
                     NK2D_TRY(predict(s, t, h));
                     NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate));
@@ -308,7 +366,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // error estimate (radau.py:477-487); with device control its first pass was queued
             // together with the attempt
             double sum = err_sum;
-            if (!s.device_ctl) {
+            if (s.device_ctl != 1) {
                 NK2D_TRY(nk2d_r_err_rhs(c, h));
                 NK2D_TRY(solve_systems(s, true, false, &buf));
                 NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
@@ -411,7 +469,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.have_lu = false; s.have_dense = false;
     s.h_lu = 0; s.dense_t_old = 0; s.dense_h = 0;
     s.m_real = s.m_cplx = 1;
-    s.device_ctl = c->device_ctl != 0;
+    s.device_ctl = c->device_ctl;
     NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
     if (s.t1 > s.t) {
         // f = fun(t0, y0);  J = jac(t0, y0)
