@@ -256,80 +256,9 @@ __device__ __forceinline__ void store_col(double* __restrict__ base, size_t col,
 // of E rows (two sweeps), the 64 block-end unknowns form a tridiagonal system that is
 // solved by parallel cyclic reduction with wave shuffles, then the interior unknowns
 // follow by substitution.  No pivoting: the matrices here are strictly diagonally
-// dominant (shifted M-matrices).  On exit r holds x.
-template <int E, typename T>
-__device__ __forceinline__ void tridiag_wave(const double (&a)[E], const double (&c)[E], const T (&d)[E],
-                                             T (&r)[E], int lane) {
-    T inv[E], al[E], be[E];
-    T dlast = d[0];
-    inv[0] = t_recip(d[0]);
-    al[0] = t_from_real(a[0], T());
-#pragma unroll
-    for (int i = 1; i < E; ++i) {
-        T m = t_mulr(inv[i - 1], a[i]);
-        T dd = t_nfmar(d[i], m, c[i - 1]);
-        dlast = dd;
-        inv[i] = t_recip(dd);
-        al[i] = t_neg(t_mul(m, al[i - 1]));
-        r[i] = t_nfma(r[i], m, r[i - 1]);
-    }
-    T A, B, C, R;
-    if constexpr (E >= 2) {
-        be[E - 1] = t_zero(T());
-        be[E - 2] = t_from_real(c[E - 2], T());
-#pragma unroll
-        for (int i = E - 3; i >= 0; --i) {
-            T m = t_mulr(inv[i + 1], c[i]);
-            al[i] = t_nfma(al[i], m, al[i + 1]);
-            be[i] = t_neg(t_mul(m, be[i + 1]));
-            r[i] = t_nfma(r[i], m, r[i + 1]);
-        }
-        T n_al = shfl_down_t(al[0], 1), n_inv = shfl_down_t(inv[0], 1);
-        T n_be = shfl_down_t(be[0], 1), n_r = shfl_down_t(r[0], 1);
-        T g = t_mulr(n_inv, c[E - 1]);  // zero on the last lane and on padding rows
-        A = al[E - 1];
-        B = t_nfma(dlast, g, n_al);
-        C = t_neg(t_mul(g, n_be));
-        R = t_nfma(r[E - 1], g, n_r);
-    } else {
-        A = t_from_real(a[0], T());
-        B = d[0];
-        C = t_from_real(c[0], T());
-        R = r[0];
-    }
-    // parallel cyclic reduction over the 64 block-end unknowns
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        T iB = t_recip(B);
-        T Am = shfl_up_t(A, s), iBm = shfl_up_t(iB, s), Cm = shfl_up_t(C, s), Rm = shfl_up_t(R, s);
-        T Ap = shfl_down_t(A, s), iBp = shfl_down_t(iB, s), Cp = shfl_down_t(C, s), Rp = shfl_down_t(R, s);
-        bool hm = lane >= s, hp = lane + s < 64;
-        T k1 = hm ? t_mul(A, iBm) : t_zero(T());
-        T k2 = hp ? t_mul(C, iBp) : t_zero(T());
-        if (!hm) { Am = t_zero(T()); Cm = t_zero(T()); Rm = t_zero(T()); }
-        if (!hp) { Ap = t_zero(T()); Cp = t_zero(T()); Rp = t_zero(T()); }
-        T nB = t_nfma(t_nfma(B, Cm, k1), Ap, k2);
-        T nR = t_nfma(t_nfma(R, Rm, k1), Rp, k2);
-        A = t_neg(t_mul(Am, k1));
-        C = t_neg(t_mul(Cp, k2));
-        B = nB;
-        R = nR;
-    }
-    T xl = t_mul(R, t_recip(B));
-    T xp = shfl_up_t(xl, 1);
-    if (lane == 0) xp = t_zero(T());
-    if constexpr (E >= 2) {
-#pragma unroll
-        for (int i = 0; i < E - 1; ++i) {
-            T v = t_nfma(t_nfma(r[i], al[i], xp), be[i], xl);
-            r[i] = t_mul(inv[i], v);
-        }
-    }
-    r[E - 1] = xl;
-}
-
+// dominant (shifted M-matrices).
 // ---------------------------------------------------------------------------------
-// Cached form of the same solve.  The matrix-only part of `tridiag_wave` (pivot
+// The solve is split in two.  The matrix-only part (pivot
 // reciprocals, the coupling g to the next lane's first row, the parallel-cyclic-reduction
 // multipliers of the 64 block-end unknowns and the final pivot) depends only on
 // (shift, Jacobian planes), i.e. on SciPy's "LU" event, while a relaxation solve runs
@@ -464,8 +393,6 @@ int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
 int nk2d_profile_collect(nk2d_ctx* c);
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
-int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci);
-int nk2d_r_newton_update(nk2d_ctx* c, int buf);
 int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
                         double mci, int src);
 int nk2d_r_err_rhs(nk2d_ctx* c, double h);

@@ -771,9 +771,9 @@ __global__ void k_predict(int ncol, const double* __restrict__ y, const double* 
     }
 }
 
-// stage tendencies F_i = fun(t + c_i h, y + Z_i) and transformed residuals
-// f_real = F^T TI_REAL - M_real W0, f_complex = F^T TI_COMPLEX - M_complex (W1 + i W2)
-// (radau.py:104-111)
+// arguments of the stage part of k_newton_fused: stage tendencies F_i = fun(t + c_i h, y + Z_i)
+// and transformed residuals f_real = F^T TI_REAL - M_real W0,
+// f_complex = F^T TI_COMPLEX - M_complex (W1 + i W2)  (radau.py:104-111)
 struct StageArgs {
     const double *y, *z, *w;
     const double* kv[3];
@@ -781,92 +781,6 @@ struct StageArgs {
     size_t nv;
     double mreal, mcr, mci;
 };
-
-template <int E>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_stage(DevP P, StageArgs A) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(P.ncol)
-    const int tr = task / P.ny, j = task - tr * P.ny;
-    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
-    ColCoef<E> cf;
-    load_coef<E>(P, j, lane, cf);
-    double y0[E], ys[E], yn[E];
-    load_col<E>(A.y, task, lane, y0);
-    load_col<E>(A.y, cs_col, lane, ys);
-    load_col<E>(A.y, cn_col, lane, yn);
-    double fr[E], fcr[E], fci[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double c[E], cs[E], cn[E], kv[E], f[E];
-        load_col<E>(A.z + i * A.nv, task, lane, c);
-        load_col<E>(A.z + i * A.nv, cs_col, lane, cs);
-        load_col<E>(A.z + i * A.nv, cn_col, lane, cn);
-        load_col<E>(A.kv[i], j, lane, kv);
-#pragma unroll
-        for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
-        tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            fr[e] = fr[e] + f[e] * cTI[0][i];
-            fcr[e] = fcr[e] + f[e] * cTI[1][i];
-            fci[e] = fci[e] + f[e] * cTI[2][i];
-        }
-    }
-    double w0[E], w1[E], w2[E];
-    load_col<E>(A.w, task, lane, w0);
-    load_col<E>(A.w + A.nv, task, lane, w1);
-    load_col<E>(A.w + 2 * A.nv, task, lane, w2);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        fr[e] = fr[e] - A.mreal * w0[e];
-        fcr[e] = fcr[e] - (A.mcr * w1[e] - A.mci * w2[e]);
-        fci[e] = fci[e] - (A.mcr * w2[e] + A.mci * w1[e]);
-    }
-    store_col<E>(A.br, task, lane, fr);
-    store_col<E>(A.bcr, task, lane, fcr);
-    store_col<E>(A.bci, task, lane, fci);
-}
-
-// dW -> sum((dW/scale)^2) partial, W += dW, Z = T W  (radau.py:113-129)
-template <int E>
-__global__ void k_newton_update(DevP P, const double* __restrict__ y, const double* __restrict__ xr,
-                                const double* __restrict__ xcr, const double* __restrict__ xci, double* __restrict__ w,
-                                double* __restrict__ z, size_t nv, double* __restrict__ part) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(P.ncol)
-    double yy[E], d0[E], d1[E], d2[E], w0[E], w1[E], w2[E];
-    load_col<E>(y, task, lane, yy);
-    load_col<E>(xr, task, lane, d0);
-    load_col<E>(xcr, task, lane, d1);
-    load_col<E>(xci, task, lane, d2);
-    load_col<E>(w, task, lane, w0);
-    load_col<E>(w + nv, task, lane, w1);
-    load_col<E>(w + 2 * nv, task, lane, w2);
-    double acc = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const double sc = P.atol + fabs(yy[e]) * P.rtol;
-        const double a = d0[e] / sc, b = d1[e] / sc, c = d2[e] / sc;
-        acc += (a * a + b * b) + c * c;
-        w0[e] = w0[e] + d0[e];
-        w1[e] = w1[e] + d1[e];
-        w2[e] = w2[e] + d2[e];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) part[task] = acc;
-    store_col<E>(w, task, lane, w0);
-    store_col<E>(w + nv, task, lane, w1);
-    store_col<E>(w + 2 * nv, task, lane, w2);
-    double zz[E];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
-        store_col<E>(z + r * nv, task, lane, zz);
-    }
-}
 
 // ---------------------------------------------------------------------------------
 // Fused simplified-Newton iteration.  One wave owns one (tracer, ypos) column and runs,
@@ -1211,18 +1125,6 @@ int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
     c->st.nlaunch++;
     return 0;
 }
-int nk2d_r_stage(nk2d_ctx* c, double mreal, double mcr, double mci) {
-    StageArgs A;
-    A.y = c->Y; A.z = c->Z; A.w = c->W;
-    A.kv[0] = c->KV[0]; A.kv[1] = c->KV[1]; A.kv[2] = c->KV[2];
-    A.br = c->BR; A.bcr = c->BCR; A.bci = c->BCI;
-    A.nv = c->nv; A.mreal = mreal; A.mcr = mcr; A.mci = mci;
-    DevP P = make_devp(c);
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_stage<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
-    NK2D_CHECK(c, hipGetLastError());
-    c->st.nlaunch++;
-    return 0;
-}
 // one launch of the fused Newton iteration; src = ping-pong buffer with the previous
 // sweep's iterate, the new iterate goes to 1-src unless do_update consumes it
 int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
@@ -1275,14 +1177,6 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     return 0;
 }
 
-int nk2d_r_newton_update(nk2d_ctx* c, int buf) {
-    DevP P = make_devp(c);
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_newton_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
-                                               P, c->Y, c->XR[buf], c->XCR[buf], c->XCI[buf], c->W, c->Z, c->nv, c->PART));
-    NK2D_CHECK(c, hipGetLastError());
-    c->st.nlaunch++;
-    return 0;
-}
 int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                                c->ncol, c->F, c->Z, c->nv, h, c->BR, c->cur_guard));

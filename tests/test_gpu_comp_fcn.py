@@ -59,3 +59,32 @@ def test_comp_fcn_free(golden_dir, tag, nz, ny, vv, kh):
     # the recorded schedule replays to the same answer (smooth map)
     fx2, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=sched)
     assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-12
+
+
+def test_controller_variants_take_identical_decisions():
+    """host-side Newton decisions (default), device-side decisions with one read-back per step
+    attempt, and the pipelined device-side controller must follow the same path bit for bit"""
+    import numpy as np
+
+    eng = make_engine(26, 26)
+    rng = np.random.default_rng(11)
+    model, _ = oracle_iage(26, 26)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2) + 0.01 * rng.standard_normal((2, 26, 26)))
+    results = []
+    for mode in (0, 1, 2):
+        eng.set_option("device_ctl", mode)
+        fx, stats, sched = eng.comp_fcn(x, record=True)
+        results.append((eng.download(fx), stats, sched))
+    eng.set_option("device_ctl", 0)
+    for res, stats, sched in results[1:]:
+        assert np.array_equal(res, results[0][0])
+        assert np.array_equal(sched, results[0][2])
+        for key in ("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton"):
+            assert stats[key] == results[0][1][key], key
+    # jac_fresh leaves SciPy's decision sequence but solves the same ODE to the same tolerance
+    eng.set_option("jac_fresh", 1)
+    fx, stats, _ = eng.comp_fcn(x)
+    eng.set_option("jac_fresh", 0)
+    assert np.allclose(eng.download(fx), results[0][0], rtol=1e-3, atol=1e-6)
+    assert stats["njev"] == stats["nsteps"] + 1 or stats["njev"] >= stats["nsteps"]
