@@ -786,10 +786,10 @@ struct StageArgs {
 // Fused simplified-Newton iteration.  One wave owns one (tracer, ypos) column and runs,
 // depending on the flags, the pieces of a Newton iteration that need no data from other
 // columns between them:
-//   do_stage  : stage tendencies + transformed residuals (k_stage) -> right-hand sides
+//   do_stage  : stage tendencies + transformed residuals (radau.py:104-111) -> right-hand sides
 //   (always)  : one line-relaxation sweep of the real AND the complex system of the column
 //               (first: no lateral terms)
-//   do_update : W += dW, Z = T W, ||dW/scale||^2 partial (k_newton_update)
+//   do_update : W += dW, Z = T W, sum((dW/scale)^2) partial (radau.py:113-129)
 // With m sweeps per solve a Newton iteration is m launches (stage fused into the first,
 // update into the last) instead of m + 2.
 // ---------------------------------------------------------------------------------
