@@ -24,6 +24,7 @@
 // 2 ny dense matrix-vector products streamed from HBM at full chip width.
 #include "nk2d_common.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -33,6 +34,8 @@ struct Precond {
     double* PJ;    // Jacobian planes, natural layout [nt][5][nz][ny]  (L, S, C, N, U)
     double* SINV;  // [tc][nb][m][m]
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
+    double* PINV;  // inverted pivot blocks [tc][NB][NB]
+    double* ROWS;  // scaled pivot rows    [tc][NB][m]
     double* YV;    // forward-sweep vectors [tc][nb][m]
     double* XV;    // solution vectors      [tc][nb][m]
     double dt;
@@ -83,23 +86,112 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
     out[((size_t)tr * P.m + r) * P.m + c] = val;
 }
 
-// one in-place-style Gauss-Jordan pivot step, src -> dst (ping-pong avoids races)
-__global__ void k_pc_gj(int m, int p, const double* __restrict__ src, double* __restrict__ dst) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    const size_t base = (size_t)blockIdx.z * m * m;
-    if (c >= m) return;
-    const double pivinv = 1.0 / src[base + (size_t)p * m + p];
-    const double prow = ((c == p) ? 1.0 : src[base + (size_t)p * m + c]) * pivinv;
-    double val;
-    if (i == p) {
-        val = prow;
-    } else {
-        const double f = src[base + (size_t)i * m + p];
-        const double a = (c == p) ? 0.0 : src[base + (size_t)i * m + c];
-        val = __builtin_fma(-f, prow, a);
+// ---------------------------------------------------------------------------------
+// Blocked Gauss-Jordan inversion without pivoting (the Schur complements are M-matrices),
+// NB pivots per step, three launches per step, src -> dst ping-pong:
+//   k_pc_gj_pivot : Pinv = inverse of the NB x NB pivot block (one workgroup, in LDS)
+//   k_pc_gj_rows  : R = Pinv * src[pb, :]   with the pivot columns of R replaced by Pinv
+//   k_pc_gj_update: dst[i, :] = (src[i, :] with pivot columns zeroed) - src[i, pb] * R   (i not in pb)
+//                   dst[pb, :] = R
+// ---------------------------------------------------------------------------------
+#define PC_NB 32
+
+__global__ void k_pc_gj_pivot(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ pinv) {
+    __shared__ double a[PC_NB][PC_NB + 1];
+    const size_t base = (size_t)blockIdx.x * m * m;
+    const int r = threadIdx.y, c = threadIdx.x;
+    const bool in = r < nb && c < nb;
+    a[r][c] = in ? src[base + (size_t)(p0 + r) * m + (p0 + c)] : ((r == c) ? 1.0 : 0.0);
+    __syncthreads();
+    for (int p = 0; p < nb; ++p) {
+        const double piv = 1.0 / a[p][p];
+        __syncthreads();
+        const double prow = ((c == p) ? 1.0 : a[p][c]) * piv;
+        const double f = a[r][p];
+        const double old = (c == p) ? 0.0 : a[r][c];
+        __syncthreads();
+        a[r][c] = (r == p) ? prow : __builtin_fma(-f, prow, old);
+        __syncthreads();
     }
-    dst[base + (size_t)i * m + c] = val;
+    if (in) pinv[(size_t)blockIdx.x * PC_NB * PC_NB + r * PC_NB + c] = a[r][c];
+}
+
+// R[p][c] for p < nb, c < m
+__global__ void k_pc_gj_rows(int m, int p0, int nb, const double* __restrict__ src, const double* __restrict__ pinv,
+                             double* __restrict__ rows) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    const int tr = blockIdx.z;
+    if (c >= m) return;
+    const double* pi = pinv + (size_t)tr * PC_NB * PC_NB + p * PC_NB;
+    double val;
+    if (c >= p0 && c < p0 + nb) {
+        val = pi[c - p0];
+    } else {
+        const double* col = src + (size_t)tr * m * m + (size_t)p0 * m + c;
+        double acc = 0.0;
+        for (int q = 0; q < nb; ++q) acc = __builtin_fma(pi[q], col[(size_t)q * m], acc);
+        val = acc;
+    }
+    rows[((size_t)tr * PC_NB + p) * m + c] = val;
+}
+
+// 64 x 64 output tile per workgroup, 4 x 4 outputs per thread, operands staged through LDS
+__global__ void __launch_bounds__(256) k_pc_gj_update(int m, int p0, int nb, const double* __restrict__ src,
+                                                      const double* __restrict__ rows, double* __restrict__ dst) {
+    __shared__ double sf[64][PC_NB + 1];   // src[i, pb]
+    __shared__ double sr[PC_NB][64 + 1];   // R[:, c]
+    const int tr = blockIdx.z;
+    const size_t base = (size_t)tr * m * m;
+    const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * PC_NB; idx += 256) {
+        const int ii = idx / PC_NB, q = idx - ii * PC_NB;
+        const int i = i0 + ii;
+        sf[ii][q] = (i < m && q < nb) ? src[base + (size_t)i * m + p0 + q] : 0.0;
+    }
+    for (int idx = tid; idx < PC_NB * 64; idx += 256) {
+        const int q = idx / 64, cc = idx - q * 64;
+        const int c = c0 + cc;
+        sr[q][cc] = (c < m && q < nb) ? rows[((size_t)tr * PC_NB + q) * m + c] : 0.0;
+    }
+    __syncthreads();
+    const int ty = tid / 16, tx = tid - ty * 16;   // thread owns rows ty*4.., columns tx + 16*k
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int q = 0; q < nb; ++q) {
+        double f[4], r[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) f[a] = sf[ty * 4 + a][q];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r[b] = sr[q][tx + 16 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(f[a], r[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + ty * 4 + a;
+        if (i >= m) continue;
+        const bool pivot_row = i >= p0 && i < p0 + nb;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = c0 + tx + 16 * b;
+            if (c >= m) continue;
+            double val;
+            if (pivot_row) {
+                val = sr[i - p0][tx + 16 * b];
+            } else {
+                const bool pivot_col = c >= p0 && c < p0 + nb;
+                val = (pivot_col ? 0.0 : src[base + (size_t)i * m + c]) - acc[a][b];
+            }
+            dst[base + (size_t)i * m + c] = val;
+        }
+    }
 }
 
 // dense mat-vec with the block-Thomas epilogues; one wave per row
@@ -188,7 +280,7 @@ PcDev make_pcdev(const nk2d_ctx* c, const Precond* pc) {
 void nk2d_precond_free(nk2d_ctx* c) {
     Precond* pc = (Precond*)c->precond;
     if (!pc) return;
-    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV};
+    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->PINV, pc->ROWS};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     delete pc;
@@ -206,11 +298,13 @@ extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
     pc->m = pc->nt * c->nz;
     pc->nb = c->ny;
     pc->dt = (c->d.t1 - c->d.t0) / pc->nt;
-    pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = nullptr;
+    pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->PINV = pc->ROWS = nullptr;
     const size_t P = (size_t)c->nz * c->ny, mm = (size_t)pc->m * pc->m;
     NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * 5 * P));
     NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * c->tc * pc->nb * mm));
     NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * c->tc * mm));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * c->tc * PC_NB * PC_NB));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * c->tc * PC_NB * pc->m));
     NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * c->tc * pc->nb * pc->m));
     NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * c->tc * pc->nb * pc->m));
     // Jacobian planes at the three mid-interval times (iage.py:85-89)
@@ -231,9 +325,15 @@ extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
         // SINV is [tc][nb][m][m]: the kernel adds the tracer stride itself
         hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, c->stream, D, j, prev, pc->BUF);
         int src = 0;
-        for (int p = 0; p < m; ++p) {
-            hipLaunchKernelGGL(k_pc_gj, grd, blk, 0, c->stream, m, p, pc->BUF + (size_t)src * c->tc * mm,
-                               pc->BUF + (size_t)(1 - src) * c->tc * mm);
+        for (int p0 = 0; p0 < m; p0 += PC_NB) {
+            const int nbk = std::min(PC_NB, m - p0);
+            const double* from = pc->BUF + (size_t)src * c->tc * mm;
+            double* to = pc->BUF + (size_t)(1 - src) * c->tc * mm;
+            hipLaunchKernelGGL(k_pc_gj_pivot, dim3(c->tc), dim3(PC_NB, PC_NB), 0, c->stream, m, p0, nbk, from, pc->PINV);
+            hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, c->tc), dim3(256), 0, c->stream, m, p0, nbk, from,
+                               pc->PINV, pc->ROWS);
+            hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, c->tc), dim3(256), 0, c->stream, m, p0,
+                               nbk, from, pc->ROWS, to);
             src = 1 - src;
         }
         for (int tr = 0; tr < c->tc; ++tr)
