@@ -6,11 +6,16 @@ method is a ctypes call into `csrc/libnk2d.so`.
 """
 
 import ctypes
+import os
 
 import numpy as np
 
 from . import _lib
 from .grid import BLDEPTH_MIN, YEAR, bldepth_time_knots
+
+
+# relative accuracy of the inner line-relaxation solves (inexact simplified Newton)
+DEFAULT_LIN_TOL = 1.0e-5
 
 
 class Nk2dError(RuntimeError):
@@ -51,7 +56,7 @@ class ModuleEngine:
     def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, surf_target=(),
                  device_id=0,
                  time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
-                 lin_tol=1.0e-7):
+                 lin_tol=None):
         self._lib = _lib.load()
         self._ctx = None
         self.grid = grid
@@ -84,6 +89,8 @@ class ModuleEngine:
         desc.t0, desc.t1 = float(time_range[0]), float(time_range[1])
         desc.rtol, desc.atol = float(rtol), float(atol)
         desc.max_step_frac = float(max_step_frac)
+        if lin_tol is None:
+            lin_tol = float(os.environ.get("NK2D_LIN_TOL", DEFAULT_LIN_TOL))
         desc.lin_tol = float(lin_tol)
         ctx = ctypes.c_void_p()
         rc = self._lib.nk2d_create(ctypes.byref(desc), ctypes.byref(ctx))
