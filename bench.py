@@ -89,11 +89,15 @@ def main():
     from nk_ooc_amd.model_state import ModelState
     from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
 
-    rank, local_rank, world = nkdist.init_process_group_from_env("nccl")
+    # NK2D_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
+    # share the visible GPUs and the (4-byte) collectives run on CPU tensors; never used by the driver
+    backend = os.environ.get("NK2D_BENCH_BACKEND", "nccl")
+    rank, local_rank, world = nkdist.init_process_group_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     n = args.grid
     workdir = tempfile.mkdtemp(prefix=f"nk2d_bench_r{rank}_")
     try:
