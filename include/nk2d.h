@@ -82,6 +82,14 @@ typedef struct nk2d_desc {
     double rtol, atol;         /* Radau tolerances (1e-6, 1e-6) */
     double max_step_frac;      /* max_step = frac*(t1-t0) (0.01) */
     double lin_tol;            /* target relative accuracy of the inner line-relaxation solves */
+    /* module kind: 0 = linear sources above (iage, forced); 1 = phosphorus (po4, dop, pop;
+       nk_ooc/py_driver_2d/phosphorus.py:17-172), then tc = 3 and
+       phos_params = {po4_halfsat, max_uptake_rate, sigma, dop_remin_rate, pop_remin_rate,
+       pop_sink_vel} (phosphorus.py:42-58), light_lim [nz][ny] (phosphorus.py:26-29) */
+    int32_t module_kind;
+    int32_t reserved0;
+    double phos_params[6];
+    const double* light_lim;
 } nk2d_desc;
 
 typedef struct nk2d_stats {
@@ -111,6 +119,12 @@ int nk2d_vec_zero(nk2d_ctx* ctx, nk2d_vec v);
 /* deterministic kernels */
 int nk2d_tend(nk2d_ctx* ctx, double t, nk2d_vec y, nk2d_vec f);
 int nk2d_vmix_coeff(nk2d_ctx* ctx, double t, double* host_out /* [nz-1][ny] */);
+/* state the stand-alone Jacobian entry points below linearise about (only state dependent
+   modules, i.e. phosphorus, use it); nk2d_comp_fcn linearises about its own running state */
+int nk2d_set_lin_state(nk2d_ctx* ctx, nk2d_vec y);
+/* out = J(t, lin_state) v : tracer_module.comp_jacobian(...) @ v,
+   py_driver_2d/tracer_module_state.py:262-270, phosphorus.py:105-172 */
+int nk2d_jacobian_apply(nk2d_ctx* ctx, double t, nk2d_vec v, nk2d_vec out);
 /* diags: [5][tc][nz][ny] in the order up(k-1), south(j-1), centre, north(j+1), down(k+1) */
 int nk2d_jacobian_diags(nk2d_ctx* ctx, double t, double* host_out);
 /* solve ((mu/h) I - J(t_jac)) x = b by line relaxation; complex when mu_im != 0.

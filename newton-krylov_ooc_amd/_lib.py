@@ -49,6 +49,10 @@ class Desc(ctypes.Structure):
         ("atol", ctypes.c_double),
         ("max_step_frac", ctypes.c_double),
         ("lin_tol", ctypes.c_double),
+        ("module_kind", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+        ("phos_params", ctypes.c_double * 6),
+        ("light_lim", c_double_p),
     ]
 
 
@@ -92,6 +96,8 @@ SIGNATURES = {
     "nk2d_tend": (_ci, [_vp, _d, _vp, _vp]),
     "nk2d_vmix_coeff": (_ci, [_vp, _d, c_double_p]),
     "nk2d_jacobian_diags": (_ci, [_vp, _d, c_double_p]),
+    "nk2d_set_lin_state": (_ci, [_vp, _vp]),
+    "nk2d_jacobian_apply": (_ci, [_vp, _d, _vp, _vp]),
     "nk2d_shifted_solve": (_ci, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, c_int32_p]),
     "nk2d_comp_fcn": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), c_double_p, _i64,
                             c_double_p, _i64, c_int64_p]),

@@ -54,7 +54,19 @@ void build_front(nk2d_ctx* c, const std::vector<double>& dzr, const std::vector<
             const double h_n = (j < ny - 1) ? kh[(size_t)k * (ny - 1) + j] * dyr[j] : 0.0;
             const double s = std::fabs(a_s + h_s) + std::fabs(a_n + h_n);
             const double q = (h_s + h_n) - (a_s + a_n) - 2.0 * (a_up + a_dn);
-            if (s > 0.0) pts.emplace_back(q, s);
+            if (c->kind == 1) {
+                // rows of po4 / dop / pop: the coupling to the other tracers of the cell is relaxed with
+                // the lateral terms (s), the module's diagonal and sinking terms change the margin (q);
+                // d uptake / d po4 <= max_rate * light / halfsat for po4 >= 0
+                const double* ph = c->d.phos_params;
+                const double upr_max = ph[1] * c->d.light_lim[(size_t)k * ny + j] / ph[0];
+                const double sink_out = (k < nz - 1) ? ph[5] * dzr[k] : 0.0, sink_in = (k > 0) ? ph[5] * dzr[k] : 0.0;
+                pts.emplace_back(q, s + ph[3] + ph[4]);
+                pts.emplace_back(q + ph[3], s + ph[2] * upr_max);
+                pts.emplace_back(q + ph[4] + sink_out - sink_in, s + (1.0 - ph[2]) * upr_max);
+            } else if (s > 0.0) {
+                pts.emplace_back(q, s);
+            }
         }
     // tabulate rho(c) for c = c0 * 10^(k * dlog)
     c->rho_c0 = 1.0e-10;
@@ -164,6 +176,10 @@ extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, 
 static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->d = *desc;
     c->nz = desc->nz; c->ny = desc->ny; c->tc = desc->tc;
+    c->kind = desc->module_kind;
+    if (c->kind != 0 && c->kind != 1) return nk2d_fail(c, "nk2d_create: unknown module_kind");
+    if (c->kind == 1 && (c->tc != 3 || desc->light_lim == nullptr))
+        return nk2d_fail(c, "nk2d_create: the phosphorus module has 3 tracers and needs light_lim");
     if (c->nz < 2 || c->ny < 1 || c->tc < 1 || c->tc > NK2D_MAX_TRACERS) return nk2d_fail(c, "nk2d_create: bad grid / tracer count");
     c->E = (c->nz + 63) / 64;
     if (c->E > NK2D_MAX_E) return nk2d_fail(c, "nk2d_create: nz > 512 levels not supported by this build");
@@ -195,6 +211,10 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->JS, c->np));
     NK2D_TRY(dev_alloc(c, &c->JN, c->np));
     NK2D_TRY(dev_alloc(c, &c->JC, c->np));
+    NK2D_TRY(dev_alloc(c, &c->LIGHT, c->np));
+    NK2D_TRY(dev_alloc(c, &c->UPR, c->np));
+    c->YLIN = nullptr;
+    c->ylin_set = 0;
     for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->KV[i], c->np));
     NK2D_TRY(dev_alloc(c, &c->Y, c->nv));
     NK2D_TRY(dev_alloc(c, &c->YOLD, c->nv));
@@ -269,9 +289,11 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(upload_plane(c, dzmr.data(), nz, 1, c->DMR));
     NK2D_CHECK(c, hipMemcpy(c->DYR, dyr.data(), sizeof(double) * ny, hipMemcpyHostToDevice));
     NK2D_CHECK(c, hipMemcpy(c->BLDMAX, desc->bldepth_max, sizeof(double) * ny, hipMemcpyHostToDevice));
+    if (c->kind == 1) NK2D_TRY(upload_plane(c, desc->light_lim, nz, ny, c->LIGHT));
     build_front(c, dzr, dyr);
     // the descriptor's pointers are not kept
     c->d.depth_edges = c->d.ypos_edges = c->d.vvel = c->d.wvel = c->d.hmix_coeff = c->d.bldepth_max = nullptr;
+    c->d.light_lim = nullptr;
     // default region: everything in region 1 with unit weights until nk2d_set_region is called
     {
         std::vector<int32_t> m((size_t)nz * ny, 1);
@@ -312,7 +334,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF,
-                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI};
+                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -445,11 +467,32 @@ extern "C" int nk2d_vmix_coeff(nk2d_ctx* c, double t, double* host_out) {
     return 0;
 }
 
+// linearisation state of the stand-alone Jacobian entry points (state dependent modules only)
+static const double* lin_state(nk2d_ctx* c) { return (c->kind == 1 && c->ylin_set) ? c->YLIN : nullptr; }
+
+extern "C" int nk2d_set_lin_state(nk2d_ctx* c, nk2d_vec y) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (!c->YLIN) NK2D_TRY(dev_alloc(c, &c->YLIN, c->nv));
+    NK2D_CHECK(c, hipMemcpyAsync(c->YLIN, y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    c->ylin_set = 1;
+    return 0;
+}
+
+extern "C" int nk2d_jacobian_apply(nk2d_ctx* c, double t, nk2d_vec v, nk2d_vec out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    double* kv[1] = {c->KV[4]};
+    NK2D_TRY(nk2d_k_vmix(c, 1, &t, kv));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4], lin_state(c)));
+    NK2D_TRY(nk2d_k_jac_apply(c, (const double*)v, (double*)out));
+    return 0;
+}
+
 extern "C" int nk2d_jacobian_diags(nk2d_ctx* c, double t, double* host_out) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->kind == 1) return nk2d_fail(c, "nk2d_jacobian_diags: the phosphorus Jacobian is not five diagonals; use nk2d_jacobian_apply");
     double* out[1] = {c->KV[4]};
     NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
-    NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4], nullptr));
     const size_t P = (size_t)c->nz * c->ny;
     NK2D_TRY(ensure_stage(c, P));
     const double* planes[5] = {c->JL, c->JS, c->JC, c->JN, c->JU};
@@ -477,7 +520,7 @@ extern "C" int nk2d_shifted_solve(nk2d_ctx* c, double t_jac, double h, double mu
     NK2D_CHECK(c, hipSetDevice(c->dev));
     double* out[1] = {c->KV[4]};
     NK2D_TRY(nk2d_k_vmix(c, 1, &t_jac, out));
-    NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4], lin_state(c)));
     const bool cplxsys = mu_im != 0.0;
     const int m = nk2d_sweeps_for(c, mu_re / h);
     NK2D_TRY(nk2d_k_factor(c, !cplxsys, cplxsys, mu_re / h, mu_re / h, mu_im / h));

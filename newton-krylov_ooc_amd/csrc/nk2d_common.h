@@ -31,6 +31,7 @@
 struct nk2d_ctx {
     nk2d_desc d;
     int nz, ny, tc, E, nzp, ncol, nreg;
+    int kind;   // module kind: 0 linear sources (iage, forced), 1 phosphorus
     size_t nv;  // doubles per state vector  (tc*ny*nzp)
     size_t np;  // doubles per (depth, ypos) plane (ny*nzp)
     int dev;
@@ -54,6 +55,10 @@ struct nk2d_ctx {
     double* WN;      // grid_weight / sum over region [np]
     // Jacobian planes at t_jac (tracer independent part), np each
     double *JL, *JU, *JS, *JN, *JC;
+    // phosphorus module: light limitation [np], d uptake / d po4 at the linearisation state [np],
+    // linearisation state of the stand-alone Jacobian entry points [nv]
+    double *LIGHT, *UPR, *YLIN;
+    int ylin_set;
     // vertical mixing planes: 3 stage times, current t, scratch
     double* KV[5];
     // Radau work vectors (nv each unless noted)
@@ -147,6 +152,16 @@ static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK 
         case 7: { constexpr int EE = 7; __VA_ARGS__; } break;               \
         case 8: { constexpr int EE = 8; __VA_ARGS__; } break;               \
         default: break;                                              \
+    }
+
+// as above, plus a compile-time module kind KK (0: linear sources, 1: phosphorus)
+#define NK2D_DISPATCH_EK(Eval, kind, ...)                                        \
+    if ((kind) == 1) {                                                            \
+        constexpr int KK = 1;                                                     \
+        NK2D_DISPATCH_E(Eval, __VA_ARGS__)                                        \
+    } else {                                                                      \
+        constexpr int KK = 0;                                                     \
+        NK2D_DISPATCH_E(Eval, __VA_ARGS__)                                        \
     }
 
 // ---------------------------------------------------------------------------------
@@ -384,7 +399,8 @@ int nk2d_k_unpack_state(nk2d_ctx* c, const double* src, double* dst_dev);
 int nk2d_k_unpack_plane(nk2d_ctx* c, const double* src, int nrows, int ncols, double* dst_dev);
 int nk2d_k_vmix(nk2d_ctx* c, int nt, const double* times, double* const* out);
 int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f);
-int nk2d_k_jac(nk2d_ctx* c, const double* kv);
+int nk2d_k_jac(nk2d_ctx* c, const double* kv, const double* ylin);
+int nk2d_k_jac_apply(nk2d_ctx* c, const double* v, double* out);
 int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre, double ccr, double cci,
                  const double* br, const double* bcr, const double* bci, int src);
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci);

@@ -17,6 +17,9 @@ struct DevP {
     double surf[NK2D_MAX_TRACERS], starget[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
     double atol, rtol;
     const int* guard;  // guarded kernels return at once when *guard != 0
+    // phosphorus module (kind 1): parameters, light limitation plane, d uptake / d po4 at t_jac
+    double ph_hs, ph_mu, ph_sig, ph_rd, ph_rp, ph_vs;
+    const double *LIGHT, *UPR;
 };
 
 static DevP make_devp(const nk2d_ctx* c) {
@@ -31,6 +34,9 @@ static DevP make_devp(const nk2d_ctx* c) {
     p.csrc = c->d.const_src;
     p.atol = c->d.atol; p.rtol = c->d.rtol;
     p.guard = c->cur_guard;
+    p.ph_hs = c->d.phos_params[0]; p.ph_mu = c->d.phos_params[1]; p.ph_sig = c->d.phos_params[2];
+    p.ph_rd = c->d.phos_params[3]; p.ph_rp = c->d.phos_params[4]; p.ph_vs = c->d.phos_params[5];
+    p.LIGHT = c->LIGHT; p.UPR = c->UPR;
     return p;
 }
 
@@ -290,7 +296,62 @@ __device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, co
     }
 }
 
+// phosphorus sources added to the transport tendency of tracer tr (0 po4, 1 dop, 2 pop) in the
+// reference's order (phosphorus.py:66-88): light- and po4-limited uptake, remineralisation of
+// dop and pop, sinking of pop.  po4 / dop / pop: the module's tracers at this wave's ypos column.
 template <int E>
+__device__ __forceinline__ void phos_tend(const DevP& P, int tr, int j, int lane, const double (&po4)[E],
+                                          const double (&dop)[E], const double (&pop)[E], const double (&dzr)[E],
+                                          double (&out)[E]) {
+    double light[E], popprev[E];
+    load_col<E>(P.LIGHT, j, lane, light);
+    shift_prev<E>(pop, popprev, lane, 0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        const double lim = po4[e] / (po4[e] + P.ph_hs);
+        const double uptake = (P.ph_mu * light[e]) * lim;
+        const double dop_remin = P.ph_rd * dop[e], pop_remin = P.ph_rp * pop[e];
+        double t = out[e];
+        if (tr == 0) {
+            t = t - uptake;
+            t = t + (dop_remin + pop_remin);
+        } else if (tr == 1) {
+            t = t + P.ph_sig * uptake;
+            t = t - dop_remin;
+        } else {
+            t = t + (1.0 - P.ph_sig) * uptake;
+            t = t - pop_remin;
+            const double sT = (k > 0) ? P.ph_vs * popprev[e] : 0.0;
+            const double sB = (k < P.nz - 1) ? P.ph_vs * pop[e] : 0.0;
+            t = t + dzr[e] * (sT - sB);
+        }
+        out[e] = (k < P.nz) ? t : 0.0;
+    }
+}
+
+// the three tracers of the phosphorus module at ypos column j:  a (+ b when b != nullptr)
+template <int E>
+__device__ __forceinline__ void load_trio(const DevP& P, const double* __restrict__ a, const double* __restrict__ b,
+                                          int j, int lane, double (&po4)[E], double (&dop)[E], double (&pop)[E]) {
+    load_col<E>(a, j, lane, po4);
+    load_col<E>(a, P.ny + j, lane, dop);
+    load_col<E>(a, 2 * P.ny + j, lane, pop);
+    if (b != nullptr) {
+        double t[E];
+        load_col<E>(b, j, lane, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) po4[e] = po4[e] + t[e];
+        load_col<E>(b, P.ny + j, lane, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) dop[e] = dop[e] + t[e];
+        load_col<E>(b, 2 * P.ny + j, lane, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) pop[e] = pop[e] + t[e];
+    }
+}
+
+template <int E, int KIND>
 __global__ void k_tend(DevP P, const double* __restrict__ y, const double* __restrict__ kvp, double* __restrict__ f) {
     TASK_PROLOGUE(P.ncol)
     const int tr = task / P.ny, j = task - tr * P.ny;
@@ -302,12 +363,17 @@ __global__ void k_tend(DevP P, const double* __restrict__ y, const double* __res
     load_col<E>(y, (j < P.ny - 1) ? task + 1 : task, lane, cn);
     load_col<E>(kvp, j, lane, kv);
     tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, out);
+    if constexpr (KIND == 1) {
+        double po4[E], dop[E], pop[E];
+        load_trio<E>(P, y, nullptr, j, lane, po4, dop, pop);
+        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, out);
+    }
     store_col<E>(f, task, lane, out);
 }
 
 int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f) {
     DevP P = make_devp(c);
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_tend<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_tend<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                                P, y, kv, f));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
@@ -320,7 +386,8 @@ int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f) {
 // ---------------------------------------------------------------------------------
 template <int E>
 __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict__ JL, double* __restrict__ JU,
-                      double* __restrict__ JS, double* __restrict__ JN, double* __restrict__ JC) {
+                      double* __restrict__ JS, double* __restrict__ JN, double* __restrict__ JC,
+                      const double* __restrict__ ylin, double* __restrict__ UPR) {
     TASK_PROLOGUE(P.ny)
     const int j = task;
     ColCoef<E> cf;
@@ -354,12 +421,28 @@ __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict
     store_col<E>(JS, j, lane, so);
     store_col<E>(JN, j, lane, no);
     store_col<E>(JC, j, lane, ce);
+    if (ylin != nullptr) {
+        // d uptake / d po4 at the linearisation state (phosphorus.py:97-103)
+        double po4[E], light[E], upr[E];
+        load_col<E>(ylin, j, lane, po4);
+        load_col<E>(P.LIGHT, j, lane, light);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double den = po4[e] + P.ph_hs;
+            const double lim_d = P.ph_hs / (den * den);
+            upr[e] = ((lane * E + e) < P.nz) ? (P.ph_mu * light[e]) * lim_d : 0.0;
+        }
+        store_col<E>(UPR, j, lane, upr);
+    }
 }
 
-int nk2d_k_jac(nk2d_ctx* c, const double* kv) {
+// ylin: linearisation state (used by the phosphorus module only)
+int nk2d_k_jac(nk2d_ctx* c, const double* kv, const double* ylin) {
     DevP P = make_devp(c);
+    if (c->kind == 1 && ylin == nullptr) return nk2d_fail(c, "nk2d_k_jac: the phosphorus Jacobian needs a linearisation state");
+    if (c->kind != 1) ylin = nullptr;
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_jac<EE>, dim3(nk2d_grid(c->ny)), dim3(NK2D_BLOCK), 0, c->stream, P, kv,
-                                               c->JL, c->JU, c->JS, c->JN, c->JC));
+                                               c->JL, c->JU, c->JS, c->JN, c->JC, ylin, c->UPR));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
@@ -389,9 +472,88 @@ __device__ __forceinline__ void load_tab(const double* __restrict__ tab, int col
     for (int i = 0; i < NK2D_TAB; ++i) t[i] = p[i * 64];
 }
 
+// sub / super diagonal of the column tridiagonal of tracer tr: -(JL + module part), -JU
+template <int E, int KIND>
+__device__ __forceinline__ void line_offdiag(const DevP& P, int tr, int lane, const double (&jl)[E], const double (&ju)[E],
+                                             double (&a)[E], double (&cc)[E]) {
+    double dzr[E];
+    if constexpr (KIND == 1) load_col<E>(P.DZR, 0, lane, dzr);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        const bool valid = k < P.nz;
+        double lo = jl[e];
+        if constexpr (KIND == 1) {
+            if (tr == 2 && k > 0) lo = lo + P.ph_vs * dzr[e];  // pop sinking in from above (phosphorus.py:142-150)
+        }
+        a[e] = valid ? -lo : 0.0;
+        cc[e] = valid ? -ju[e] : 0.0;
+    }
+}
+
+// coupling between the tracers of the phosphorus module, kept on the right-hand side of the
+// line relaxation: r += (d tend[tr] / d other tracers) * x_old  (phosphorus.py:119-140)
+template <int E>
+__device__ __forceinline__ void phos_couple(const DevP& P, int tr, int j, int lane, const double* __restrict__ xold,
+                                            const double (&upr)[E], double (&r)[E]) {
+    if (tr == 0) {
+        double x1[E], x2[E];
+        load_col<E>(xold, P.ny + j, lane, x1);
+        load_col<E>(xold, 2 * P.ny + j, lane, x2);
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = __builtin_fma(P.ph_rd, x1[e], __builtin_fma(P.ph_rp, x2[e], r[e]));
+    } else {
+        double x0[E];
+        load_col<E>(xold, j, lane, x0);
+        const double frac = (tr == 1) ? P.ph_sig : 1.0 - P.ph_sig;
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = __builtin_fma(frac * upr[e], x0[e], r[e]);
+    }
+}
+
+// out = J v with the planes of the last k_jac (and, for the phosphorus module, its coupling)
+template <int E, int KIND>
+__global__ void k_jac_apply(DevP P, SweepArgs A, const double* __restrict__ v, double* __restrict__ out) {
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    double jl[E], ju[E], js[E], jn[E], jc[E], a[E], cc[E], x[E], xs[E], xn[E], xp[E], xq[E], r[E];
+    load_col<E>(A.JL, j, lane, jl);
+    load_col<E>(A.JU, j, lane, ju);
+    load_col<E>(A.JS, j, lane, js);
+    load_col<E>(A.JN, j, lane, jn);
+    load_col<E>(A.JC, j, lane, jc);
+    line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
+    load_col<E>(v, task, lane, x);
+    load_col<E>(v, (j > 0) ? task - 1 : task, lane, xs);
+    load_col<E>(v, (j < P.ny - 1) ? task + 1 : task, lane, xn);
+    shift_prev<E>(x, xp, lane, 0.0);
+    shift_next<E>(x, xq, lane, 0.0);
+    double upr[E], dzr[E];
+    if constexpr (KIND == 1) {
+        load_col<E>(P.UPR, j, lane, upr);
+        load_col<E>(P.DZR, 0, lane, dzr);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        double d = jc[e] - P.decay[tr];
+        if (k == 0) d = d - P.surf[tr];
+        if constexpr (KIND == 1) {
+            if (tr == 0) d = d - upr[e];
+            else if (tr == 1) d = d - P.ph_rd;
+            else d = d - (P.ph_rp + ((k < P.nz - 1) ? P.ph_vs * dzr[e] : 0.0));
+        }
+        r[e] = (((d * x[e] - a[e] * xp[e]) - cc[e] * xq[e]) + js[e] * xs[e]) + jn[e] * xn[e];
+    }
+    if constexpr (KIND == 1) phos_couple<E>(P, tr, j, lane, v, upr, r);
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = ((lane * E + e) < P.nz) ? r[e] : 0.0;
+    store_col<E>(out, task, lane, r);
+}
+
 // pivots and PCR tables of every column's tridiagonal T_j = tridiag(-JL, c - JC + extra, -JU)
 // for the real and/or the complex shift; one launch per SciPy "LU" event
-template <int E>
+template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     TASK_PROLOGUE(A.ntasks)
     // the (system, tracer) variants of one ypos column sit in adjacent waves of a block, so
@@ -404,15 +566,24 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     load_col<E>(A.JL, j, lane, jl);
     load_col<E>(A.JU, j, lane, ju);
     load_col<E>(A.JC, j, lane, jc);
+    line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
+    double upr[E], dzr[E];
+    if constexpr (KIND == 1) {
+        load_col<E>(P.UPR, j, lane, upr);
+        load_col<E>(P.DZR, 0, lane, dzr);
+    }
     const double shift_re = is_c ? A.ccr : A.cre;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = lane * E + e;
         const bool valid = k < P.nz;
-        a[e] = valid ? -jl[e] : 0.0;
-        cc[e] = valid ? -ju[e] : 0.0;
         double d = (shift_re - jc[e]) + P.decay[tr];
         if (k == 0) d = d + P.surf[tr];
+        if constexpr (KIND == 1) {
+            if (tr == 0) d = d + upr[e];
+            else if (tr == 1) d = d + P.ph_rd;
+            else d = d + (P.ph_rp + ((k < P.nz - 1) ? P.ph_vs * dzr[e] : 0.0));
+        }
         dre[e] = valid ? d : 1.0;
     }
     if (!is_c) {
@@ -439,7 +610,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     }
 }
 
-template <int E>
+template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
     GUARD_RETURN(P.guard)
     TASK_PROLOGUE(A.ntasks)
@@ -450,17 +621,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
     double jl[E], ju[E], a[E], cc[E];
     load_col<E>(A.JL, j, lane, jl);
     load_col<E>(A.JU, j, lane, ju);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool valid = (lane * E + e) < P.nz;
-        a[e] = valid ? -jl[e] : 0.0;
-        cc[e] = valid ? -ju[e] : 0.0;
-    }
+    line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     const int cs_col = (j > 0) ? col - 1 : col, cn_col = (j < P.ny - 1) ? col + 1 : col;
-    double js[E], jn[E];
+    double js[E], jn[E], upr[E];
     if (!A.first) {
         load_col<E>(A.JS, j, lane, js);
         load_col<E>(A.JN, j, lane, jn);
+        if constexpr (KIND == 1) load_col<E>(P.UPR, j, lane, upr);
     }
     if (!is_c) {
         double r[E], inv[E], tab[NK2D_TAB];
@@ -473,6 +640,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
             load_col<E>(A.xr_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], r[e]));
+            if constexpr (KIND == 1) phos_couple<E>(P, tr, j, lane, A.xr_old, upr, r);
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) r[e] = ((lane * E + e) < P.nz) ? r[e] : 0.0;
@@ -501,6 +669,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
             load_col<E>(A.xci_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) ri[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], ri[e]));
+            if constexpr (KIND == 1) {
+                phos_couple<E>(P, tr, j, lane, A.xcr_old, upr, rr);
+                phos_couple<E>(P, tr, j, lane, A.xci_old, upr, ri);
+            }
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -521,6 +693,16 @@ static void fill_factor_args(const nk2d_ctx* c, SweepArgs& A) {
     A.fr_tab = c->FR_TAB; A.fc_tabr = c->FC_TABR; A.fc_tabi = c->FC_TABI;
 }
 
+int nk2d_k_jac_apply(nk2d_ctx* c, const double* v, double* out) {
+    SweepArgs A = {};
+    fill_factor_args(c, A);
+    DevP P = make_devp(c);
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_jac_apply<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A, v, out));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci) {
     SweepArgs A = {};
     fill_factor_args(c, A);
@@ -531,7 +713,7 @@ int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double cc
     if (A.ntasks == 0) return 0;
     DevP P = make_devp(c);
     P.guard = nullptr;
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_factor<EE>, dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_factor<EE, KK>), dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
@@ -555,7 +737,7 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
     const bool sample = false;  // the profiled kernel is k_newton_fused
     if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
     const int wpb = c->sweep_wpb;  // waves per block of the sweep kernel
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_sweep<EE>, dim3((A.ntasks + wpb - 1) / wpb), dim3(64 * wpb), 0, c->stream, P, A));
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_sweep<EE, KK>), dim3((A.ntasks + wpb - 1) / wpb), dim3(64 * wpb), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
     if (sample) {
         NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
@@ -800,7 +982,7 @@ struct FusedArgs {
     int do_stage, do_update;
 };
 
-template <int E>
+template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
     GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
@@ -826,6 +1008,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
 #pragma unroll
             for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
             tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
+            if constexpr (KIND == 1) {
+                double po4[E], dop[E], pop[E];
+                load_trio<E>(P, A.st.y, A.st.z + i * A.st.nv, j, lane, po4, dop, pop);
+                phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, f);
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 fr[e] = fr[e] + f[e] * cTI[0][i];
@@ -858,12 +1045,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         double jl[E], ju[E];
         load_col<E>(A.sw.JL, j, lane, jl);
         load_col<E>(A.sw.JU, j, lane, ju);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool valid = (lane * E + e) < P.nz;
-            a[e] = valid ? -jl[e] : 0.0;
-            cc[e] = valid ? -ju[e] : 0.0;
-        }
+        line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     }
     if (!A.sw.first) {
         double js[E], jn[E], xs[E], xn[E];
@@ -881,6 +1063,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         load_col<E>(A.sw.xci_old, cn_col, lane, xn);
 #pragma unroll
         for (int e = 0; e < E; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
+        if constexpr (KIND == 1) {
+            double upr[E];
+            load_col<E>(P.UPR, j, lane, upr);
+            phos_couple<E>(P, tr, j, lane, A.sw.xr_old, upr, fr);
+            phos_couple<E>(P, tr, j, lane, A.sw.xcr_old, upr, fcr);
+            phos_couple<E>(P, tr, j, lane, A.sw.xci_old, upr, fci);
+        }
     }
     // real system
     {
@@ -969,7 +1158,7 @@ __global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* 
 }
 
 // filtered error estimate right-hand side  fun(t, y + error) + Z^T E / h  (radau.py:485-487)
-template <int E>
+template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK)
     k_err_rhs2(DevP P, const double* __restrict__ y, const double* __restrict__ err, const double* __restrict__ kvp,
                const double* __restrict__ z, size_t nv, double h, double* __restrict__ out) {
@@ -993,6 +1182,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
     load_col<E>(kvp, j, lane, kv);
     tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    if constexpr (KIND == 1) {
+        double po4[E], dop[E], pop[E];
+        load_trio<E>(P, y, err, j, lane, po4, dop, pop);
+        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, ff);
+    }
     double z0[E], z1[E], z2[E];
     load_col<E>(z, task, lane, z0);
     load_col<E>(z + nv, task, lane, z1);
@@ -1166,7 +1360,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     const bool sample = c->prof_every > 0 && (c->sweep_launches % c->prof_every) == 0 &&
                         c->prof_used + 2 <= c->prof_ev.size();
     if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_newton_fused<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
     if (sample) {
         NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
@@ -1186,7 +1380,7 @@ int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
 }
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
     DevP P = make_devp(c);
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs2<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_err_rhs2<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
                                                c->Y, err, c->KV[3], c->Z, c->nv, h, c->BR));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;

@@ -289,6 +289,7 @@ void nk2d_precond_free(nk2d_ctx* c) {
 
 extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->kind != 0) return nk2d_fail(c, "nk2d_precond_setup: only the linear modules (iage, forced) have a device preconditioner");
     nk2d_precond_free(c);
     Precond* pc = new Precond();
     c->precond = pc;
@@ -312,7 +313,7 @@ extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
         const double t = c->d.t0 + (tau + 0.5) * pc->dt;
         double* out[1] = {c->KV[4]};
         NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
-        NK2D_TRY(nk2d_k_jac(c, c->KV[4]));
+        NK2D_TRY(nk2d_k_jac(c, c->KV[4], nullptr));
         const double* planes[5] = {c->JL, c->JS, c->JC, c->JN, c->JU};
         for (int pl = 0; pl < 5; ++pl)
             NK2D_TRY(nk2d_k_unpack_plane(c, planes[pl], c->nz, c->ny, pc->PJ + ((size_t)tau * 5 + pl) * P));

@@ -57,7 +57,7 @@ int eval_kv(nk2d_ctx* c, double t, int slot) {
 int refresh_jac(Ctl& s, double t, bool kv_in_slot3) {
     nk2d_ctx* c = s.c;
     if (!kv_in_slot3) NK2D_TRY(eval_kv(c, t, 4));
-    NK2D_TRY(nk2d_k_jac(c, kv_in_slot3 ? c->KV[3] : c->KV[4]));
+    NK2D_TRY(nk2d_k_jac(c, kv_in_slot3 ? c->KV[3] : c->KV[4], c->Y));  // c->Y is the state at t at every call site
     s.t_jac = t;
     return 0;
 }

@@ -56,7 +56,7 @@ class ModuleEngine:
     def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, surf_target=(),
                  device_id=0,
                  time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
-                 lin_tol=None):
+                 lin_tol=None, module_kind=0, phos_params=None, light_lim=None):
         self._lib = _lib.load()
         self._ctx = None
         self.grid = grid
@@ -92,6 +92,13 @@ class ModuleEngine:
         if lin_tol is None:
             lin_tol = float(os.environ.get("NK2D_LIN_TOL", DEFAULT_LIN_TOL))
         desc.lin_tol = float(lin_tol)
+        desc.module_kind = int(module_kind)
+        if module_kind == 1:
+            keep.append(np.ascontiguousarray(light_lim, dtype=np.float64))
+            assert keep[-1].shape == (self.nz, self.ny)
+            desc.light_lim = _dp(keep[-1])
+            desc.phos_params = (ctypes.c_double * 6)(*[float(v) for v in phos_params])
+        self.module_kind = int(module_kind)
         ctx = ctypes.c_void_p()
         rc = self._lib.nk2d_create(ctypes.byref(desc), ctypes.byref(ctx))
         if rc != 0:
@@ -167,6 +174,16 @@ class ModuleEngine:
         host = np.empty((5, self.tc, self.nz, self.ny))
         self._chk(self._lib.nk2d_jacobian_diags(self._ctx, float(t), _dp(host)))
         return host
+
+    def set_lin_state(self, y):
+        """state the stand-alone Jacobian calls linearise about (phosphorus only uses it)"""
+        self._chk(self._lib.nk2d_set_lin_state(self._ctx, y.ptr))
+
+    def jacobian_apply(self, t, v):
+        """J(t, lin_state) v as a new device vector"""
+        out = self.new_vec()
+        self._chk(self._lib.nk2d_jacobian_apply(self._ctx, float(t), v.ptr, out.ptr))
+        return out
 
     def shifted_solve(self, t_jac, h, mu, b_re, b_im=None):
         """x = ((mu/h) I - J(t_jac))^-1 b; returns (x_re, x_im or None, sweeps)"""
@@ -315,3 +332,39 @@ def forced_engine(grid, modelinfo, device_id=0, **kwargs):
     const_src = float(modelinfo["forced_sms_const"]) if sms_opt == "const" else 0.0
     return ModuleEngine(grid, tc=1, surf_rate=(surf_rate,), surf_target=(surf_target,),
                         decay_rate=(decay,), const_src=const_src, device_id=device_id, **kwargs)
+
+
+PHOSPHORUS_PARAM_NAMES = ("po4_halfsat", "max_uptake_rate", "sigma", "dop_remin_rate",
+                          "pop_remin_rate", "pop_sink_vel")
+
+
+def phosphorus_params(overrides=None):
+    """parameters of the phosphorus module with the reference's defaults (phosphorus.py:42-58)"""
+    params = {
+        "po4_halfsat": 0.5,
+        "max_uptake_rate": 1.0 / (3.0 * 86400.0),
+        "sigma": 0.67,
+        "dop_remin_rate": 1.0 / (0.5 * 365.0 * 86400.0),
+        "pop_remin_rate": 1.0 / (0.5 * 365.0 * 86400.0),
+        "pop_sink_vel": 2.0 / 86400.0,
+    }
+    for name, val in (overrides or {}).items():
+        if name not in params:
+            raise ValueError(f"unknown phosphorus parameter {name}")
+        params[name] = float(val)
+    return params
+
+
+def phosphorus_light_lim(grid):
+    """light limitation: e-folding depth 25 m, Gaussian in ypos (phosphorus.py:26-29)"""
+    return np.outer(np.exp((-1.0 / 25.0) * grid.depth.mid),
+                    np.exp(-1.0 * ((grid.ypos.mid - 2.5e6) / 1.5e6) ** 2))
+
+
+def phosphorus_engine(grid, params=None, device_id=0, **kwargs):
+    """engine of the `phosphorus` tracer module (po4, dop, pop; phosphorus.py:17-172):
+    nonlinear uptake couples the three tracers in every cell"""
+    prm = phosphorus_params(params)
+    return ModuleEngine(grid, tc=3, device_id=device_id, module_kind=1,
+                        phos_params=[prm[name] for name in PHOSPHORUS_PARAM_NAMES],
+                        light_lim=phosphorus_light_lim(grid), **kwargs)

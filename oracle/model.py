@@ -375,6 +375,80 @@ class Forced(TracerModule):
     apply_precond = Iage.apply_precond
 
 
+class Phosphorus(TracerModule):
+    """phosphorus module: po4, dop, pop coupled per cell (reference
+    `py_driver_2d/phosphorus.py:17-172`): light- and po4-limited uptake (Michaelis-Menten),
+    remineralisation of dop and pop back to po4, sinking of pop"""
+
+    tc = 3
+    tracer_names = ("po4", "dop", "pop")
+
+    def __init__(self, model, **params):
+        super().__init__(model)
+        self.light_lim = np.outer(
+            np.exp((-1.0 / 25.0) * model.depth.mid),
+            np.exp(-1.0 * ((model.ypos.mid - 2.5e6) / 1.5e6) ** 2),
+        )
+        self.params = {
+            "po4_halfsat": 0.5,
+            "max_uptake_rate": 1.0 / (3.0 * 86400.0),
+            "sigma": 0.67,
+            "dop_remin_rate": 1.0 / (0.5 * 365.0 * 86400.0),
+            "pop_remin_rate": 1.0 / (0.5 * 365.0 * 86400.0),
+            "pop_sink_vel": 2.0 / 86400.0,
+        }
+        self.params.update(params)
+
+    def po4_uptake(self, po4):
+        lim = po4 / (po4 + self.params["po4_halfsat"])
+        return self.params["max_uptake_rate"] * self.light_lim * lim
+
+    def po4_uptake_deriv(self, po4):
+        lim_d = self.params["po4_halfsat"] / (po4 + self.params["po4_halfsat"]) ** 2
+        return self.params["max_uptake_rate"] * self.light_lim * lim_d
+
+    def _add_sources(self, time, c, tend):
+        prm = self.params
+        uptake = self.po4_uptake(c[0])
+        tend[0] -= uptake
+        tend[1] += prm["sigma"] * uptake
+        tend[2] += (1.0 - prm["sigma"]) * uptake
+        dop_remin = prm["dop_remin_rate"] * c[1]
+        pop_remin = prm["pop_remin_rate"] * c[2]
+        tend[0] += dop_remin + pop_remin
+        tend[1] -= dop_remin
+        tend[2] -= pop_remin
+        sink = np.zeros((self.model.nz + 1, self.model.ny))
+        sink[1:-1, :] = prm["pop_sink_vel"] * c[2, :-1]
+        tend[2] += self.model.depth.delta_r[:, np.newaxis] * (sink[:-1, :] - sink[1:, :])
+        return tend
+
+    def comp_jacobian(self, time, y):
+        m = self.model
+        prm = self.params
+        P = m.nz * m.ny
+        c = np.asarray(y).reshape(self.tc, m.nz, m.ny)
+        up, south, center, north, dn = m.jac_diags(time)
+        base = m.diags_to_csr(up, south, center, north, dn)
+        jac = sparse.block_diag([base] * 3, "csr")
+        upd = sparse.diags(self.po4_uptake_deriv(c[0]).reshape(-1))
+        zero = sparse.csr_matrix((P, P))
+        ident = sparse.identity(P)
+        jac = jac + sparse.bmat([[-upd, zero, zero], [prm["sigma"] * upd, zero, zero],
+                                 [(1.0 - prm["sigma"]) * upd, zero, zero]])
+        rd = prm["dop_remin_rate"] * ident
+        rp = prm["pop_remin_rate"] * ident
+        jac = jac + sparse.bmat([[zero, rd, rp], [zero, -rd, zero], [zero, zero, -rp]])
+        d0 = np.empty((m.nz, m.ny))
+        d0[:] = -prm["pop_sink_vel"] * m.depth.delta_r[:, np.newaxis]
+        d0[-1, :] = 0.0
+        dm1 = np.empty((m.nz - 1, m.ny))
+        dm1[:] = prm["pop_sink_vel"] * m.depth.delta_r[1:, np.newaxis]
+        sink = sparse.diags((d0.reshape(-1), dm1.reshape(-1)), (0, -m.ny))
+        jac = jac + sparse.bmat([[zero, zero, zero], [zero, zero, zero], [zero, zero, sink]])
+        return jac.tocsr()
+
+
 def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3):
     """The SAME operator as `Iage.apply_precond`, M^-1 = (I - A_0 A_1 A_2)^-1 - I with
     A_k = I - dt J(t_k), evaluated without forming the triple product: with

@@ -225,6 +225,56 @@ def gen_forced(tag, nz, ny, params, seed, with_fcn=False):
     print("wrote forced", tag)
 
 
+def gen_phosphorus(tag, nz, ny, seed, with_fcn=False):
+    """reference phosphorus module: tendencies, Jacobian, one forward year"""
+    from scipy import integrate
+
+    from nk_ooc.py_driver_2d.advection import Advection
+    from nk_ooc.py_driver_2d.horiz_mix import HorizMix
+    from nk_ooc.py_driver_2d.phosphorus import phosphorus
+    from nk_ooc.py_driver_2d.vert_mix import VertMix
+
+    depth, ypos = ref_axes(nz, ny)
+    modelinfo = {"max_abs_vvel": "0.1", "horiz_mix_coeff": "1000.0"}
+    processes = {"advection": Advection(depth, ypos, modelinfo),
+                 "horiz_mix": HorizMix(depth, ypos, modelinfo),
+                 "vert_mix": VertMix(depth, ypos)}
+    tm = object.__new__(phosphorus)
+    tm.name = "phosphorus"
+    tm.tracer_cnt = 3
+    tm.depth = depth
+    tm.ypos = ypos
+    tm.light_lim = np.outer(np.exp((-1.0 / 25.0) * depth.mid),
+                            np.exp(-1.0 * ((ypos.mid - 2.5e6) / 1.5e6) ** 2))
+    tm.po4_ind, tm.dop_ind, tm.pop_ind = 0, 1, 2
+    tm.params = phosphorus.gen_params({})
+    tm.pop_sink_work = np.zeros((nz + 1, ny))
+    year = 365.0 * 86400.0
+    times = [0.0, 0.3 * year, 0.66 * year]
+    rng = np.random.default_rng(seed)
+    # positive, vertically structured state (the init_iterate profiles of tracer_module_defs.yaml)
+    prof = [np.interp(depth.mid, zs, vs) for zs, vs in (([1.3e2, 2.6e2], [5.5e-3, 4.1e0]),
+                                                       ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                       ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+    y0 = np.stack([np.broadcast_to(p[:, None], (nz, ny)) for p in prof]).copy()
+    y = (y0 * (1.0 + 0.2 * rng.random(y0.shape))).reshape(-1)
+    out = {"nz": nz, "ny": ny, "times": np.asarray(times), "y": y, "light_lim": tm.light_lim}
+    out["tend"] = np.stack([tm.comp_tend(t, y, processes).copy() for t in times])
+    for i, t in enumerate(times):
+        jac = tm.comp_jacobian(t, y, processes).tocsr()
+        jac.sum_duplicates()
+        jac.sort_indices()
+        out[f"jac{i}_data"], out[f"jac{i}_indices"], out[f"jac{i}_indptr"] = jac.data, jac.indices, jac.indptr
+    if with_fcn:
+        time_range = (0.0, year)
+        sol = integrate.solve_ivp(
+            tm.comp_tend, time_range, y, "Radau", np.array(time_range), max_step=year * 0.01,
+            atol=1.0e-6, rtol=1.0e-6, args=(processes,), jac=tm.comp_jacobian)
+        out.update(y0=y, fcn=sol.y[:, -1] - y, nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu)
+    np.savez_compressed(os.path.join(HERE, f"phosphorus_{tag}.npz"), **out)
+    print("wrote phosphorus", tag)
+
+
 def gen_lstsq(seed):
     """_comp_krylov_basis_coeffs known answers (krylov_solver.py:168-181)"""
     from nk_ooc.krylov_solver import _comp_krylov_basis_coeffs
@@ -255,6 +305,8 @@ def main():
     gen_precond("26x26", 26, 26, 0.1, 1000.0, 4)
     gen_precond("20x3_columns", 20, 3, 0.0, 0.0, 5)
     gen_lstsq(6)
+    gen_phosphorus("22x9", 22, 9, 9, with_fcn=True)
+    gen_phosphorus("70x12", 70, 12, 10)
     gen_forced("decay_22x9", 22, 9, {"surf_restore_opt": "none", "sms_opt": "decay",
                                      "sms_decay_rate": 1.0e-8}, 7, with_fcn=True)
     gen_forced("restore_const_22x9", 22, 9, {"surf_restore_opt": "const", "surf_restore_const": 1.5,
