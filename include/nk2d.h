@@ -52,6 +52,7 @@ typedef struct nk2d_ctx nk2d_ctx;
 typedef void* nk2d_vec;
 
 #define NK2D_MAX_TRACERS 4
+#define NK2D_MAX_SHIFTS 4
 #define NK2D_SCHED_WIDTH 6 /* doubles per accepted step: t, t_new, h, n_newton, t_jac, h_lu */
 
 typedef struct nk2d_desc {
@@ -150,6 +151,13 @@ int nk2d_comp_fcn_hist(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats
 /* preconditioner  M^-1 v = (I - prod_k (I - dt J(t_k)))^-1 v - v */
 int nk2d_precond_setup(nk2d_ctx* ctx);
 int nk2d_precond_apply(nk2d_ctx* ctx, nk2d_vec v, nk2d_vec out);
+/* shifted systems of the phosphorus preconditioner (phosphorus.py:233-255): factorise
+   A_i = scale * J(t, lin_state) - shifts[i] * I (all tracers of the module coupled, nshift <=
+   NK2D_MAX_SHIFTS) by block elimination over the ypos columns, replacing the reference's
+   sp_linalg.spsolve(mat - shift * mat_id, .) and the solves inside sp_linalg.eigs(sigma=...);
+   nk2d_shift_solve: out = A_i^-1 v.  Shares its storage with nk2d_precond_setup. */
+int nk2d_shift_factor(nk2d_ctx* ctx, double t, double scale, int32_t nshift, const double* shifts);
+int nk2d_shift_solve(nk2d_ctx* ctx, int32_t i, nk2d_vec v, nk2d_vec out);
 
 /* state algebra; region scalars are host arrays [nreg], broadcast with fill 1.0 where mask<=0 */
 int nk2d_dot(nk2d_ctx* ctx, nk2d_vec a, nk2d_vec b, double* out /* [nreg] */);

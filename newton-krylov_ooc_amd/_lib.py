@@ -97,6 +97,8 @@ SIGNATURES = {
     "nk2d_vmix_coeff": (_ci, [_vp, _d, c_double_p]),
     "nk2d_jacobian_diags": (_ci, [_vp, _d, c_double_p]),
     "nk2d_set_lin_state": (_ci, [_vp, _vp]),
+    "nk2d_shift_factor": (_ci, [_vp, _d, _d, ctypes.c_int32, c_double_p]),
+    "nk2d_shift_solve": (_ci, [_vp, ctypes.c_int32, _vp, _vp]),
     "nk2d_jacobian_apply": (_ci, [_vp, _d, _vp, _vp]),
     "nk2d_shifted_solve": (_ci, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, c_int32_p]),
     "nk2d_comp_fcn": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), c_double_p, _i64,

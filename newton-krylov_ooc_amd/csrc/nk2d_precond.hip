@@ -31,7 +31,10 @@ namespace {
 
 struct Precond {
     int m, nb, nz, nt, tc;
-    double* PJ;    // Jacobian planes, natural layout [nt][5][nz][ny]  (L, S, C, N, U)
+    int mode;      // 0: time-periodic system of the linear modules, 1: shifted systems (nk2d_shift_factor)
+    int nsys;      // independent systems held in SINV: tracers (mode 0) or shifts (mode 1)
+    double scale, sigma[NK2D_MAX_SHIFTS];
+    double* PJ;    // Jacobian planes, natural layout [nt][6][nz][ny]  (L, S, C, N, U, d uptake / d po4)
     double* SINV;  // [tc][nb][m][m]
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
     double* PINV;  // inverted pivot blocks [tc][NB][NB]
@@ -42,17 +45,61 @@ struct Precond {
 };
 
 // planes index
-enum { PL_L = 0, PL_S = 1, PL_C = 2, PL_N = 3, PL_U = 4 };
+enum { PL_L = 0, PL_S = 1, PL_C = 2, PL_N = 3, PL_U = 4, PL_UPR = 5, PL_COUNT = 6 };
 
 struct PcDev {
-    int m, nb, nz, ny, nt, tc;
+    int m, nb, nz, ny, nt, tc, mode, kind, E;
     const double* PJ;
+    const double* DZR;   // packed depth.delta_r
     double dt;
+    double scale, sigma[NK2D_MAX_SHIFTS];
     double surf[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS];
+    double ph_sig, ph_rd, ph_rp, ph_vs;
 };
 
 __device__ __forceinline__ double pj(const PcDev& P, int tau, int pl, int k, int j) {
-    return P.PJ[(((size_t)tau * 5 + pl) * P.nz + k) * P.ny + j];
+    return P.PJ[(((size_t)tau * PL_COUNT + pl) * P.nz + k) * P.ny + j];
+}
+
+__device__ __forceinline__ double dzr_at(const PcDev& P, int k) { return P.DZR[(size_t)(k % P.E) * 64 + k / P.E]; }
+
+// coupling of unknown (slot, k) of block j to the same unknown of block j-1 (lat_l) and of
+// unknown (slot, k) of block j to block j+1 (lat_u): mode 0 blocks hold I - dt J at time level
+// `slot`, mode 1 blocks hold scale J (one set of planes) for tracer `slot`
+__device__ __forceinline__ double lat_l(const PcDev& P, int slot, int k, int j) {
+    return (P.mode == 0) ? -(P.dt * pj(P, slot, PL_S, k, j)) : P.scale * pj(P, 0, PL_S, k, j);
+}
+__device__ __forceinline__ double lat_u(const PcDev& P, int slot, int k, int j) {
+    return (P.mode == 0) ? -(P.dt * pj(P, slot, PL_N, k, j)) : P.scale * pj(P, 0, PL_N, k, j);
+}
+
+// diagonal block of the shifted system scale J - sigma I at column j: rows / columns are
+// (tracer, level); tracers couple through the phosphorus terms only (phosphorus.py:119-170)
+__device__ __forceinline__ double shifted_entry(const PcDev& P, int sys, int j, int trr, int k, int trc, int kc) {
+    if (trr == trc) {
+        if (kc == k) {
+            double d = pj(P, 0, PL_C, k, j) - P.decay[trr];
+            if (k == 0) d = d - P.surf[trr];
+            if (P.kind == 1) {
+                if (trr == 0) d = d - pj(P, 0, PL_UPR, k, j);
+                else if (trr == 1) d = d - P.ph_rd;
+                else d = d - (P.ph_rp + ((k < P.nz - 1) ? P.ph_vs * dzr_at(P, k) : 0.0));
+            }
+            return P.scale * d - P.sigma[sys];
+        }
+        if (kc == k - 1) {
+            double lo = pj(P, 0, PL_L, k, j);
+            if (P.kind == 1 && trr == 2) lo = lo + P.ph_vs * dzr_at(P, k);
+            return P.scale * lo;
+        }
+        if (kc == k + 1) return P.scale * pj(P, 0, PL_U, k, j);
+        return 0.0;
+    }
+    if (P.kind == 1 && kc == k) {
+        if (trr == 0) return P.scale * ((trc == 1) ? P.ph_rd : P.ph_rp);
+        if (trc == 0) return P.scale * (((trr == 1) ? P.ph_sig : 1.0 - P.ph_sig) * pj(P, 0, PL_UPR, k, j));
+    }
+    return 0.0;
 }
 
 // S_j = D_j - diag(l_j) Sinv_{j-1} diag(u_{j-1});  one thread per entry (r, c)
@@ -64,7 +111,9 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
     const int tau = r / P.nz, k = r - tau * P.nz;
     const int tc_ = c / P.nz, kc = c - tc_ * P.nz;
     double val = 0.0;
-    if (tc_ == tau) {
+    if (P.mode == 1) {
+        val = shifted_entry(P, tr, j, tau, k, tc_, kc);
+    } else if (tc_ == tau) {
         if (kc == k) {
             double jc = pj(P, tau, PL_C, k, j) - P.decay[tr];
             if (k == 0) jc = jc - P.surf[tr];
@@ -79,8 +128,8 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
     }
     if (sinv_prev) {
         // l_j[r] = -dt JS[tau][k][j] (coupling to column j-1), u_{j-1}[c] = -dt JN[tc_][kc][j-1]
-        const double l = -(P.dt * pj(P, tau, PL_S, k, j));
-        const double u = -(P.dt * pj(P, tc_, PL_N, kc, j - 1));
+        const double l = lat_l(P, tau, k, j);
+        const double u = lat_u(P, tc_, kc, j - 1);
         val = val - (l * sinv_prev[((size_t)tr * P.nb * P.m + r) * P.m + c]) * u;
     }
     out[((size_t)tr * P.m + r) * P.m + c] = val;
@@ -212,7 +261,7 @@ __global__ void k_pc_gemv(PcDev P, int mode, int j, const double* __restrict__ M
         double x = av[c];
         if (mode == 1 && bv) {
             const int tc_ = c / P.nz, kc = c - tc_ * P.nz;
-            const double u = -(P.dt * pj(P, tc_, PL_N, kc, j));
+            const double u = lat_u(P, tc_, kc, j);
             x = x - u * bv[c];
         }
         acc = __builtin_fma(row[c], x, acc);
@@ -222,7 +271,7 @@ __global__ void k_pc_gemv(PcDev P, int mode, int j, const double* __restrict__ M
         double res = acc;
         if (mode == 0) {
             const int tau = r / P.nz, k = r - tau * P.nz;
-            const double l = -(P.dt * pj(P, tau, PL_S, k, j));
+            const double l = lat_l(P, tau, k, j);
             res = rhs[(size_t)tr * v_tr_stride + r] - l * acc;
         }
         out[(size_t)tr * v_tr_stride + r] = res;
@@ -267,9 +316,47 @@ __global__ void k_pc_result(int ncol, int ny, int nz, int m, const double* __res
     store_col<E>(out, task, lane, vv);
 }
 
+// shifted systems: block j of the right-hand side holds every tracer of ypos column j
+template <int E>
+__global__ void k_pc_rhs_all(int ncol, int ny, int nz, int m, const double* __restrict__ v, double* __restrict__ rhs) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int tr = task / ny, j = task - tr * ny;
+    double vv[E];
+    load_col<E>(v, task, lane, vv);
+    double* dst = rhs + (size_t)j * m + (size_t)tr * nz;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        if (k < nz) dst[k] = vv[e];
+    }
+}
+
+template <int E>
+__global__ void k_pc_result_all(int ncol, int ny, int nz, int m, const double* __restrict__ x, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (task >= ncol) return;
+    const int tr = task / ny, j = task - tr * ny;
+    const double* src = x + (size_t)j * m + (size_t)tr * nz;
+    double vv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        vv[e] = (k < nz) ? src[k] : 0.0;
+    }
+    store_col<E>(out, task, lane, vv);
+}
+
 PcDev make_pcdev(const nk2d_ctx* c, const Precond* pc) {
     PcDev P;
     P.m = pc->m; P.nb = pc->nb; P.nz = c->nz; P.ny = c->ny; P.nt = pc->nt; P.tc = c->tc;
+    P.mode = pc->mode; P.kind = c->kind; P.E = c->E; P.DZR = c->DZR;
+    P.scale = pc->scale;
+    for (int i = 0; i < NK2D_MAX_SHIFTS; ++i) P.sigma[i] = pc->sigma[i];
+    P.ph_sig = c->d.phos_params[2]; P.ph_rd = c->d.phos_params[3]; P.ph_rp = c->d.phos_params[4];
+    P.ph_vs = c->d.phos_params[5];
     P.PJ = pc->PJ; P.dt = pc->dt;
     for (int i = 0; i < NK2D_MAX_TRACERS; ++i) { P.surf[i] = c->d.surf_rate[i]; P.decay[i] = c->d.decay_rate[i]; }
     return P;
@@ -287,59 +374,71 @@ void nk2d_precond_free(nk2d_ctx* c) {
     c->precond = nullptr;
 }
 
-extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
-    NK2D_CHECK(c, hipSetDevice(c->dev));
-    if (c->kind != 0) return nk2d_fail(c, "nk2d_precond_setup: only the linear modules (iage, forced) have a device preconditioner");
+namespace {
+
+// allocate for `nsys` systems of block size m = nslot * nz, load the Jacobian planes at the
+// `nt` times and run the block elimination (Schur complements + their explicit inverses)
+int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const double* times, const double* ylin) {
     nk2d_precond_free(c);
     Precond* pc = new Precond();
     c->precond = pc;
-    pc->nt = 3;
+    pc->mode = mode;
+    pc->nsys = nsys;
+    pc->nt = nt;
     pc->nz = c->nz;
     pc->tc = c->tc;
-    pc->m = pc->nt * c->nz;
+    pc->m = nslot * c->nz;
     pc->nb = c->ny;
-    pc->dt = (c->d.t1 - c->d.t0) / pc->nt;
+    pc->dt = (c->d.t1 - c->d.t0) / 3;
+    pc->scale = 0.0;
+    for (int i = 0; i < NK2D_MAX_SHIFTS; ++i) pc->sigma[i] = 0.0;
     pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->PINV = pc->ROWS = nullptr;
     const size_t P = (size_t)c->nz * c->ny, mm = (size_t)pc->m * pc->m;
-    NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * 5 * P));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * c->tc * pc->nb * mm));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * c->tc * mm));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * c->tc * PC_NB * PC_NB));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * c->tc * PC_NB * pc->m));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * c->tc * pc->nb * pc->m));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * c->tc * pc->nb * pc->m));
-    // Jacobian planes at the three mid-interval times (iage.py:85-89)
+    NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * PL_COUNT * P));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * nsys * pc->nb * mm));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * nsys * mm));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * nsys * PC_NB * PC_NB));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * nsys * PC_NB * pc->m));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * nsys * pc->nb * pc->m));
+    NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * nsys * pc->nb * pc->m));
     for (int tau = 0; tau < pc->nt; ++tau) {
-        const double t = c->d.t0 + (tau + 0.5) * pc->dt;
+        double t = times[tau];
         double* out[1] = {c->KV[4]};
         NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
-        NK2D_TRY(nk2d_k_jac(c, c->KV[4], nullptr));
-        const double* planes[5] = {c->JL, c->JS, c->JC, c->JN, c->JU};
-        for (int pl = 0; pl < 5; ++pl)
-            NK2D_TRY(nk2d_k_unpack_plane(c, planes[pl], c->nz, c->ny, pc->PJ + ((size_t)tau * 5 + pl) * P));
+        NK2D_TRY(nk2d_k_jac(c, c->KV[4], ylin));
+        const double* planes[PL_COUNT] = {c->JL, c->JS, c->JC, c->JN, c->JU, c->UPR};
+        for (int pl = 0; pl < PL_COUNT; ++pl)
+            NK2D_TRY(nk2d_k_unpack_plane(c, planes[pl], c->nz, c->ny, pc->PJ + ((size_t)tau * PL_COUNT + pl) * P));
     }
+    return 0;
+}
+
+int precond_eliminate(nk2d_ctx* c) {
+    Precond* pc = (Precond*)c->precond;
+    const int nsys = pc->nsys;
+    const size_t mm = (size_t)pc->m * pc->m;
     PcDev D = make_pcdev(c, pc);
     const int m = pc->m;
-    const dim3 blk(256), grd((m + 255) / 256, m, c->tc);
+    const dim3 blk(256), grd((m + 255) / 256, m, nsys);
     for (int j = 0; j < pc->nb; ++j) {
         const double* prev = (j > 0) ? pc->SINV + (size_t)(j - 1) * mm : nullptr;
-        // SINV is [tc][nb][m][m]: the kernel adds the tracer stride itself
+        // SINV is [nsys][nb][m][m]: the kernel adds the system stride itself
         hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, c->stream, D, j, prev, pc->BUF);
         int src = 0;
         for (int p0 = 0; p0 < m; p0 += PC_NB) {
             const int nbk = std::min(PC_NB, m - p0);
-            const double* from = pc->BUF + (size_t)src * c->tc * mm;
-            double* to = pc->BUF + (size_t)(1 - src) * c->tc * mm;
-            hipLaunchKernelGGL(k_pc_gj_pivot, dim3(c->tc), dim3(PC_NB, PC_NB), 0, c->stream, m, p0, nbk, from, pc->PINV);
-            hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, c->tc), dim3(256), 0, c->stream, m, p0, nbk, from,
+            const double* from = pc->BUF + (size_t)src * nsys * mm;
+            double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
+            hipLaunchKernelGGL(k_pc_gj_pivot, dim3(nsys), dim3(PC_NB, PC_NB), 0, c->stream, m, p0, nbk, from, pc->PINV);
+            hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, c->stream, m, p0, nbk, from,
                                pc->PINV, pc->ROWS);
-            hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, c->tc), dim3(256), 0, c->stream, m, p0,
+            hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream, m, p0,
                                nbk, from, pc->ROWS, to);
             src = 1 - src;
         }
-        for (int tr = 0; tr < c->tc; ++tr)
-            NK2D_CHECK(c, hipMemcpyAsync(pc->SINV + ((size_t)tr * pc->nb + j) * mm,
-                                         pc->BUF + ((size_t)src * c->tc + tr) * mm, sizeof(double) * mm,
+        for (int sys = 0; sys < nsys; ++sys)
+            NK2D_CHECK(c, hipMemcpyAsync(pc->SINV + ((size_t)sys * pc->nb + j) * mm,
+                                         pc->BUF + ((size_t)src * nsys + sys) * mm, sizeof(double) * mm,
                                          hipMemcpyDeviceToDevice, c->stream));
         NK2D_CHECK(c, hipGetLastError());
     }
@@ -347,32 +446,88 @@ extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
     return 0;
 }
 
-extern "C" int nk2d_precond_apply(nk2d_ctx* c, nk2d_vec v, nk2d_vec out) {
-    NK2D_CHECK(c, hipSetDevice(c->dev));
+// block forward / backward substitution of systems [sys0, sys0 + nsys) with the right-hand
+// sides already in XV; the solutions end up in XV
+int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     Precond* pc = (Precond*)c->precond;
-    if (!pc) return nk2d_fail(c, "nk2d_precond_apply: call nk2d_precond_setup first");
     PcDev D = make_pcdev(c, pc);
     const int m = pc->m, nb = pc->nb;
     const size_t mm = (size_t)m * m;
-    const size_t mstride = (size_t)nb * mm;      // tracer stride inside SINV
-    const size_t vstride = (size_t)nb * m;       // tracer stride inside YV / XV
+    const size_t mstride = (size_t)nb * mm;      // system stride inside SINV
+    const size_t vstride = (size_t)nb * m;       // system stride inside YV / XV
+    const double* sinv = pc->SINV + (size_t)sys0 * mstride;
+    double* yv = pc->YV + (size_t)sys0 * vstride;
+    double* xv = pc->XV + (size_t)sys0 * vstride;
+    const dim3 blk(256), grd((m + 3) / 4, nsys);
+    // y_0 = r_0
+    for (int sys = 0; sys < nsys; ++sys)
+        NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
+                                     hipMemcpyDeviceToDevice, c->stream));
+    for (int j = 1; j < nb; ++j)
+        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
+                           yv + (size_t)(j - 1) * m, (const double*)nullptr, xv + (size_t)j * m, vstride,
+                           yv + (size_t)j * m);
+    // backward: x_j = Sinv_j (y_j - U_j x_{j+1})
+    for (int j = nb - 1; j >= 0; --j)
+        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
+                           yv + (size_t)j * m, (j < nb - 1) ? xv + (size_t)(j + 1) * m : (const double*)nullptr,
+                           (const double*)nullptr, vstride, xv + (size_t)j * m);
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->kind != 0) return nk2d_fail(c, "nk2d_precond_setup: state dependent modules use nk2d_shift_factor / nk2d_shift_solve");
+    // Jacobian planes at the three mid-interval times (iage.py:85-89)
+    const double dt = (c->d.t1 - c->d.t0) / 3;
+    const double times[3] = {c->d.t0 + 0.5 * dt, c->d.t0 + 1.5 * dt, c->d.t0 + 2.5 * dt};
+    NK2D_TRY(precond_build(c, 0, 3, 3, c->tc, times, nullptr));
+    return precond_eliminate(c);
+}
+
+// A_i = scale * J(t, lin_state) - shifts[i] * I, all tracers of the module in one system
+extern "C" int nk2d_shift_factor(nk2d_ctx* c, double t, double scale, int32_t nshift, const double* shifts) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (nshift < 1 || nshift > NK2D_MAX_SHIFTS) return nk2d_fail(c, "nk2d_shift_factor: 1 <= nshift <= NK2D_MAX_SHIFTS");
+    const double* ylin = nullptr;
+    if (c->kind == 1) {
+        if (!c->ylin_set) return nk2d_fail(c, "nk2d_shift_factor: call nk2d_set_lin_state first");
+        ylin = c->YLIN;
+    }
+    NK2D_TRY(precond_build(c, 1, 1, c->tc, nshift, &t, ylin));
+    Precond* pc = (Precond*)c->precond;
+    pc->scale = scale;
+    for (int i = 0; i < nshift; ++i) pc->sigma[i] = shifts[i];
+    return precond_eliminate(c);
+}
+
+extern "C" int nk2d_shift_solve(nk2d_ctx* c, int32_t i, nk2d_vec v, nk2d_vec out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    Precond* pc = (Precond*)c->precond;
+    if (!pc || pc->mode != 1) return nk2d_fail(c, "nk2d_shift_solve: call nk2d_shift_factor first");
+    if (i < 0 || i >= pc->nsys) return nk2d_fail(c, "nk2d_shift_solve: no such system");
+    const size_t vstride = (size_t)pc->nb * pc->m;
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                              c->ncol, c->ny, c->nz, pc->m, (const double*)v, pc->XV + (size_t)i * vstride));
+    NK2D_TRY(precond_substitute(c, i, 1));
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                              c->ncol, c->ny, c->nz, pc->m, pc->XV + (size_t)i * vstride, (double*)out));
+    NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int nk2d_precond_apply(nk2d_ctx* c, nk2d_vec v, nk2d_vec out) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    Precond* pc = (Precond*)c->precond;
+    if (!pc || pc->mode != 0) return nk2d_fail(c, "nk2d_precond_apply: call nk2d_precond_setup first");
+    const int m = pc->m;
     // right-hand sides into XV (used as r_j), forward sweep writes YV
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
                                               c->ny, c->nz, m, (const double*)v, pc->XV));
-    const dim3 blk(256), grd((m + 3) / 4, c->tc);
-    // y_0 = r_0
-    for (int tr = 0; tr < c->tc; ++tr)
-        NK2D_CHECK(c, hipMemcpyAsync(pc->YV + (size_t)tr * vstride, pc->XV + (size_t)tr * vstride, sizeof(double) * m,
-                                     hipMemcpyDeviceToDevice, c->stream));
-    for (int j = 1; j < nb; ++j)
-        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, pc->SINV + (size_t)(j - 1) * mm, mstride,
-                           pc->YV + (size_t)(j - 1) * m, (const double*)nullptr, pc->XV + (size_t)j * m, vstride,
-                           pc->YV + (size_t)j * m);
-    // backward: x_j = Sinv_j (y_j - U_j x_{j+1})
-    for (int j = nb - 1; j >= 0; --j)
-        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, pc->SINV + (size_t)j * mm, mstride,
-                           pc->YV + (size_t)j * m, (j < nb - 1) ? pc->XV + (size_t)(j + 1) * m : (const double*)nullptr,
-                           (const double*)nullptr, vstride, pc->XV + (size_t)j * m);
+    NK2D_TRY(precond_substitute(c, 0, pc->nsys));
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                               c->ncol, c->ny, c->nz, m, (const double*)v, pc->XV, (double*)out));
     NK2D_CHECK(c, hipGetLastError());

@@ -245,7 +245,29 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_precond_setup(self._ctx))
         self._precond_ready = True
 
+    def shift_factor(self, t, scale, shifts):
+        """factorise scale * J(t, lin_state) - shift * I for every shift (block elimination)"""
+        arr = np.ascontiguousarray(shifts, dtype=np.float64)
+        self._chk(self._lib.nk2d_shift_factor(self._ctx, float(t), float(scale), len(arr), _dp(arr)))
+        self._precond_ready = False
+
+    def shift_solve(self, i, v, out=None):
+        out = self.new_vec() if out is None else out
+        self._chk(self._lib.nk2d_shift_solve(self._ctx, int(i), v.ptr, out.ptr))
+        return out
+
+    def precond_setup_state(self, po4, time_range=(0.0, YEAR)):
+        """state dependent preconditioner (phosphorus): linearise about the given po4 field"""
+        from .phosphorus import PhosphorusPrecond
+
+        self._state_precond = PhosphorusPrecond(self, po4, time_range)
+        return self._state_precond
+
     def precond_apply(self, v, out=None):
+        if self.module_kind == 1:
+            if getattr(self, "_state_precond", None) is None:
+                raise Nk2dError("phosphorus preconditioner: call precond_setup_state(po4) first")
+            return self._state_precond.apply(v, out=out)
         if not self._precond_ready:
             self.precond_setup()
         out = self.new_vec() if out is None else out

@@ -488,3 +488,56 @@ def gen_init_iterate(model, knots_z=(55.0, 200.0), knots_v=(0.0, 2.0), tc=2):
     col = np.interp(model.depth.mid, knots_z, knots_v)
     one = np.broadcast_to(col[:, np.newaxis], (model.nz, model.ny))
     return np.stack([one] * tc).copy()
+
+
+def phosphorus_precond_matrix(module, po4, time_range=(0.0, YEAR)):
+    """mat of `phosphorus.apply_precond_jacobian` (phosphorus.py:208-230) for time_n = 1:
+    mat = I - (I - T J(T/2, po4)) with only po4 non-zero in the linearisation state"""
+    m = module.model
+    vals = np.zeros((module.tc, m.nz, m.ny))
+    vals[0] = po4
+    n = vals.size
+    time_delta = time_range[1] - time_range[0]
+    time_mid = time_range[0] + 0.5 * time_delta
+    mat_id = sparse.identity(n)
+    mat = mat_id * (mat_id - time_delta * module.comp_jacobian(time_mid, vals.reshape(-1)))
+    return (mat_id - mat).tocsc()
+
+
+def phosphorus_small_eigs(mat, sigma, k=5, v0=None):
+    """`sp_linalg.eigs(mat, k=5, sigma=...)` sorted by magnitude.  The reference passes
+    sigma=0.0 (phosphorus.py:239), i.e. shift-invert about an eigenvalue of the singular mat;
+    a small positive sigma keeps the inner LU well conditioned."""
+    e_vals, e_vects = sp_linalg.eigs(mat, k=k, sigma=sigma, v0=v0)
+    order = np.argsort(np.abs(e_vals))
+    return e_vals[order], e_vects[:, order]
+
+
+def apply_precond_phosphorus(module, regions, po4, v, time_range=(0.0, YEAR), eig_sigma=0.02, shift=None):
+    """restatement of `phosphorus.apply_precond_jacobian` (phosphorus.py:197-274): shifted
+    double solve extrapolated to zero shift, then removal of the null-space component so that
+    the (region weighted, summed over tracers) mean of the solution is zero.  `eig_sigma=0.0`
+    reproduces the reference's eigs call, the default evaluates the same eigen-pair with a
+    non-singular shift-invert.  Returns (result, e_vals, shift)."""
+    mat = phosphorus_precond_matrix(module, po4, time_range)
+    n = mat.shape[0]
+    mat_id = sparse.identity(n, format="csc")
+    e_vals, e_vects = phosphorus_small_eigs(mat, eig_sigma)
+    null_comp = e_vects[:, 0]
+    if max(abs(null_comp.imag)) > 1.0e-10 * max(abs(null_comp.real)):
+        raise RuntimeError("1st eigenvector has non-trivial imaginary part")
+    null_vect = null_comp.real
+    if shift is None:
+        shift = 0.5 * e_vals[1].real
+    solve_tmp = sp_linalg.spsolve(mat - shift * mat_id, v)
+    solve_vals = sp_linalg.spsolve(mat - (0.5 * shift) * mat_id, v)
+    solve_vals = 2.0 * solve_vals - solve_tmp
+
+    def mean(x):  # TracerModuleStateBase.mean: summed over the module's tracers
+        return sum(regions.mean_of(plane) for plane in x.reshape(module.tc, -1))
+
+    mask = regions.mask.reshape(-1)
+    e_vect = null_vect.reshape(module.tc, -1) / regions.bcast(mean(null_vect)).reshape(-1)
+    sol = solve_vals.reshape(module.tc, -1) - regions.bcast(mean(solve_vals)).reshape(-1) * e_vect
+    sol = np.where(mask != 0, sol, solve_vals.reshape(module.tc, -1))
+    return sol.reshape(-1) - v, e_vals, shift

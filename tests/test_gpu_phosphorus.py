@@ -76,3 +76,39 @@ def test_phosphorus_comp_fcn(golden_dir):
     fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]))
     assert np.allclose(eng.download(fx).reshape(-1), g["fcn"], rtol=1e-3, atol=1e-6)
     assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
+
+
+@pytest.mark.parametrize("tag", ["22x9", "70x12"])
+def test_phosphorus_preconditioner(golden_dir, tag):
+    """shifted block solves, the eigen-pair from subspace inverse iteration on the device
+    solver, and the assembled preconditioner against the oracle (sparse direct + ARPACK)"""
+    from oracle.krylov import Regions
+    from oracle.model import apply_precond_phosphorus, phosphorus_precond_matrix
+
+    g, eng, tm = _setup(golden_dir, tag)
+    nz, ny = int(g["nz"]), int(g["ny"])
+    depth, ypos = default_axes(nz, ny)
+    weight = np.outer(depth.delta, ypos.delta)
+    mask = np.ones((nz, ny), dtype=np.int32)
+    eng.set_region(mask, weight)
+    po4 = g["y"].reshape(3, nz, ny)[0]
+    mat = phosphorus_precond_matrix(tm, po4)
+    n = mat.shape[0]
+    rng = np.random.default_rng(21)
+    v = rng.standard_normal(n)
+    # one shifted system, both signs of the shift
+    ylin = np.zeros((3, nz, ny))
+    ylin[0] = po4
+    eng.set_lin_state(eng.upload(ylin))
+    eng.shift_factor(0.5 * YEAR, YEAR, [0.02, -0.03])
+    for i, sigma in enumerate([0.02, -0.03]):
+        want = spsolve((mat - sigma * identity(n, format="csc")).tocsc(), v)
+        got = eng.download(eng.shift_solve(i, eng.upload(v))).reshape(-1)
+        assert rel_err(got, want) < 1e-8
+    pc = eng.precond_setup_state(po4)
+    want, e_vals, shift = apply_precond_phosphorus(tm, Regions(mask, weight), po4, v)
+    assert abs(pc.e_vals[0]) < 1e-9
+    assert abs(pc.e_vals[1].real - e_vals[1].real) < 1e-8 * abs(e_vals[1].real)
+    assert abs(pc.shift - shift) < 1e-8 * abs(shift)
+    got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert rel_err(got, want) < 1e-6
