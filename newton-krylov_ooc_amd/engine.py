@@ -99,6 +99,8 @@ class ModuleEngine:
             desc.light_lim = _dp(keep[-1])
             desc.phos_params = (ctypes.c_double * 6)(*[float(v) for v in phos_params])
         self.module_kind = int(module_kind)
+        self.light_lim = keep[-1] if module_kind == 1 else None
+        self.phos = dict(zip(PHOSPHORUS_PARAM_NAMES, phos_params)) if module_kind == 1 else None
         ctx = ctypes.c_void_p()
         rc = self._lib.nk2d_create(ctypes.byref(desc), ctypes.byref(ctx))
         if rc != 0:
@@ -256,6 +258,11 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_shift_solve(self._ctx, int(i), v.ptr, out.ptr))
         return out
 
+    def po4_uptake(self, po4):
+        """host evaluation of the uptake history variable (phosphorus.py:90-95)"""
+        prm = self.phos
+        return prm["max_uptake_rate"] * self.light_lim * (po4 / (po4 + prm["po4_halfsat"]))
+
     def precond_setup_state(self, po4, time_range=(0.0, YEAR)):
         """state dependent preconditioner (phosphorus): linearise about the given po4 field"""
         from .phosphorus import PhosphorusPrecond
@@ -373,8 +380,32 @@ def phosphorus_params(overrides=None):
     for name, val in (overrides or {}).items():
         if name not in params:
             raise ValueError(f"unknown phosphorus parameter {name}")
-        params[name] = float(val)
+        params[name] = _eval_number(val)
     return params
+
+
+def _eval_number(expr):
+    """value of a number or of an arithmetic expression string such as "1.0 / (3.0 * 86400.0)"
+    (the reference evaluates modelinfo parameters with utils.eval_expr)"""
+    if not isinstance(expr, str):
+        return float(expr)
+    import ast
+    import operator
+
+    ops = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul,
+           ast.Div: operator.truediv, ast.Pow: operator.pow}
+
+    def walk(node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            return float(node.value)
+        if isinstance(node, ast.BinOp) and type(node.op) in ops:
+            return ops[type(node.op)](walk(node.left), walk(node.right))
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            val = walk(node.operand)
+            return -val if isinstance(node.op, ast.USub) else val
+        raise ValueError(f"unsupported expression {expr!r}")
+
+    return walk(ast.parse(expr, mode="eval").body)
 
 
 def phosphorus_light_lim(grid):

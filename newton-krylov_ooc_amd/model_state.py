@@ -23,7 +23,8 @@ import numpy as np
 
 from . import hist as hist_mod
 from . import ncio
-from .engine import ModuleEngine, forced_engine, iage_engine
+from .engine import (PHOSPHORUS_PARAM_NAMES, ModuleEngine, forced_engine, iage_engine,
+                     phosphorus_engine)
 from .grid import Grid2d, SpatialAxis
 
 YEAR = 365.0 * 86400.0
@@ -172,6 +173,9 @@ def _module_engine(name, module_def, grid, device_id, modelinfo):
         return iage_engine(grid, device_id=device_id, **kwargs)
     if py_mod_name == "forced":
         return forced_engine(grid, modelinfo, device_id=device_id, **kwargs)
+    if py_mod_name == "phosphorus":
+        params = {key: modelinfo[key] for key in PHOSPHORUS_PARAM_NAMES if key in modelinfo}
+        return phosphorus_engine(grid, params, device_id=device_id, **kwargs)
     raise NotImplementedError(
         f"tracer module {name} (py_mod_name={py_mod_name}) has no HIP engine yet")
 
@@ -188,6 +192,8 @@ class ModelState:
     _engines = None
     _grid = None
     _resident = {}
+    _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
+    _precond_state = {}     # precond file -> {module name: linearisation field}
     last_stats = None       # stats of the most recent comp_fcn, per module
 
     # ---- class-level set-up (py_driver_2d/model_state.py:44-65) -----------------------
@@ -199,6 +205,8 @@ class ModelState:
         cls._engines = None
         cls._grid = None
         cls._resident = {}
+        cls._hist_end = {}
+        cls._precond_state = {}
         cls.model_config_obj = None
 
     @classmethod
@@ -430,6 +438,14 @@ class ModelState:
                 fx, st, hist = tms.eng.comp_fcn_hist(tms.vec, t_eval)
                 tracers = {name: dict(meta.get("attrs", {}))
                            for name, meta in tms._tracer_module_def["tracers"].items()}
+                if tms.eng.module_kind == 1:
+                    # tracer-like history variable of the module (phosphorus.py:174-195) and the
+                    # end-of-year po4 its preconditioner linearises about
+                    po4_units = tracers["po4"].get("units", "1")
+                    tracers["po4_uptake"] = {"long_name": "uptake of po4", "units": f"{po4_units} / s"}
+                    uptake = tms.eng.po4_uptake(hist[:, 0])
+                    hist = np.concatenate((hist, uptake[:, np.newaxis]), axis=1)
+                    type(self)._hist_end.setdefault(os.path.abspath(hist_fname), {})[tms.name] = hist[-1, 0].copy()
                 hists.append((tracers, hist))
             mods.append(tms._like(fx))
             stats.append(st)
@@ -480,6 +496,10 @@ class ModelState:
         step = f"ModelStateBase.gen_precond_jacobian {precond_fname}"
         if solver_state is not None and solver_state.step_logged(step, per_iteration=False):
             return
+        if hist_fname is not None:
+            ends = self._hist_end.get(os.path.abspath(hist_fname))
+            if ends:
+                type(self)._precond_state[os.path.abspath(precond_fname)] = dict(ends)
         if self.write_files:
             time_attrs = {"long_name": "time", "units": "seconds since 0001-01-01", "calendar": "noleap"}
             dims, variables = {}, {}
@@ -518,10 +538,37 @@ class ModelState:
         if solver_state is not None and solver_state.step_logged(fcn_complete_step):
             logger.debug('"%s" logged, returning result', fcn_complete_step)
             return type(self)(res_fname)
+        for tms in self.tracer_modules:
+            if tms.eng.module_kind == 1:
+                self._ensure_state_precond(tms, precond_fname)
         res_ms = self._new([tms._like(tms.eng.precond_apply(tms.vec)) for tms in self.tracer_modules])
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
         return res_ms.dump(res_fname, f"{_class_name(self)}.apply_precond_jacobian")
+
+    def _ensure_state_precond(self, tms, precond_fname):
+        """factorise the state dependent (phosphorus) preconditioner of `precond_fname` once; the
+        reference redoes its eigs + two sparse LU for every application (phosphorus.py:197-274)"""
+        key = os.path.abspath(precond_fname)
+        if getattr(tms.eng, "_state_precond_key", None) == key:
+            return
+        field = self._precond_state.get(key, {}).get(tms.name)
+        if field is None:
+            # resumed run: po4 at the sample closest to the end of the year (phosphorus.py:222-224)
+            data, _ = ncio.read_file(precond_fname, ["time", "po4"])
+            field = data["po4"][np.argmin(abs(self.time_range[1] - data["time"]))]
+        pc = tms.eng.precond_setup_state(field, self.time_range)
+        tms.eng._state_precond_key = key
+        logger = logging.getLogger(__name__)
+        for ind, val in enumerate(pc.e_vals[:5]):
+            logger.info("small e_val[%d] = %e + %e j", ind, val.real, val.imag)
+        if self.write_files:
+            # null vector scaled to unit mean, as the reference leaves it next to the precond file
+            e_vect = tms.eng.download(pc.e_hat)
+            tracer_vals = {name: e_vect[ind] for ind, name in enumerate(tms.tracer_names)}
+            ncio.write_state_file(os.path.join(os.path.dirname(key), "precond_null_space.nc"),
+                                  [self.depth, self.ypos], tracer_vals,
+                                  ncio.history_stamp(f"{_class_name(self)}.apply_precond_jacobian"))
 
     # ---- finite-difference Jacobian-vector product ---------------------------------------------------------
     def comp_jacobian_fcn_state_prod(self, fcn, direction, res_fname, solver_state):

@@ -90,6 +90,11 @@ class OracleModule:
     def apply_precond(self, v):
         if self.precond_kind == "reference":
             return self.tm.apply_precond(v)
+        if self.precond_kind == "phosphorus":
+            # self.precond_po4: po4 at the end of the iterate's forward year (set by the caller)
+            from .model import apply_precond_phosphorus
+
+            return apply_precond_phosphorus(self.tm, self.reg, self.precond_po4, v)[0]
         from .model import apply_precond_stable
 
         return apply_precond_stable(self.tm, v)

@@ -112,3 +112,87 @@ def test_phosphorus_preconditioner(golden_dir, tag):
     assert abs(pc.shift - shift) < 1e-8 * abs(shift)
     got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
     assert rel_err(got, want) < 1e-6
+
+
+def test_phosphorus_krylov_solve(tmp_path):
+    """tracer_module_names = phosphorus through the solver mirrors: forward year with history,
+    preconditioner from the end-of-year po4, GMRES iterations; compared with the oracle"""
+    import os
+
+    from nk_ooc_amd import ncio
+    from nk_ooc_amd.krylov_solver import KrylovSolver
+    from nk_ooc_amd.model_config import ModelConfig
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+    from oracle import krylov
+
+    nz, ny = 22, 9
+    work = str(tmp_path)
+    cfg = make_config(work, nz, ny, tracer_module_names="phosphorus",
+                      extra_solverinfo={"krylov_max_iter": "3", "krylov_rel_tol": "1e-9"})
+    gen_grid_vars_file(cfg["modelinfo"])
+    ModelState.reset_class()
+    ModelState.model_config_obj = ModelConfig(cfg["modelinfo"])
+    ModelState.write_files = True
+    iterate = ModelState("gen_init_iterate")
+    assert iterate.tracer_modules[0].tracer_names == ["po4", "dop", "pop"]
+    hist_fname = os.path.join(work, "hist_00.nc")
+    fcn = iterate.comp_fcn(os.path.join(work, "fcn_00.nc"), None, hist_fname)
+    data, _ = ncio.read_file(hist_fname, ["po4", "po4_uptake", "po4_uptake_time_mean"])
+    assert data["po4_uptake"].shape == (61, nz, ny) and np.all(data["po4_uptake"] >= 0.0)
+    solverinfo = dict(cfg["solverinfo"], krylov_workdir=os.path.join(work, "krylov_00"))
+    solver = KrylovSolver(iterate, solverinfo, False, False, hist_fname)
+    solver.solve(os.path.join(work, "increment_00.nc"), fcn)
+    beta = solver._solver_state.get_value_saved_state("beta")
+    h_mat = solver._solver_state.get_value_saved_state("h_mat")
+    assert os.path.exists(os.path.join(work, "krylov_00", "precond_null_space.nc"))
+    # oracle
+    depth, ypos = default_axes(nz, ny)
+    regions = krylov.Regions(np.ones((nz, ny), dtype=np.int32), np.outer(depth.delta, ypos.delta))
+    mod = krylov.OracleModule(Phosphorus(Py2dModel(depth, ypos)), regions, precond="phosphorus")
+    x = [iterate.tracer_modules[0].get_tracer_vals_all().reshape(-1)]
+    f = [mod.comp_fcn(x[0])]
+    assert np.allclose(fcn.tracer_modules[0].get_tracer_vals_all().reshape(-1), f[0], rtol=1e-3, atol=1e-6)
+    mod.precond_po4 = (x[0] + f[0]).reshape(3, nz, ny)[0]
+    assert np.allclose(data["po4"][-1], mod.precond_po4, rtol=1e-3, atol=1e-6)
+    _, trace = krylov.krylov_solve([mod], x, f, rel_tol=1e-9, max_iter=3)
+    assert rel_err(beta, trace["beta"]) < 1e-3
+    assert rel_err(h_mat, trace["h_mat"][-1]) < 5e-2
+    ModelState.reset_class()
+
+
+def test_phosphorus_newton(tmp_path):
+    """Newton-Krylov on the phosphorus module run to convergence through the driver mirror:
+    the converged iterate satisfies the reference's convergence test when F is evaluated by the
+    CPU oracle, and total phosphorus (weighted mean over the three tracers) is conserved"""
+    import os
+
+    from nk_ooc_amd import ncio, nk_driver
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import make_config, setup
+    from oracle import krylov
+
+    nz, ny = 22, 9
+    work = str(tmp_path)
+    cfg = make_config(work, nz, ny, tracer_module_names="phosphorus")
+    ModelState.write_files = True
+    setup(cfg, fp_cnt=1)
+    solver = nk_driver.run(cfg)
+    assert solver.converged().all()
+    assert 1 <= solver.get_iteration() <= 4
+    names = ["po4", "dop", "pop"]
+    read = lambda fname: np.stack([ncio.read_file(fname, names)[0][n] for n in names]).reshape(-1)
+    x0 = read(cfg["solverinfo"]["init_iterate_fname"])
+    x = solver.iterate.tracer_modules[0].get_tracer_vals_all().reshape(-1)
+    depth, ypos = default_axes(nz, ny)
+    regions = krylov.Regions(np.ones((nz, ny), dtype=np.int32), np.outer(depth.delta, ypos.delta))
+    mod = krylov.OracleModule(Phosphorus(Py2dModel(depth, ypos)), regions)
+    total = lambda v: sum(regions.mean_of(p) for p in v.reshape(3, -1))[0]
+    assert abs(total(x) - total(x0)) < 1e-9 * abs(total(x0))
+    f_cpu = mod.comp_fcn(x)
+    fn, xn = np.sqrt(mod.dot(f_cpu, f_cpu)), np.sqrt(mod.dot(x, x))
+    assert np.all(fn < 2.0 * 1.0e-5 * xn), (fn, xn)
+    stats, _ = ncio.read_file(os.path.join(work, "Newton_stats.nc"))
+    for name in ("iterate_norm_phosphorus", "fcn_norm_phosphorus", "Krylov_iterations", "po4", "pop_mean_ypos"):
+        assert name in stats, name
+    ModelState.reset_class()
