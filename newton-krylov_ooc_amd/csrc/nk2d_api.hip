@@ -254,6 +254,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->hist_host = nullptr;
     c->sweep_wpb = 4;
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
+    c->part_on_host = 0;
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
 
@@ -340,6 +342,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
+    if (c->hPART) (void)hipHostFree(c->hPART);
     if (c->hCTL) (void)hipHostFree(c->hCTL);
     if (c->hSNAP) {
         (void)hipHostFree(c->hSNAP);

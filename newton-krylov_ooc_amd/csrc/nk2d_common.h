@@ -83,6 +83,8 @@ struct nk2d_ctx {
     double* PART;    // per-task partials
     double* RED;     // reduced scalars (device)
     double* hRED;    // pinned host mirror
+    double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
+    int part_on_host;
     // staging for host <-> device layout conversion
     double* STAGE;
     size_t stage_elems;

@@ -796,11 +796,30 @@ __global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, 
 }
 
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, c->PART, ntasks, nout, c->RED);
+    if (c->part_on_host && host_out && nout == 1) {
+        // host-controlled integrator: the producing kernel wrote its per-column partials straight
+        // into pinned host memory; summing them here (fixed order) needs no reduction launch
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        // same association as k_reduce (strided partial sums, then a binary tree), so that the host-
+        // and the device-controlled integrators see bit-identical norms
+        double sh[NK2D_BLOCK];
+        for (int t = 0; t < NK2D_BLOCK; ++t) {
+            double acc = 0.0;
+            for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += c->hPART[i];
+            sh[t] = acc;
+        }
+        for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1)
+            for (int t = 0; t < o; ++t) sh[t] += sh[t + o];
+        *host_out = sh[0];
+        return 0;
+    }
+    // a result the host waits for goes straight into the pinned, device-visible host buffer: no
+    // separate device-to-host copy (a blit kernel of its own on this runtime) behind the reduction
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, c->PART, ntasks, nout,
+                       host_out ? c->hRED : c->RED);
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     if (host_out) {
-        NK2D_CHECK(c, hipMemcpyAsync(c->hRED, c->RED, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
         std::memcpy(host_out, c->hRED, sizeof(double) * nout);
     }
@@ -1333,7 +1352,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     A.sw.xr_old = c->XR[src]; A.sw.xcr_old = c->XCR[src]; A.sw.xci_old = c->XCI[src];
     A.sw.xr_new = c->XR[1 - src]; A.sw.xcr_new = c->XCR[1 - src]; A.sw.xci_new = c->XCI[1 - src];
     A.sw.first = first ? 1 : 0;
-    A.part = c->PART;
+    A.part = c->part_on_host ? c->hPART : c->PART;
     A.do_stage = do_stage ? 1 : 0;
     A.do_update = do_update ? 1 : 0;
     DevP P = make_devp(c);
@@ -1389,7 +1408,7 @@ int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
 int nk2d_r_err_norm(nk2d_ctx* c, const double* err) {
     DevP P = make_devp(c);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_norm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
-                                               c->Y, c->Z + 2 * c->nv, err, c->PART));
+                                               c->Y, c->Z + 2 * c->nv, err, c->part_on_host ? c->hPART : c->PART));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
@@ -1397,7 +1416,7 @@ int nk2d_r_err_norm(nk2d_ctx* c, const double* err) {
 int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys) {
     DevP P = make_devp(c);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_wnorm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, a,
-                                               b, ca, cb, ys, c->PART));
+                                               b, ca, cb, ys, c->part_on_host ? c->hPART : c->PART));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;

@@ -470,6 +470,13 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.h_lu = 0; s.dense_t_old = 0; s.dense_h = 0;
     s.m_real = s.m_cplx = 1;
     s.device_ctl = c->device_ctl;
+    // per-column partials go to pinned host memory while the host takes the decisions; the flag is
+    // dropped on every way out of this function
+    struct PartGuard {
+        nk2d_ctx* c;
+        ~PartGuard() { c->part_on_host = 0; }
+    } part_guard{c};
+    c->part_on_host = (s.device_ctl == 0 && !replay) ? 1 : 0;
     NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
     if (s.t1 > s.t) {
         // f = fun(t0, y0);  J = jac(t0, y0)
