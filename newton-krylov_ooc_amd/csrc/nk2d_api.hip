@@ -101,6 +101,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
+    if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "sweep_wpb") {
         const int w = (int)value;
         if (w != 1 && w != 2 && w != 4) return nk2d_fail(c, "nk2d_set_option: sweep_wpb must be 1, 2 or 4");
@@ -256,6 +257,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
     c->part_on_host = 0;
+    c->speculate = 1;
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
 

@@ -85,6 +85,7 @@ struct nk2d_ctx {
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
     int part_on_host;
+    int speculate;   // 1: queue the next Newton iteration's front launches before reading the norm
     // staging for host <-> device layout conversion
     double* STAGE;
     size_t stage_elems;
@@ -407,6 +408,7 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
                  const double* br, const double* bcr, const double* bci, int src);
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci);
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
+int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
 int nk2d_profile_collect(nk2d_ctx* c);

@@ -795,23 +795,27 @@ __global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, 
     }
 }
 
+// sum of the per-column partials the producing kernel wrote into pinned host memory; the caller
+// has waited for that kernel.  Same association as k_reduce (strided partial sums, then a
+// binary tree), so that the host- and the device-controlled integrators see bit-identical norms.
+int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out) {
+    double sh[NK2D_BLOCK];
+    for (int t = 0; t < NK2D_BLOCK; ++t) {
+        double acc = 0.0;
+        for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += c->hPART[i];
+        sh[t] = acc;
+    }
+    for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1)
+        for (int t = 0; t < o; ++t) sh[t] += sh[t + o];
+    *out = sh[0];
+    return 0;
+}
+
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
     if (c->part_on_host && host_out && nout == 1) {
-        // host-controlled integrator: the producing kernel wrote its per-column partials straight
-        // into pinned host memory; summing them here (fixed order) needs no reduction launch
+        // host-controlled integrator: no reduction launch
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-        // same association as k_reduce (strided partial sums, then a binary tree), so that the host-
-        // and the device-controlled integrators see bit-identical norms
-        double sh[NK2D_BLOCK];
-        for (int t = 0; t < NK2D_BLOCK; ++t) {
-            double acc = 0.0;
-            for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += c->hPART[i];
-            sh[t] = acc;
-        }
-        for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1)
-            for (int t = 0; t < o; ++t) sh[t] += sh[t + o];
-        *host_out = sh[0];
-        return 0;
+        return nk2d_part_sum(c, ntasks, host_out);
     }
     // a result the host waits for goes straight into the pinned, device-visible host buffer: no
     // separate device-to-host copy (a blit kernel of its own on this runtime) behind the reduction

@@ -140,9 +140,29 @@ int newton_fixed(Ctl& s, double h, int n_iters) {
     return 0;
 }
 
+// the launches of one simplified-Newton iteration that change nothing the integrator keeps
+// (right-hand sides and ping-pong iterates only): all but the last, which carries the update
+int newton_front(Ctl& s, double mreal, double mcr, double mci) {
+    const int m = std::max(s.m_real, s.m_cplx);
+    int src = 0;
+    for (int it = 0; it + 1 < m; ++it) {
+        NK2D_TRY(nk2d_r_newton_fused(s.c, it == 0, it == 0, false, mreal, mcr, mci, src));
+        src = 1 - src;
+    }
+    return 0;
+}
+int newton_back(Ctl& s, double mreal, double mcr, double mci) {
+    const int m = std::max(s.m_real, s.m_cplx);
+    NK2D_TRY(nk2d_r_newton_fused(s.c, m == 1, m == 1, true, mreal, mcr, mci, (m - 1) & 1));
+    s.c->st.nsolve += 2;
+    return 0;
+}
+
 // simplified Newton iterations on the collocation system (radau.py:48-136), decisions on
-// the host: one scalar read-back per iteration.  force_iters is unused here (replay has
-// newton_fixed) but kept for symmetry.
+// the host: one read-back of the per-column norm partials per iteration.  While the host waits
+// for them the device already runs the front launches of the NEXT iteration; if the iteration
+// stops here they were wasted work on buffers nobody reads.  force_iters is unused here (replay
+// has newton_fixed) but kept for symmetry.
 int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, double* rate_out, bool* have_rate) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
@@ -150,14 +170,28 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     bool has_old = false, has_rate = false;
     *converged = false;
     const int kmax = force_iters >= 0 ? force_iters : NEWTON_MAXITER;
+    const bool speculate = c->part_on_host && force_iters < 0 && c->speculate;
+    bool front_queued = false;
     int k = -1;
     for (k = 0; k < kmax; ++k) {
-        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
+        if (!front_queued) NK2D_TRY(newton_front(s, mreal, mcr, mci));
+        front_queued = false;
+        NK2D_TRY(newton_back(s, mreal, mcr, mci));
         c->st.nfev += 3;
         c->st.nnewton++;
         if (force_iters >= 0) continue;
         double sum = 0.0;
-        NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
+        if (speculate) {
+            NK2D_CHECK(c, hipEventRecord(c->snap_ev[0], c->stream));
+            if (k + 1 < kmax) {
+                NK2D_TRY(newton_front(s, mreal, mcr, mci));
+                front_queued = true;
+            }
+            NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[0]));
+            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum));
+        } else {
+            NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
+        }
         const double dW_norm = rms_from_sum(sum, 3.0 * s.n_total);
         if (!(dW_norm == dW_norm)) break;  // NaN: treat as divergence
         if (has_old) { rate = dW_norm / dW_norm_old; has_rate = true; }

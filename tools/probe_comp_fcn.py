@@ -1,7 +1,8 @@
 """probe: time one forward year on the GPU at several grid sizes (development aid)"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nk_ooc_amd.engine import iage_engine
 from nk_ooc_amd.grid import Grid2d
 
