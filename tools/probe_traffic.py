@@ -1,7 +1,8 @@
 """probe (torch-free) for rocprofv3 --pmc passes: one free-running forward year at n x n"""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nk_ooc_amd.engine import iage_engine
 from nk_ooc_amd.grid import Grid2d
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 416
