@@ -29,6 +29,7 @@ class FakeEngine:
         self.nz, self.ny, self.tc = nz, ny, tc
         self.shape = (tc, nz, ny)
         self.nreg = 1
+        self.module_kind = 0
         rng = np.random.default_rng(seed)
         n = tc * nz * ny
         self.A = 0.3 * rng.standard_normal((n, n)) / np.sqrt(n)
