@@ -30,7 +30,29 @@ def bldepth(grid, time):
 
 
 def _units_product(*units):
-    return " ".join(f"({unit})" for unit in units)
+    """units string of a product in the reference's canonical form (`utils.units_str_format`,
+    nk_ooc/utils.py:189-205, which lets pint multiply the factors): powers of a unit are merged,
+    numerator terms are separated by blanks, every denominator term follows a " / ", e.g.
+    ("years", "m", "m") -> "years m^2", ("mmol / m^3", "m") -> "mmol / m^2"."""
+    powers = {}
+    for unit in units:
+        sign = 1
+        for token in unit.replace("*", " * ").replace("/", " / ").split():
+            if token == "/":
+                sign = -1
+            elif token == "*":
+                sign = 1
+            elif token != "1":
+                name, _, exponent = token.partition("^")
+                # "a / b / c": every term after a slash stays in the denominator
+                powers[name] = powers.get(name, 0) + sign * (int(exponent) if exponent else 1)
+
+    def term(name, power):
+        return name if power == 1 else f"{name}^{power}"
+
+    numer = [term(name, power) for name, power in powers.items() if power > 0]
+    denom = [term(name, -power) for name, power in powers.items() if power < 0]
+    return " / ".join([" ".join(numer) if numer else "1"] + denom)
 
 
 def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):

@@ -59,6 +59,13 @@ def test_newton_column_regions(tmp_path):
         assert np.all(np.isclose(_read_state(os.path.join(workdir, name)),
                                  _read_state(os.path.join(BASE, name)), **kw)), name
 
+    # the reference CI's own check (scripts/ci_py_driver_2d_iage_column_regions.sh): baseline_cmp per file
+    from nk_ooc_amd import baseline_cmp
+
+    for name, rtol, atol in (("iterate_01.nc", 1.9e-2, 2e-9), ("increment_00.nc", 1.9e-2, 2e-9)):
+        assert baseline_cmp.compare(name, workdir, BASE, rtol=rtol, atol=atol), name
+    assert baseline_cmp.compare("hist_0000.nc", gen, BASE, rtol=1.0e-3, atol=1.0e-6)
+
     # Newton_state.json: same schema and the same sequence of checkpointed actions
     got = json.load(open(os.path.join(workdir, "Newton_state.json")))
     want = json.load(open(os.path.join(BASE, "Newton_state.json")))

@@ -128,3 +128,33 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnk2d.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_baseline_cmp(tmp_path):
+    """comparer with the reference's CLI: a reference-written file against itself, against a
+    copy with one value moved beyond / within tolerance, and against a file with other metadata"""
+    import shutil
+    import subprocess
+    import sys
+
+    from scipy.io import netcdf_file
+
+    from nk_ooc_amd import baseline_cmp
+
+    base = os.path.join(os.path.dirname(__file__), "golden", "ref_baselines", "ci_py_driver_2d_iage")
+    assert baseline_cmp.compare("fcn_0000.nc", base, base)
+    work = str(tmp_path)
+    shutil.copy(os.path.join(base, "fcn_0000.nc"), work)
+    with netcdf_file(os.path.join(work, "fcn_0000.nc"), "a") as fptr:
+        vals = fptr.variables["iage"][:].copy()
+        vals[3, 4] = vals[3, 4] * (1.0 + 1.0e-5) + 1.0e-8
+        fptr.variables["iage"][:] = vals
+    assert not baseline_cmp.compare("fcn_0000.nc", work, base)
+    assert baseline_cmp.compare("fcn_0000.nc", work, base, rtol=1.0e-3, atol=1.0e-6)
+    assert not baseline_cmp.metadata_same(os.path.join(base, "fcn_0000.nc"), os.path.join(base, "grid_vars.nc"))
+    # command line: exit status 0 / 1 as the reference's CI scripts expect
+    cmd = [sys.executable, "-m", "nk_ooc_amd.baseline_cmp", "--fname", "fcn_0000.nc", "--expr_dir", work,
+           "--baseline_dir", base]
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert subprocess.run(cmd, env=env, capture_output=True).returncode == 1
+    assert subprocess.run(cmd + ["--rtol", "1e-3", "--atol", "1e-6"], env=env, capture_output=True).returncode == 0
