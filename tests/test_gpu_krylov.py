@@ -129,6 +129,13 @@ def test_krylov_column_regions_vs_reference_baselines(tmp_path):
                        _read_state(os.path.join(d, "perturb_fcn_w_raw_00.nc")), atol=5.0e-6)
     assert isclose_all(_read_state(os.path.join(kdir, "krylov_res_00.nc")),
                        _read_state(os.path.join(d, "krylov_res_00.nc")), rtol=1.9e-2)
+    # the same four comparisons through the comparer the reference's CI script calls (also checks
+    # dimensions, variable names and attributes), scripts/ci_py_driver_2d_iage_column_regions.sh
+    from nk_ooc_amd import baseline_cmp
+
+    for name, rtol, atol in (("precond_fcn_00.nc", 2.0e-3, 2.0e-9), ("basis_00.nc", 1.0e-7, 5.0e-5),
+                             ("perturb_fcn_w_raw_00.nc", 1.0e-7, 5.0e-6), ("krylov_res_00.nc", 1.9e-2, 2.0e-9)):
+        assert baseline_cmp.compare(name, kdir, d, rtol=rtol, atol=atol), name
     # checkpoint trail
     state = json.load(open(os.path.join(kdir, "Krylov_state.json")))
     assert state["iteration"] in (1, 2)
