@@ -5,6 +5,9 @@ object `{"iteration": int, "step_log": [str, ...], <saved values>}` written with
 indent 2; ndarrays are stored as `{"__ndarray__": nested list}`; per-iteration
 step strings are prefixed with the two-digit iteration (`"03:<step>"`).  A
 checkpoint written by the reference resumes here and vice versa.
+
+The file is rewritten after every change (a few hundred bytes) -- the run can be killed
+between any two solver actions and resumed from the last completed one.
 """
 
 import functools
@@ -14,110 +17,126 @@ import os
 
 import numpy as np
 
-
-class _NdarrayEncoder(json.JSONEncoder):
-    def default(self, o):
-        if isinstance(o, np.ndarray):
-            return {"__ndarray__": o.tolist()}
-        return super().default(o)
+LOG = logging.getLogger(__name__)
+NDARRAY_TAG = "__ndarray__"
 
 
-def _ndarray_hook(dct):
-    if "__ndarray__" in dct:
-        return np.asarray(dct["__ndarray__"])
-    return dct
+def _to_json(obj):
+    """json.dump `default=` hook: the only non-JSON type stored is the ndarray"""
+    if isinstance(obj, np.ndarray):
+        return {NDARRAY_TAG: obj.tolist()}
+    raise TypeError(f"{type(obj).__name__} is not JSON serializable")
+
+
+def _from_json(mapping):
+    """json.load `object_hook=`: tagged nested lists come back as ndarrays"""
+    return np.asarray(mapping[NDARRAY_TAG]) if NDARRAY_TAG in mapping else mapping
+
+
+def _equal(left, right):
+    if isinstance(left, np.ndarray) or isinstance(right, np.ndarray):
+        return np.array_equal(left, right)
+    return left == right
 
 
 class SolverState:
     """iteration counter + step log + saved values of one iterative solver"""
 
     def __init__(self, name, workdir, resume=False, rewind=False):
-        logger = logging.getLogger(__name__)
+        if rewind and not resume:
+            raise RuntimeError(f"rewind cannot be True if resume is False, name={name}")
         os.makedirs(workdir, exist_ok=True)
-        self._name = name
-        self._workdir = workdir
-        self._state_fname = os.path.join(workdir, f"{name}_state.json")
-        self._rewound_step_string = None
+        self._name, self._workdir = name, workdir
+        self._path = os.path.join(workdir, f"{name}_state.json")
+        self._undone = None          # step string taken back by a rewind
         if resume:
-            self._read_saved_state()
+            self._data = self._load()
             if rewind:
-                self._rewound_step_string = self._saved_state["step_log"].pop()
-                logger.info('rewinding step "%s" for "%s"', self._rewound_step_string, name)
+                self._undone = self._data["step_log"].pop()
+                LOG.info('rewinding step "%s" for "%s"', self._undone, name)
         else:
-            if rewind:
-                raise RuntimeError(f"rewind cannot be True if resume is False, name={name}")
-            self._saved_state = {"iteration": 0, "step_log": []}
+            self._data = {"iteration": 0, "step_log": []}
             self.log_step("__init__", per_iteration=False)
-            logger.info('"%s" iteration now %d', name, self._saved_state["iteration"])
+            self._announce()
 
+    # ---- file ------------------------------------------------------------------------------
+    def _load(self):
+        with open(self._path, mode="r") as fptr:
+            return json.load(fptr, object_hook=_from_json)
+
+    def _store(self):
+        with open(self._path, mode="w") as fptr:
+            json.dump(self._data, fptr, indent=2, default=_to_json)
+
+    def _announce(self):
+        LOG.info('"%s" iteration now %d', self._name, self._data["iteration"])
+
+    # ---- iteration counter -------------------------------------------------------------------
     def get_workdir(self):
         return self._workdir
 
     def get_iteration(self):
-        return self._saved_state["iteration"]
+        return self._data["iteration"]
 
     def inc_iteration(self):
-        self._saved_state["iteration"] += 1
+        self._data["iteration"] += 1
         self.log_step("inc_iteration")
-        logging.getLogger(__name__).info(
-            '"%s" iteration now %d', self._name, self._saved_state["iteration"])
-        return self._saved_state["iteration"]
+        self._announce()
+        return self._data["iteration"]
 
-    def _step_string(self, stepval, per_iteration):
-        return f"{self.get_iteration():02}:{stepval}" if per_iteration else stepval
+    # ---- step log -------------------------------------------------------------------------------
+    def _entry(self, stepval, per_iteration):
+        """step strings of one iteration carry the iteration number in front"""
+        if per_iteration:
+            return f"{self._data['iteration']:02}:{stepval}"
+        return stepval
 
     def step_logged(self, stepval, per_iteration=True):
-        return self._step_string(stepval, per_iteration) in self._saved_state["step_log"]
+        return self._entry(stepval, per_iteration) in self._data["step_log"]
 
     def log_step(self, stepval, per_iteration=True):
-        if not self.step_logged(stepval, per_iteration):
-            self._saved_state["step_log"].append(self._step_string(stepval, per_iteration))
-            self._write_saved_state()
+        entry = self._entry(stepval, per_iteration)
+        if entry in self._data["step_log"]:
+            return
+        self._data["step_log"].append(entry)
+        self._store()
 
     def step_was_rewound(self, stepval, per_iteration=True):
-        if self._rewound_step_string is None:
-            return False
-        return self._step_string(stepval, per_iteration) == self._rewound_step_string
+        return self._undone is not None and self._undone == self._entry(stepval, per_iteration)
+
+    # ---- saved values ---------------------------------------------------------------------------
+    def get_value_saved_state(self, key):
+        return self._data[key]
 
     def set_value_saved_state(self, key, value):
-        """store a value and confirm it survives the JSON round trip exactly"""
-        self._saved_state[key] = value
-        self._write_saved_state()
-        self._read_saved_state()
-        reread = self._saved_state[key]
-        same = np.array_equal(reread, value) if isinstance(value, np.ndarray) else reread == value
-        if not same:
+        """store a value; the state is re-read from the file at once so that what the solver goes on
+        with is exactly what a resumed run would see (and the round trip is verified)"""
+        self._data[key] = value
+        self._store()
+        self._data = self._load()
+        if not _equal(self._data[key], value):
             raise RuntimeError("saved_state value not recovered on reread")
-
-    def get_value_saved_state(self, key):
-        return self._saved_state[key]
-
-    def _write_saved_state(self):
-        with open(self._state_fname, mode="w") as fptr:
-            json.dump(self._saved_state, fptr, indent=2, cls=_NdarrayEncoder)
-
-    def _read_saved_state(self):
-        with open(self._state_fname, mode="r") as fptr:
-            self._saved_state = json.load(fptr, object_hook=_ndarray_hook)
 
 
 def action_step_log_wrap(step, per_iteration=True, post_exit=False):
     """decorator: run the wrapped action once per step-log entry.  `solver_state`
     must be passed by keyword; `step` is formatted with the call's keyword arguments."""
 
-    def outer(func):
-        @functools.wraps(func)
-        def inner(*args, **kwargs):
-            solver_state = kwargs["solver_state"]
+    def decorate(action):
+        @functools.wraps(action)
+        def guarded(*args, **kwargs):
+            ledger = kwargs["solver_state"]
             label = step.format(**kwargs)
-            if solver_state is not None and solver_state.step_logged(label, per_iteration):
+            if ledger is None:
+                action(*args, **kwargs)
+            elif not ledger.step_logged(label, per_iteration):
+                action(*args, **kwargs)
+                ledger.log_step(label, per_iteration)
+            else:
                 return
-            func(*args, **kwargs)
-            if solver_state is not None:
-                solver_state.log_step(label, per_iteration)
             if post_exit:
                 raise SystemExit
 
-        return inner
+        return guarded
 
-    return outer
+    return decorate

@@ -76,7 +76,7 @@ def test_reads_reference_checkpoint():
     assert st.get_iteration() == 2
     assert np.array_equal(st.get_value_saved_state("armijo_factor"), np.array([[1.0, 0.0, 0.0]]))
     assert st.step_logged("KrylovSolver instantiated") is False
-    assert "01:KrylovSolver instantiated" in st._saved_state["step_log"]
+    assert "01:KrylovSolver instantiated" in st.get_value_saved_state("step_log")
 
 
 def test_netcdf3_roundtrip_and_reference_files(tmp_path):
