@@ -22,13 +22,19 @@ cent, `tests/test_oracle_phosphorus.py`), and with it `shift` and the preconditi
 eigenvalue used here is the converged one (it agrees with a dense eigen-decomposition).
 """
 
+import logging
+import time
+
 import numpy as np
 
 
 class PhosphorusPrecond:
     """factorised phosphorus preconditioner for one linearisation state"""
 
-    def __init__(self, eng, po4, time_range, nvec=6, mu=0.02, tol=1.0e-11, max_iter=300):
+    def __init__(self, eng, po4, time_range, nvec=6, mu=0.02, tol=1.0e-10, max_iter=300, start=None):
+        """`start`: (n, nvec) basis to start the subspace iteration from, e.g. the converged basis of
+        the previous Newton iteration's preconditioner (`self.basis`)"""
+        wall0 = time.time()
         self.eng = eng
         t0, t1 = float(time_range[0]), float(time_range[1])
         self.t_mid = t0 + 0.5 * (t1 - t0)        # time_n = 1 (phosphorus.py:208-229)
@@ -37,22 +43,28 @@ class PhosphorusPrecond:
         ylin[0] = po4                             # only po4 enters the Jacobian (phosphorus.py:213-216)
         eng.set_lin_state(eng.upload(ylin))
         self.ones = eng.upload(np.ones(eng.shape))
-        self.e_vals, null_vect, self.eig_iters = self._smallest_eigs(nvec, mu, tol, max_iter)
+        self.e_vals, null_vect, self.eig_iters = self._smallest_eigs(nvec, mu, tol, max_iter, start)
+        wall1 = time.time()
         self.null_vect = null_vect
         self.shift = 0.5 * self.e_vals[1].real
         eng.shift_factor(self.t_mid, self.scale, [self.shift, 0.5 * self.shift])
         e_vect = eng.upload(null_vect.reshape(eng.shape))
         self.e_hat = eng.scale(e_vect, 1.0 / eng.dot(e_vect, self.ones))
+        logging.getLogger(__name__).info(
+            "phosphorus preconditioner: %d subspace iterations (%.2f s), shift %.6e, factorisations %.2f s",
+            self.eig_iters, wall1 - wall0, self.shift, time.time() - wall1)
 
-    def _smallest_eigs(self, nvec, mu, tol, max_iter):
+    def _smallest_eigs(self, nvec, mu, tol, max_iter, start):
         """eigenvalues of mat closest to zero and the null vector, by subspace inverse
         iteration with Rayleigh-Ritz extraction; the solves run on the device, the
         (n x nvec) dense algebra on the host"""
         eng = self.eng
         n = int(np.prod(eng.shape))
         eng.shift_factor(self.t_mid, self.scale, [mu])
-        rng = np.random.default_rng(0)
-        basis, _ = np.linalg.qr(rng.standard_normal((n, nvec)))
+        if start is not None and start.shape == (n, nvec):
+            basis, _ = np.linalg.qr(start)
+        else:
+            basis, _ = np.linalg.qr(np.random.default_rng(0).standard_normal((n, nvec)))
         prev = None
         for it in range(max_iter):
             work = np.empty((n, nvec))
@@ -68,6 +80,7 @@ class PhosphorusPrecond:
                 break
             prev = lead
             basis, _ = np.linalg.qr(work)
+        self.basis = basis
         null_comp = basis @ ritz[:, 0]
         if np.max(np.abs(null_comp.imag)) > 1.0e-10 * np.max(np.abs(null_comp.real)):
             raise RuntimeError("1st eigenvector has non-trivial imaginary part")
