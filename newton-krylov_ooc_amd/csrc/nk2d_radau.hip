@@ -364,6 +364,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         bool have_rate = false;
         int n_iter = 0;
         while (!accepted) {
+            // a NaN / Inf in the state or the tendency makes every comparison below false: SciPy's loop
+            // (radau.py:445-476) would halve NaN forever; fail instead
+            if (!std::isfinite(h_abs)) return nk2d_fail(c, "Radau: step size is not finite (non-finite state or tendency)", -3);
             if (h_abs < min_step) return nk2d_fail(c, "Radau: required step size is less than spacing between numbers", -3);
             h = h_abs;
             t_new = t + h;

@@ -1,0 +1,117 @@
+"""Error behaviour at the C ABI: bad descriptors, calls out of order, inconsistent replay
+schedules and non-finite states end in a negative status with a message -- never in a hang,
+a fault or a silently wrong result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+YEAR = 365.0 * 86400.0
+
+
+def _iage(nz=22, ny=9, **kwargs):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    return iage_engine(Grid2d.default(nz, ny), **kwargs)
+
+
+def _state(eng, seed=0):
+    rng = np.random.default_rng(seed)
+    return eng.upload(1.0 + rng.random(eng.shape))
+
+
+def test_create_rejects_unsupported_shapes():
+    from nk_ooc_amd.engine import ModuleEngine, Nk2dError
+    from nk_ooc_amd.grid import Grid2d
+
+    with pytest.raises(Nk2dError, match="512"):
+        ModuleEngine(Grid2d.default(520, 4), tc=1)
+    with pytest.raises(Nk2dError, match="tracer"):
+        ModuleEngine(Grid2d.default(22, 9), tc=5)
+    with pytest.raises(Nk2dError, match="phosphorus"):
+        ModuleEngine(Grid2d.default(22, 9), tc=2, module_kind=1, phos_params=[0.0] * 6,
+                     light_lim=np.zeros((22, 9)))
+    # the largest supported column (8 levels per lane) and a two-column grid do work
+    for nz, ny in ((512, 3), (70, 2)):
+        eng = ModuleEngine(Grid2d.default(nz, ny), tc=1, decay_rate=(1.0e-8,))
+        out = eng.download(eng.tend(0.0, _state(eng)))
+        assert out.shape == (1, nz, ny) and np.all(np.isfinite(out))
+
+
+def test_options_and_call_order():
+    from nk_ooc_amd.engine import Nk2dError
+
+    eng = _iage()
+    with pytest.raises(Nk2dError, match="unknown option"):
+        eng.set_option("no_such_option", 1.0)
+    with pytest.raises(Nk2dError, match="lin_tol"):
+        eng.set_option("lin_tol", 2.0)
+    with pytest.raises(Nk2dError, match="device_ctl"):
+        eng.set_option("device_ctl", 7.0)
+    x = _state(eng)
+    out = eng.new_vec()
+    assert eng._lib.nk2d_precond_apply(eng._ctx, x.ptr, out.ptr) < 0
+    assert b"nk2d_precond_setup" in eng._lib.nk2d_last_error(eng._ctx)
+    assert eng._lib.nk2d_shift_solve(eng._ctx, 0, x.ptr, out.ptr) < 0
+    assert b"nk2d_shift_factor" in eng._lib.nk2d_last_error(eng._ctx)
+    with pytest.raises(Nk2dError, match="NK2D_MAX_SHIFTS"):
+        eng.shift_factor(0.5 * YEAR, YEAR, [0.1] * 9)
+    eng.shift_factor(0.5 * YEAR, YEAR, [0.1])
+    with pytest.raises(Nk2dError, match="no such system"):
+        eng.shift_solve(3, x)
+    # after a refused call the context keeps working
+    assert np.all(np.isfinite(eng.download(eng.shift_solve(0, x))))
+
+
+def test_phosphorus_needs_its_linearisation_state():
+    from nk_ooc_amd.engine import Nk2dError, phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = phosphorus_engine(Grid2d.default(22, 9))
+    x = _state(eng)
+    with pytest.raises(Nk2dError, match="linearisation state"):
+        eng.jacobian_apply(0.0, x)
+    with pytest.raises(Nk2dError, match="nk2d_set_lin_state"):
+        eng.shift_factor(0.5 * YEAR, YEAR, [0.02])
+    with pytest.raises(Nk2dError, match="nk2d_jacobian_apply"):
+        eng.jacobian_diags(0.0)
+    with pytest.raises(Nk2dError, match="nk2d_shift_factor"):
+        eng.precond_setup()
+    with pytest.raises(Nk2dError, match="precond_setup_state"):
+        eng.precond_apply(x)
+    with pytest.raises(ValueError, match="unknown phosphorus parameter"):
+        phosphorus_engine(Grid2d.default(22, 9), params={"po4_halfsat_typo": "1.0"})
+    eng2 = phosphorus_engine(Grid2d.default(22, 9), params={"max_uptake_rate": "1.0 / (2.0 * 86400.0)"})
+    assert eng2.phos["max_uptake_rate"] == 1.0 / (2.0 * 86400.0)
+
+
+def test_replay_schedule_is_validated():
+    from nk_ooc_amd.engine import Nk2dError
+
+    eng = _iage()
+    x = _state(eng)
+    _, _, sched = eng.comp_fcn(x, record=True)
+    bad = sched.copy()
+    bad[0, 0] = 10.0                       # does not start where the state is
+    with pytest.raises(Nk2dError, match="replay schedule"):
+        eng.comp_fcn(x, replay=bad)
+    bad = sched.copy()
+    bad[5, 4] = bad[5, 0] + 1.0            # Jacobian refreshed off a step start
+    with pytest.raises(Nk2dError, match="replay schedule"):
+        eng.comp_fcn(x, replay=bad)
+    with pytest.raises(Nk2dError, match="record buffer"):
+        eng.comp_fcn(x, record=True, record_cap=8)
+    # the context is usable afterwards and reproduces the recorded run
+    fx, _, _ = eng.comp_fcn(x, replay=sched)
+    fy, _, _ = eng.comp_fcn(x)
+    assert np.allclose(eng.download(fx), eng.download(fy), rtol=1e-9, atol=1e-12)
+
+
+def test_non_finite_state_terminates_with_an_error():
+    from nk_ooc_amd.engine import Nk2dError
+
+    eng = _iage()
+    vals = 1.0 + np.random.default_rng(1).random(eng.shape)
+    vals[0, 3, 4] = np.nan
+    with pytest.raises(Nk2dError, match="step size"):
+        eng.comp_fcn(eng.upload(vals))
