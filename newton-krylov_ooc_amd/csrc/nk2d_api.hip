@@ -17,21 +17,43 @@ int dev_alloc(nk2d_ctx* c, T** p, size_t n) {
     return 0;
 }
 
+// STAGE (device) holds a host-layout copy for the pack / unpack kernels; hSTAGE is its pinned host
+// twin.  Host arrays of the caller are pageable: copying them straight to / from the device makes
+// the runtime pin the pages on the fly (milliseconds per call), so they go through hSTAGE.
 int ensure_stage(nk2d_ctx* c, size_t n) {
     if (n <= c->stage_elems) return 0;
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->STAGE) NK2D_CHECK(c, hipFree(c->STAGE));
-    c->STAGE = nullptr;
+    if (c->hSTAGE) NK2D_CHECK(c, hipHostFree(c->hSTAGE));
+    c->STAGE = c->hSTAGE = nullptr;
     c->stage_elems = 0;
     NK2D_CHECK(c, hipMalloc((void**)&c->STAGE, sizeof(double) * n));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hSTAGE, sizeof(double) * n));
     c->stage_elems = n;
+    return 0;
+}
+
+// host (pageable) -> STAGE
+int stage_in(nk2d_ctx* c, const double* host, size_t n) {
+    NK2D_TRY(ensure_stage(c, n));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));  // hSTAGE may still feed an earlier copy
+    std::memcpy(c->hSTAGE, host, sizeof(double) * n);
+    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, c->hSTAGE, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// STAGE -> host (pageable); returns with the copy complete
+int stage_out(nk2d_ctx* c, double* host, size_t n) {
+    NK2D_CHECK(c, hipMemcpyAsync(c->hSTAGE, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(host, c->hSTAGE, sizeof(double) * n);
     return 0;
 }
 
 // host row-major [nrows][ncols] -> packed device plane of ncols columns
 int upload_plane(nk2d_ctx* c, const double* host, int nrows, int ncols, double* dst, double fill = 0.0) {
     const size_t n = (size_t)nrows * ncols;
-    NK2D_TRY(ensure_stage(c, n));
-    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_TRY(stage_in(c, host, n));
     NK2D_TRY(nk2d_k_pack_plane(c, c->STAGE, nrows, ncols, dst, fill));
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -260,6 +282,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->speculate = 1;
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
+    c->hRCOEF = nullptr;
 
     // ---- axis metrics exactly as SpatialAxis derives them (spatial_axis.py:35-39)
     std::vector<double> zmid(nz), dz(nz), dzr(nz), dzm(nz), dzmr(nz), zm1(nz), dy(ny), dyr(ny);
@@ -313,6 +336,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     if (!c) return -2;
     c->stream = nullptr;
     c->STAGE = nullptr;
+    c->hSTAGE = nullptr;
     c->stage_elems = 0;
     c->precond = nullptr;
     c->st = nk2d_stats();
@@ -341,10 +365,13 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
+    for (double* b : c->vec_pool) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hPART) (void)hipHostFree(c->hPART);
+    if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
+    if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
     if (c->hCTL) (void)hipHostFree(c->hCTL);
     if (c->hSNAP) {
         (void)hipHostFree(c->hSNAP);
@@ -393,9 +420,11 @@ extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* w
         c->PART = nullptr;
         NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol * nreg));
         if (c->RCOEF) NK2D_CHECK(c, hipFree(c->RCOEF));
-        c->RCOEF = nullptr;
+        if (c->hRCOEF) NK2D_CHECK(c, hipHostFree(c->hRCOEF));
+        c->RCOEF = c->hRCOEF = nullptr;
         c->rcoef_elems = (size_t)nreg * 1024 + 4096;
         NK2D_TRY(dev_alloc(c, &c->RCOEF, c->rcoef_elems));
+        NK2D_CHECK(c, hipHostMalloc((void**)&c->hRCOEF, sizeof(double) * c->rcoef_elems));
         if ((size_t)nreg * 2 > 4096) return nk2d_fail(c, "nk2d_set_region: too many regions");
     }
     c->nreg = nreg;
@@ -406,25 +435,40 @@ extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* w
 // ---------------------------------------------------------------------------------
 // vectors
 // ---------------------------------------------------------------------------------
+// State vectors come from a per-context pool: hipMalloc / hipFree cost milliseconds each and the
+// solver mirrors create and drop a dozen temporaries per Krylov iteration.  A vector handed out
+// is zero-filled (stream ordered); freed vectors are kept (at most NK2D_POOL_MAX) until destroy.
+#define NK2D_POOL_MAX 64
 extern "C" int nk2d_vec_alloc(nk2d_ctx* c, nk2d_vec* out) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     double* p = nullptr;
-    NK2D_TRY(dev_alloc(c, &p, c->nv));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    if (!c->vec_pool.empty()) {
+        p = c->vec_pool.back();
+        c->vec_pool.pop_back();
+        NK2D_CHECK(c, hipMemsetAsync(p, 0, sizeof(double) * c->nv, c->stream));
+    } else {
+        NK2D_TRY(dev_alloc(c, &p, c->nv));
+    }
     *out = p;
     return 0;
 }
 extern "C" int nk2d_vec_free(nk2d_ctx* c, nk2d_vec v) {
+    if (!v) return 0;
     NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->vec_pool.size() < NK2D_POOL_MAX) {
+        // work queued on the context's stream that still reads v finishes before any later use,
+        // which is queued on the same stream
+        c->vec_pool.push_back((double*)v);
+        return 0;
+    }
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-    if (v) NK2D_CHECK(c, hipFree(v));
+    NK2D_CHECK(c, hipFree(v));
     return 0;
 }
 extern "C" int nk2d_vec_upload(nk2d_ctx* c, nk2d_vec v, const double* host) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     const size_t n = (size_t)c->tc * c->nz * c->ny;
-    NK2D_TRY(ensure_stage(c, n));
-    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_TRY(stage_in(c, host, n));
     NK2D_TRY(nk2d_k_pack_state(c, c->STAGE, (double*)v));
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -434,9 +478,7 @@ extern "C" int nk2d_vec_download(nk2d_ctx* c, nk2d_vec v, double* host) {
     const size_t n = (size_t)c->tc * c->nz * c->ny;
     NK2D_TRY(ensure_stage(c, n));
     NK2D_TRY(nk2d_k_unpack_state(c, (const double*)v, c->STAGE));
-    NK2D_CHECK(c, hipMemcpyAsync(host, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return stage_out(c, host, n);
 }
 extern "C" int nk2d_vec_copy(nk2d_ctx* c, nk2d_vec dst, nk2d_vec src) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
@@ -467,9 +509,7 @@ extern "C" int nk2d_vmix_coeff(nk2d_ctx* c, double t, double* host_out) {
     const size_t n = (size_t)(c->nz - 1) * c->ny;
     NK2D_TRY(ensure_stage(c, n));
     NK2D_TRY(nk2d_k_unpack_plane(c, c->KV[4], c->nz - 1, c->ny, c->STAGE));
-    NK2D_CHECK(c, hipMemcpyAsync(host_out, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return stage_out(c, host_out, n);
 }
 
 // linearisation state of the stand-alone Jacobian entry points (state dependent modules only)
@@ -504,8 +544,7 @@ extern "C" int nk2d_jacobian_diags(nk2d_ctx* c, double t, double* host_out) {
     std::vector<double> tmp(P);
     for (int d = 0; d < 5; ++d) {
         NK2D_TRY(nk2d_k_unpack_plane(c, planes[d], c->nz, c->ny, c->STAGE));
-        NK2D_CHECK(c, hipMemcpyAsync(tmp.data(), c->STAGE, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_TRY(stage_out(c, tmp.data(), P));
         for (int tr = 0; tr < c->tc; ++tr) {
             double* dst = host_out + ((size_t)d * c->tc + tr) * P;
             std::memcpy(dst, tmp.data(), sizeof(double) * P);
@@ -563,9 +602,7 @@ int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first) {
         NK2D_TRY(nk2d_r_dense(c, x, c->TMP));
         NK2D_TRY(ensure_stage(c, n));
         NK2D_TRY(nk2d_k_unpack_state(c, c->TMP, c->STAGE));
-        NK2D_CHECK(c, hipMemcpyAsync(c->hist_host + (size_t)c->hist_next * n, c->STAGE, sizeof(double) * n,
-                                     hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_TRY(stage_out(c, c->hist_host + (size_t)c->hist_next * n, n));
         c->hist_next++;
     }
     (void)first;
@@ -727,9 +764,13 @@ __global__ void k_mask(int ncol, int ny, double* __restrict__ v, const int32_t* 
     store_col<E>(v, task, lane, vv);
 }
 
-static int stage_coef(nk2d_ctx* c, const double* host, size_t n, size_t offset) {
+// region scalars (and vector pointers) of an algebra call: pageable caller memory -> pinned twin
+// -> device.  Every entry point that stages coefficients synchronises before it returns, so the
+// pinned twin is free again at the next call.
+static int stage_coef(nk2d_ctx* c, const void* host, size_t n, size_t offset) {
     if (offset + n > c->rcoef_elems) return nk2d_fail(c, "region coefficient staging overflow");
-    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + offset, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->hRCOEF + offset, host, sizeof(double) * n);
+    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + offset, c->hRCOEF + offset, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
@@ -780,7 +821,7 @@ extern "C" int nk2d_lin_comb(nk2d_ctx* c, nk2d_vec out, int32_t n, const nk2d_ve
     const size_t ncoef = (size_t)n * c->nreg;
     if (ncoef + (size_t)n > c->rcoef_elems) return nk2d_fail(c, "nk2d_lin_comb: too many vectors");
     NK2D_TRY(stage_coef(c, coef, ncoef, 0));
-    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + ncoef, vecs, sizeof(void*) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_TRY(stage_coef(c, vecs, (size_t)n, ncoef));  // pointers are 8-byte slots like the coefficients
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_lin_comb<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                                c->ncol, c->ny, n, c->nreg, (const double* const*)(c->RCOEF + ncoef),
                                                c->RCOEF, c->MASK, (double*)out));

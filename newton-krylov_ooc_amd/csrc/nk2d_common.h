@@ -86,11 +86,15 @@ struct nk2d_ctx {
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
     int part_on_host;
     int speculate;   // 1: queue the next Newton iteration's front launches before reading the norm
+    // freed state vectors kept for reuse (nk2d_vec_alloc / nk2d_vec_free)
+    std::vector<double*> vec_pool;
     // staging for host <-> device layout conversion
     double* STAGE;
+    double* hSTAGE;  // pinned host twin of STAGE
     size_t stage_elems;
     // region scalars staged on device for the algebra kernels
     double* RCOEF;
+    double* hRCOEF;  // pinned host twin of RCOEF
     size_t rcoef_elems;
 
     // line-relaxation contraction bound rho(c) = max_i s_i / (c + q_i), tabulated at create
