@@ -418,7 +418,7 @@ int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
 int nk2d_profile_collect(nk2d_ctx* c);
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
 int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
-                        double mci, int src);
+                        double mci, int src, bool delta);
 int nk2d_r_err_rhs(nk2d_ctx* c, double h);
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h);
 int nk2d_r_err_norm(nk2d_ctx* c, const double* err);

@@ -1003,6 +1003,9 @@ struct FusedArgs {
     SweepArgs sw;
     double* part;
     int do_stage, do_update;
+    // two-sweep solves: the first launch keeps only x1 = T^-1 b, the second computes
+    // x2 = x1 + T^-1 (lateral couplings of x1) and never needs the right-hand sides back
+    int delta;
 };
 
 template <int E, int KIND>
@@ -1053,11 +1056,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             fcr[e] = fcr[e] - (A.st.mcr * w1[e] - A.st.mci * w2[e]);
             fci[e] = fci[e] - (A.st.mcr * w2[e] + A.st.mci * w1[e]);
         }
-        if (!A.do_update) {  // later sweeps read the right-hand sides back
+        if (!A.do_update && !A.delta) {  // later sweeps read the right-hand sides back
             store_col<E>(A.st.br, task, lane, fr);
             store_col<E>(A.st.bcr, task, lane, fcr);
             store_col<E>(A.st.bci, task, lane, fci);
         }
+    } else if (A.delta) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
     } else {
         load_col<E>(A.sw.br, task, lane, fr);
         load_col<E>(A.sw.bcr, task, lane, fcr);
@@ -1122,6 +1128,18 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
 #pragma unroll
         for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
+    }
+    if (!A.do_stage && A.delta) {  // correction of the first sweep's solution
+        double x1[E];
+        load_col<E>(A.sw.xr_old, task, lane, x1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fr[e] = x1[e] + fr[e];
+        load_col<E>(A.sw.xcr_old, task, lane, x1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fcr[e] = x1[e] + fcr[e];
+        load_col<E>(A.sw.xci_old, task, lane, x1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) fci[e] = x1[e] + fci[e];
     }
     if (!A.do_update) {
         store_col<E>(A.sw.xr_new, task, lane, fr);
@@ -1345,7 +1363,7 @@ int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
 // one launch of the fused Newton iteration; src = ping-pong buffer with the previous
 // sweep's iterate, the new iterate goes to 1-src unless do_update consumes it
 int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
-                        double mci, int src) {
+                        double mci, int src, bool delta) {
     FusedArgs A = {};
     A.st.y = c->Y; A.st.z = c->Z; A.st.w = c->W;
     A.st.kv[0] = c->KV[0]; A.st.kv[1] = c->KV[1]; A.st.kv[2] = c->KV[2];
@@ -1359,6 +1377,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     A.part = c->part_on_host ? c->hPART : c->PART;
     A.do_stage = do_stage ? 1 : 0;
     A.do_update = do_update ? 1 : 0;
+    A.delta = delta ? 1 : 0;
     DevP P = make_devp(c);
     {
         // algorithmic (unique) bytes of this launch, P = nz*ny cells, N = tc*P values:
@@ -1371,9 +1390,9 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         //   update: y (N, unless the stage read it), W read + write (6N), Z write (3N)
         const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
         double words = 0.0;
-        if (do_stage) words += 7.0 * N + 7.0 * Pc + (do_update ? 0.0 : 3.0 * N);
+        if (do_stage) words += 7.0 * N + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * N);
         words += (first ? 2.0 : 4.0) * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N;
-        if (!do_stage) words += 3.0 * N;
+        if (!do_stage && !delta) words += 3.0 * N;
         if (!first) words += 3.0 * N;
         if (!do_update) words += 3.0 * N;
         if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;

@@ -121,7 +121,7 @@ int newton_iteration(Ctl& s, double mreal, double mcr, double mci) {
     const int m = std::max(s.m_real, s.m_cplx);
     int src = 0;
     for (int it = 0; it < m; ++it) {
-        NK2D_TRY(nk2d_r_newton_fused(c, it == 0, it == 0, it == m - 1, mreal, mcr, mci, src));
+        NK2D_TRY(nk2d_r_newton_fused(c, it == 0, it == 0, it == m - 1, mreal, mcr, mci, src, m == 2));
         src = 1 - src;
     }
     c->st.nsolve += 2;
@@ -146,14 +146,14 @@ int newton_front(Ctl& s, double mreal, double mcr, double mci) {
     const int m = std::max(s.m_real, s.m_cplx);
     int src = 0;
     for (int it = 0; it + 1 < m; ++it) {
-        NK2D_TRY(nk2d_r_newton_fused(s.c, it == 0, it == 0, false, mreal, mcr, mci, src));
+        NK2D_TRY(nk2d_r_newton_fused(s.c, it == 0, it == 0, false, mreal, mcr, mci, src, m == 2));
         src = 1 - src;
     }
     return 0;
 }
 int newton_back(Ctl& s, double mreal, double mcr, double mci) {
     const int m = std::max(s.m_real, s.m_cplx);
-    NK2D_TRY(nk2d_r_newton_fused(s.c, m == 1, m == 1, true, mreal, mcr, mci, (m - 1) & 1));
+    NK2D_TRY(nk2d_r_newton_fused(s.c, m == 1, m == 1, true, mreal, mcr, mci, (m - 1) & 1, m == 2));
     s.c->st.nsolve += 2;
     return 0;
 }

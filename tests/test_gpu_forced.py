@@ -93,7 +93,9 @@ def test_two_module_krylov(tmp_path):
         assert np.allclose(fcn.tracer_modules[i].get_tracer_vals_all().reshape(-1), f[i], rtol=1e-3, atol=1e-6)
     _, trace = krylov.krylov_solve(mods, x, f, rel_tol=1e-9, max_iter=2)
     assert rel_err(beta, trace["beta"]) < 1e-4
-    assert rel_err(h_mat, trace["h_mat"][-1]) < 2e-2
+    # Hessenberg entries are finite differences of two free-running forward years (integrator
+    # tolerance 1e-6 over sigma = 1e-4 |x|): noise of a few per cent of the largest entry
+    assert rel_err(h_mat, trace["h_mat"][-1]) < 5e-2
     # the saved-state file holds both modules' tracers
     from nk_ooc_amd import ncio
 
