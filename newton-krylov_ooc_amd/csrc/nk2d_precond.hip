@@ -33,6 +33,7 @@ struct Precond {
     int m, nb, nz, nt, tc;
     int mode;      // 0: time-periodic system of the linear modules, 1: shifted systems (nk2d_shift_factor)
     int nsys;      // independent systems held in SINV: tracers (mode 0) or shifts (mode 1)
+    int cap_sys;   // systems the buffers were allocated for
     double scale, sigma[NK2D_MAX_SHIFTS];
     double* PJ;    // Jacobian planes, natural layout [nt][6][nz][ny]  (L, S, C, N, U, d uptake / d po4)
     double* SINV;  // [tc][nb][m][m]
@@ -379,28 +380,39 @@ namespace {
 // allocate for `nsys` systems of block size m = nslot * nz, load the Jacobian planes at the
 // `nt` times and run the block elimination (Schur complements + their explicit inverses)
 int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const double* times, const double* ylin) {
-    nk2d_precond_free(c);
-    Precond* pc = new Precond();
-    c->precond = pc;
+    Precond* pc = (Precond*)c->precond;
+    const int m = nslot * c->nz;
+    // gigabytes of Schur inverses: keep the allocation when the next factorisation fits in it (the
+    // phosphorus preconditioner factorises three shifted systems per Newton iteration)
+    const bool reuse = pc && pc->mode == mode && pc->nt == nt && pc->m == m && pc->nb == c->ny && pc->cap_sys >= nsys;
+    if (!reuse) {
+        nk2d_precond_free(c);
+        pc = new Precond();
+        c->precond = pc;
+        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->PINV = pc->ROWS = nullptr;
+        pc->cap_sys = std::max(nsys, mode == 1 ? 2 : nsys);
+    }
     pc->mode = mode;
     pc->nsys = nsys;
     pc->nt = nt;
     pc->nz = c->nz;
     pc->tc = c->tc;
-    pc->m = nslot * c->nz;
+    pc->m = m;
     pc->nb = c->ny;
     pc->dt = (c->d.t1 - c->d.t0) / 3;
     pc->scale = 0.0;
     for (int i = 0; i < NK2D_MAX_SHIFTS; ++i) pc->sigma[i] = 0.0;
-    pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->PINV = pc->ROWS = nullptr;
     const size_t P = (size_t)c->nz * c->ny, mm = (size_t)pc->m * pc->m;
-    NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * PL_COUNT * P));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * nsys * pc->nb * mm));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * nsys * mm));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * nsys * PC_NB * PC_NB));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * nsys * PC_NB * pc->m));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * nsys * pc->nb * pc->m));
-    NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * nsys * pc->nb * pc->m));
+    if (!reuse) {
+        const size_t cap = (size_t)pc->cap_sys;
+        NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * PL_COUNT * P));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * cap * pc->nb * mm));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * cap * mm));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * cap * PC_NB * PC_NB));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * cap * PC_NB * pc->m));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * cap * pc->nb * pc->m));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * cap * pc->nb * pc->m));
+    }
     for (int tau = 0; tau < pc->nt; ++tau) {
         double t = times[tau];
         double* out[1] = {c->KV[4]};

@@ -267,10 +267,10 @@ class ModuleEngine:
         """state dependent preconditioner (phosphorus): linearise about the given po4 field"""
         from .phosphorus import PhosphorusPrecond
 
-        # the eigenvectors move little between Newton iterations: start from the last converged basis
+        # the eigenvectors move little between Newton iterations: start from the last ones
         last = getattr(self, "_state_precond", None)
         self._state_precond = PhosphorusPrecond(self, po4, time_range,
-                                                start=None if last is None else last.basis)
+                                                start=None if last is None else last.restart)
         return self._state_precond
 
     def precond_apply(self, v, out=None):

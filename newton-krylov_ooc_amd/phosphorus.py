@@ -13,8 +13,8 @@ iterate's history, `T` = one year) the reference computes, for every application
 Here the two shifted matrices are factorised ONCE per preconditioner (block elimination over
 the ypos columns with the three tracers of a column in one block, `nk2d_shift_factor`) and every
 application is two block substitutions (`nk2d_shift_solve`) plus region-weighted algebra, all on
-the device.  The eigen-pair comes from subspace inverse iteration with the same block solver
-at a small POSITIVE shift, where `-(mat - mu I)` is a non-singular M-matrix.
+the device.  The eigen-pair comes from shift-invert Arnoldi with the same block solver at a
+small POSITIVE shift, where `-(mat - mu I)` is a non-singular M-matrix.
 
 The reference's `sigma=0.0` asks ARPACK to invert the exactly singular `mat`; its second
 eigenvalue then depends on ARPACK's random start vector (real part scattered by several per
@@ -31,9 +31,9 @@ import numpy as np
 class PhosphorusPrecond:
     """factorised phosphorus preconditioner for one linearisation state"""
 
-    def __init__(self, eng, po4, time_range, nvec=6, mu=0.02, tol=1.0e-10, max_iter=300, start=None):
-        """`start`: (n, nvec) basis to start the subspace iteration from, e.g. the converged basis of
-        the previous Newton iteration's preconditioner (`self.basis`)"""
+    def __init__(self, eng, po4, time_range, mu=0.02, tol=1.0e-10, max_solves=80, start=None):
+        """`start`: start vector of the Arnoldi process, e.g. `restart` of the previous Newton
+        iteration's preconditioner (the eigenvectors move little between iterations)"""
         wall0 = time.time()
         self.eng = eng
         t0, t1 = float(time_range[0]), float(time_range[1])
@@ -43,7 +43,7 @@ class PhosphorusPrecond:
         ylin[0] = po4                             # only po4 enters the Jacobian (phosphorus.py:213-216)
         eng.set_lin_state(eng.upload(ylin))
         self.ones = eng.upload(np.ones(eng.shape))
-        self.e_vals, null_vect, self.eig_iters = self._smallest_eigs(nvec, mu, tol, max_iter, start)
+        self.e_vals, null_vect, self.eig_solves = self._smallest_eigs(mu, tol, max_solves, start)
         wall1 = time.time()
         self.null_vect = null_vect
         self.shift = 0.5 * self.e_vals[1].real
@@ -51,40 +51,67 @@ class PhosphorusPrecond:
         e_vect = eng.upload(null_vect.reshape(eng.shape))
         self.e_hat = eng.scale(e_vect, 1.0 / eng.dot(e_vect, self.ones))
         logging.getLogger(__name__).info(
-            "phosphorus preconditioner: %d subspace iterations (%.2f s), shift %.6e, factorisations %.2f s",
-            self.eig_iters, wall1 - wall0, self.shift, time.time() - wall1)
+            "phosphorus preconditioner: %d Arnoldi solves (factor %.2f s, solves %.2f s, host algebra %.2f s), "
+            "shift %.6e, factorisation of the two shifted systems %.2f s",
+            self.eig_solves, self.clock["factor"], self.clock["solve"], self.clock["host"], self.shift,
+            time.time() - wall1)
 
-    def _smallest_eigs(self, nvec, mu, tol, max_iter, start):
-        """eigenvalues of mat closest to zero and the null vector, by subspace inverse
-        iteration with Rayleigh-Ritz extraction; the solves run on the device, the
-        (n x nvec) dense algebra on the host"""
+    def _smallest_eigs(self, mu, tol, max_solves, start):
+        """eigenvalues of mat closest to zero and the null vector by shift-invert Arnoldi: the
+        Krylov space of (mat - mu I)^-1 is built with the device block solver (one solve per
+        basis vector, ~20 in all), orthogonalisation and the small Hessenberg eigenproblem run
+        on the host.  A Ritz pair (theta, s) of the inverse has residual |h[j+1,j] s[j]|."""
         eng = self.eng
         n = int(np.prod(eng.shape))
+        clock = {"factor": -time.time(), "solve": 0.0, "host": 0.0}
         eng.shift_factor(self.t_mid, self.scale, [mu])
-        if start is not None and start.shape == (n, nvec):
-            basis, _ = np.linalg.qr(start)
-        else:
-            basis, _ = np.linalg.qr(np.random.default_rng(0).standard_normal((n, nvec)))
-        prev = None
-        for it in range(max_iter):
-            work = np.empty((n, nvec))
-            for col in range(nvec):
-                sol = eng.shift_solve(0, eng.upload(basis[:, col].reshape(eng.shape)))
-                work[:, col] = eng.download(sol).reshape(-1)
-            theta, ritz = np.linalg.eig(basis.T @ work)       # theta ~ 1 / (lambda - mu)
+        eng.sync()
+        clock["factor"] += time.time()
+        if start is None or start.shape != (n,):
+            start = np.random.default_rng(0).standard_normal(n)
+        basis = np.empty((max_solves + 1, n))          # one Krylov vector per (contiguous) row
+        hess = np.zeros((max_solves + 1, max_solves))
+        basis[0] = start / np.linalg.norm(start)
+        for col in range(max_solves):
+            tick = time.time()
+            sol = eng.shift_solve(0, eng.upload(basis[col].reshape(eng.shape)))
+            work = eng.download(sol).reshape(-1)
+            clock["solve"] += time.time() - tick
+            tick = time.time()
+            # classical Gram-Schmidt, repeated only when cancellation was severe (DGKS criterion)
+            before = np.linalg.norm(work)
+            for _ in range(2):
+                proj = basis[:col + 1] @ work
+                work -= proj @ basis[:col + 1]
+                hess[:col + 1, col] += proj
+                after = np.linalg.norm(work)
+                if after > 0.7 * before:
+                    break
+                before = after
+            hess[col + 1, col] = after
+            basis[col + 1] = work / hess[col + 1, col]
+            clock["host"] += time.time() - tick
+            used = col + 1
+            if used % 4 and used != max_solves:
+                continue
+            theta, ritz = np.linalg.eig(hess[:used, :used])       # theta ~ 1 / (lambda - mu)
             lam = mu + 1.0 / theta
             order = np.argsort(np.abs(lam))
-            lam, ritz = lam[order], ritz[:, order]
-            lead = lam[:3]
-            if prev is not None and np.all(np.abs(lead[1:] - prev[1:]) <= tol * np.abs(lead[1:])):
+            lam, ritz, theta = lam[order], ritz[:, order], theta[order]
+            resid = abs(hess[used, used - 1]) * np.abs(ritz[used - 1, :3]) / np.abs(theta[:3])
+            if used >= 8 and np.all(resid <= tol):
                 break
-            prev = lead
-            basis, _ = np.linalg.qr(work)
-        self.basis = basis
-        null_comp = basis @ ritz[:, 0]
+        tick = time.time()
+        lead = ritz[:, :3]
+        vects = basis[:used].T @ lead.real + 1j * (basis[:used].T @ lead.imag)   # two real products
+        clock["host"] += time.time() - tick
+        self.clock = clock
+        null_comp = vects[:, 0]
         if np.max(np.abs(null_comp.imag)) > 1.0e-10 * np.max(np.abs(null_comp.real)):
             raise RuntimeError("1st eigenvector has non-trivial imaginary part")
-        return lam, np.ascontiguousarray(null_comp.real), it + 1
+        # start vector of the next preconditioner: the invariant subspace found here
+        self.restart = vects[:, 0].real + vects[:, 1].real + vects[:, 1].imag
+        return lam, np.ascontiguousarray(null_comp.real), used
 
     def apply(self, v, out=None):
         eng = self.eng

@@ -80,7 +80,7 @@ def test_phosphorus_comp_fcn(golden_dir):
 
 @pytest.mark.parametrize("tag", ["22x9", "70x12"])
 def test_phosphorus_preconditioner(golden_dir, tag):
-    """shifted block solves, the eigen-pair from subspace inverse iteration on the device
+    """shifted block solves, the eigen-pair from shift-invert Arnoldi on the device
     solver, and the assembled preconditioner against the oracle (sparse direct + ARPACK)"""
     from oracle.krylov import Regions
     from oracle.model import apply_precond_phosphorus, phosphorus_precond_matrix
