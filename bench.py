@@ -133,7 +133,7 @@ def main():
 
         if args.warmup > 0:
             run(args.warmup, "krylov_warm")
-        eng.profile_reset(32)
+        eng.profile_reset(8)
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -154,10 +154,11 @@ def main():
 
         if rank == 0:
             total_jvps = args.steps * world
-            bytes_per_launch = prof["bytes"] / max(prof["launches"], 1)
-            # an event pair around one launch also times the event machinery itself; the
-            # empty-pair reading taken on the same stream is subtracted
-            kernel_us = max(prof["avg_us"] - prof["event_overhead_us"], 1e-3)
+            # HIP-event windows around back-to-back launches of the kernel on the context's stream
+            # (nk2d_profile_reset/read): per-launch time net of the event machinery, and the
+            # algorithmic bytes of exactly those launches
+            bytes_per_launch = prof["bytes"] / max(prof["samples"], 1)
+            kernel_us = max(prof["avg_us"], 1e-3)
             achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
             traffic = None
             pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")
@@ -196,7 +197,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic,
                     "avg_launch_us": kernel_us,
-                    "event_pair_raw_us": prof["avg_us"],
+                    "event_windows": prof["windows"],
                     "event_pair_empty_us": prof["event_overhead_us"],
                     "event_samples": prof["samples"],
                     "launches": prof["launches"],

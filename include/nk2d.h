@@ -170,14 +170,17 @@ int nk2d_lin_comb(nk2d_ctx* ctx, nk2d_vec out, int32_t n, const nk2d_vec* vecs,
 int nk2d_mgs(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* h_out);
 int nk2d_apply_region_mask(nk2d_ctx* ctx, nk2d_vec v);
 
-/* Measurement plumbing (bench.py): time every every_n-th launch of the dominant kernel
-   (the line-relaxation sweep) with a HIP event pair on the context's stream, and count the
-   algorithmic bytes of all sweep launches.  every_n = 0 switches sampling off. */
+/* Measurement plumbing (bench.py): time every every_n-th WINDOW of the dominant kernel
+   (k_newton_fused) with a HIP event pair on the context's stream.  A window is the launches of one
+   simplified-Newton iteration that are queued back to back with nothing between them (first
+   iteration of a step attempt).  every_n = 0 switches sampling off. */
 int nk2d_profile_reset(nk2d_ctx* ctx, int32_t every_n);
-/* avg_us: mean elapsed time of the sampled event pairs; overhead_us: what an EMPTY event
-   pair reads on this stream (subtract it to get the kernel's own duration) */
+/* avg_us: (window times - one empty-pair reading per window) / launches inside the windows;
+   samples: those launches; windows: timed windows; bytes: algorithmic bytes of the launches in
+   the windows; launches: all launches of the kernel since the reset; overhead_us: what an EMPTY
+   event pair reads on this stream */
 int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
-                      double* overhead_us);
+                      double* overhead_us, int64_t* windows);
 
 /* run-time options: "lin_tol" (relative accuracy of the inner line-relaxation solves),
    "device_ctl" (1: take the Newton convergence decisions on the device and read back once

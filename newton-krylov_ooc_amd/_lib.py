@@ -114,7 +114,7 @@ SIGNATURES = {
     "nk2d_mgs": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
     "nk2d_apply_region_mask": (_ci, [_vp, _vp]),
     "nk2d_profile_reset": (_ci, [_vp, _i32]),
-    "nk2d_profile_read": (_ci, [_vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p]),
+    "nk2d_profile_read": (_ci, [_vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p, c_int64_p]),
     "nk2d_set_option": (_ci, [_vp, ctypes.c_char_p, _d]),
     "nk2d_sync": (_ci, [_vp]),
     "nk2d_stream": (_vp, [_vp]),

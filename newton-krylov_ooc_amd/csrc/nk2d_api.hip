@@ -178,21 +178,28 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     c->prof_used = 0;
     c->prof_ms_sum = 0.0;
     c->prof_cnt = 0;
+    c->prof_windows = 0;
+    c->prof_win_launches.clear();
+    c->win_open = 0;
+    c->win_seq = 0;
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
     return 0;
 }
 
 extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
-                                 double* overhead_us) {
+                                 double* overhead_us, int64_t* windows) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     NK2D_TRY(nk2d_profile_collect(c));
-    if (avg_us) *avg_us = c->prof_cnt > 0 ? 1000.0 * c->prof_ms_sum / (double)c->prof_cnt : 0.0;
+    // per launch: (sum of window times - one empty-pair reading per window) / launches in the windows
+    const double net_ms = c->prof_ms_sum - (double)c->prof_windows * c->prof_overhead_ms;
+    if (avg_us) *avg_us = c->prof_cnt > 0 ? 1000.0 * net_ms / (double)c->prof_cnt : 0.0;
     if (overhead_us) *overhead_us = 1000.0 * c->prof_overhead_ms;
     if (samples) *samples = c->prof_cnt;
     if (launches) *launches = c->sweep_launches;
     if (bytes) *bytes = c->sweep_bytes;
+    if (windows) *windows = c->prof_windows;
     return 0;
 }
 
@@ -347,6 +354,9 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->prof_ms_sum = 0.0;
     c->prof_overhead_ms = 0.0;
     c->prof_cnt = 0;
+    c->prof_windows = 0;
+    c->win_open = 0;
+    c->win_seq = 0;
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
     *out = c;  // returned even on failure so that nk2d_last_error can be read

@@ -120,8 +120,13 @@ struct nk2d_ctx {
     double prof_ms_sum;
     double prof_overhead_ms;          // elapsed time of an EMPTY event pair (calibration)
     int64_t prof_cnt;
-    int64_t sweep_launches;           // since the last nk2d_profile_reset
-    double sweep_bytes;               // algorithmic bytes of those launches
+    int64_t sweep_launches;           // launches of the dominant kernel since the last nk2d_profile_reset
+    double sweep_bytes;               // algorithmic bytes of the launches inside timed windows
+    int64_t prof_windows;             // timed windows folded into prof_ms_sum (prof_cnt: their launches)
+    std::vector<int> prof_win_launches;
+    int win_open, win_launches;
+    int64_t win_seq;
+    double win_bytes;
 };
 
 #define NK2D_CHECK(ctx, call)                                                        \
@@ -413,6 +418,8 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci);
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
 int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out);
+int nk2d_prof_window_begin(nk2d_ctx* c);
+int nk2d_prof_window_end(nk2d_ctx* c);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
 int nk2d_profile_collect(nk2d_ctx* c);

@@ -754,9 +754,11 @@ int nk2d_profile_collect(nk2d_ctx* c) {
         float ms = 0.f;
         NK2D_CHECK(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
         c->prof_ms_sum += ms;
-        c->prof_cnt++;
+        c->prof_windows++;
+        c->prof_cnt += c->prof_win_launches[i / 2];
     }
     c->prof_used = 0;
+    c->prof_win_launches.clear();
     return 0;
 }
 
@@ -1396,20 +1398,41 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         if (!first) words += 3.0 * N;
         if (!do_update) words += 3.0 * N;
         if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;
-        c->sweep_bytes += 8.0 * words;
         c->sweep_launches++;
+        if (c->win_open) {
+            c->win_launches++;
+            c->win_bytes += 8.0 * words;
+        }
     }
-    const bool sample = c->prof_every > 0 && (c->sweep_launches % c->prof_every) == 0 &&
-                        c->prof_used + 2 <= c->prof_ev.size();
-    if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     NK2D_CHECK(c, hipGetLastError());
-    if (sample) {
-        NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
-        c->prof_used += 2;
-    }
     c->st.nlaunch++;
     c->st.nsweeps++;
+    return 0;
+}
+
+// Timing windows of the dominant kernel: an event pair around the launches of one simplified-
+// Newton iteration that are queued back to back with nothing else between them (the first
+// iteration of a step attempt: stage+sweep ... sweep+update).  Per-launch time = (elapsed - reading
+// of an empty event pair) / launches in the window, so it includes the hand-over from one launch
+// to the next, as the per-kernel durations of rocprofv3 do.  Every prof_every-th window is timed.
+int nk2d_prof_window_begin(nk2d_ctx* c) {
+    c->win_open = 0;
+    if (c->prof_every <= 0 || c->prof_used + 2 > c->prof_ev.size()) return 0;
+    if ((c->win_seq++ % c->prof_every) != 0) return 0;
+    NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
+    c->win_open = 1;
+    c->win_launches = 0;
+    c->win_bytes = 0.0;
+    return 0;
+}
+int nk2d_prof_window_end(nk2d_ctx* c) {
+    if (!c->win_open) return 0;
+    c->win_open = 0;
+    NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used + 1], c->stream));
+    c->prof_win_launches.push_back(c->win_launches);
+    c->sweep_bytes += c->win_bytes;
+    c->prof_used += 2;
     return 0;
 }
 

@@ -174,9 +174,14 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     bool front_queued = false;
     int k = -1;
     for (k = 0; k < kmax; ++k) {
-        if (!front_queued) NK2D_TRY(newton_front(s, mreal, mcr, mci));
+        const bool timed = !front_queued;   // front and back launches are queued back to back
+        if (timed) {
+            NK2D_TRY(nk2d_prof_window_begin(c));
+            NK2D_TRY(newton_front(s, mreal, mcr, mci));
+        }
         front_queued = false;
         NK2D_TRY(newton_back(s, mreal, mcr, mci));
+        if (timed) NK2D_TRY(nk2d_prof_window_end(c));
         c->st.nfev += 3;
         c->st.nnewton++;
         if (force_iters >= 0) continue;

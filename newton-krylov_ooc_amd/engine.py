@@ -223,14 +223,16 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_profile_reset(self._ctx, int(every_n)))
 
     def profile_read(self):
+        """timing windows of the dominant kernel since profile_reset: `avg_us` per launch (net of
+        the event overhead), `bytes` algorithmic bytes of the `samples` launches in the windows"""
         avg = ctypes.c_double()
-        samples, launches = ctypes.c_int64(), ctypes.c_int64()
+        samples, launches, windows = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         nbytes, ovh = ctypes.c_double(), ctypes.c_double()
         self._chk(self._lib.nk2d_profile_read(self._ctx, ctypes.byref(avg), ctypes.byref(samples),
                                               ctypes.byref(launches), ctypes.byref(nbytes),
-                                              ctypes.byref(ovh)))
+                                              ctypes.byref(ovh), ctypes.byref(windows)))
         return {"avg_us": avg.value, "samples": samples.value, "launches": launches.value,
-                "bytes": nbytes.value, "event_overhead_us": ovh.value}
+                "bytes": nbytes.value, "event_overhead_us": ovh.value, "windows": windows.value}
 
     def comp_fcn_hist(self, x, t_eval, out=None):
         """forward year with dense output: returns (fx, stats, hist [len(t_eval), tc, nz, ny])"""
