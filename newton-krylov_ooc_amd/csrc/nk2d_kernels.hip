@@ -1200,6 +1200,92 @@ __global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* 
     store_col<E>(out, task, lane, ff);
 }
 
+// ---------------------------------------------------------------------------------
+// Fused error estimate (radau.py:477-481) for solves of at most two sweeps:
+//   launch 0: right-hand side f + Z^T E / h formed in registers, first line sweep (no lateral
+//             terms) -> x1
+//   launch 1: x2 = x1 + T^-1 (lateral couplings of x1)                    (two-sweep solves only)
+//   last    : sum((x / (atol + max(|y|, |y + Z2|) rtol))^2) partial, x stored for the filter pass
+// Two launches per step instead of four (right-hand side, two sweeps, norm).
+// ---------------------------------------------------------------------------------
+struct ErrArgs {
+    SweepArgs sw;          // real system: planes, factor, ping-pong iterates
+    const double *f, *z, *y;
+    size_t nv;
+    double h;
+    double* part;
+    int stage;             // 0: first launch, 1: second
+    int last;              // this launch ends the solve
+};
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    double r[E], x1[E], a[E], cc[E];
+    {
+        double jl[E], ju[E];
+        load_col<E>(A.sw.JL, j, lane, jl);
+        load_col<E>(A.sw.JU, j, lane, ju);
+        line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
+    }
+    if (A.stage == 0) {
+        double z0[E], z1[E], z2[E];
+        load_col<E>(A.f, task, lane, r);
+        load_col<E>(A.z, task, lane, z0);
+        load_col<E>(A.z + A.nv, task, lane, z1);
+        load_col<E>(A.z + 2 * A.nv, task, lane, z2);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / A.h;
+            r[e] = r[e] + ze;
+        }
+    } else {
+        const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+        double js[E], jn[E], xs[E], xn[E];
+        load_col<E>(A.sw.JS, j, lane, js);
+        load_col<E>(A.sw.JN, j, lane, jn);
+        load_col<E>(A.sw.xr_old, cs_col, lane, xs);
+        load_col<E>(A.sw.xr_old, cn_col, lane, xn);
+        load_col<E>(A.sw.xr_old, task, lane, x1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], js[e] * xs[e]);
+        if constexpr (KIND == 1) {
+            double upr[E];
+            load_col<E>(P.UPR, j, lane, upr);
+            phos_couple<E>(P, tr, j, lane, A.sw.xr_old, upr, r);
+        }
+    }
+    {
+        double inv[E], tab[NK2D_TAB];
+        load_col<E>(A.sw.fr_inv, task, lane, inv);
+        load_tab<E>(A.sw.fr_tab, task, lane, tab);
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = ((lane * E + e) < P.nz) ? r[e] : 0.0;
+        tridiag_apply<E, double>(a, cc, inv, tab, r, lane);
+    }
+    if (A.stage == 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = x1[e] + r[e];
+    }
+    store_col<E>(A.sw.xr_new, task, lane, r);
+    if (!A.last) return;
+    double yy[E], z2[E];
+    load_col<E>(A.y, task, lane, yy);
+    load_col<E>(A.z + 2 * A.nv, task, lane, z2);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double yn = yy[e] + z2[e];
+        const double sc = P.atol + fmax(fabs(yy[e]), fabs(yn)) * P.rtol;
+        const double q = r[e] / sc;
+        acc += q * q;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) A.part[task] = acc;
+}
+
 // filtered error estimate right-hand side  fun(t, y + error) + Z^T E / h  (radau.py:485-487)
 template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK)
@@ -1443,6 +1529,33 @@ int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
     c->st.nlaunch++;
     return 0;
 }
+// error estimate of a solve with m <= 2 sweeps in m launches; the solution ends in XR[*buf] and
+// its norm partials in PART / hPART
+int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf) {
+    ErrArgs A = {};
+    fill_factor_args(c, A.sw);
+    A.f = c->F; A.z = c->Z; A.y = c->Y;
+    A.nv = c->nv;
+    A.h = h;
+    A.part = c->part_on_host ? c->hPART : c->PART;
+    DevP P = make_devp(c);
+    int src = 0;
+    for (int it = 0; it < m; ++it) {
+        A.sw.xr_old = c->XR[src];
+        A.sw.xr_new = c->XR[1 - src];
+        A.stage = it;
+        A.last = (it == m - 1) ? 1 : 0;
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_err_fused<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        NK2D_CHECK(c, hipGetLastError());
+        c->st.nlaunch++;
+        c->st.nsweeps++;
+        src = 1 - src;
+    }
+    *buf = src;
+    c->st.nsolve++;
+    return 0;
+}
+
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
     DevP P = make_devp(c);
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_err_rhs2<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,

@@ -233,9 +233,13 @@ int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* ra
         NK2D_TRY(nk2d_r_reduce_newton(c));
     }
     c->cur_guard = c->ICTL + 5;  // skip_err (cleared by a converged Newton iteration)
-    NK2D_TRY(nk2d_r_err_rhs(c, h));
-    NK2D_TRY(solve_systems(s, true, false, err_buf));
-    NK2D_TRY(nk2d_r_err_norm(c, c->XR[*err_buf]));
+    if (s.m_real <= 2) {
+        NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf));
+    } else {
+        NK2D_TRY(nk2d_r_err_rhs(c, h));
+        NK2D_TRY(solve_systems(s, true, false, err_buf));
+        NK2D_TRY(nk2d_r_err_norm(c, c->XR[*err_buf]));
+    }
     NK2D_TRY(nk2d_r_reduce_err(c));
     c->cur_guard = nullptr;
     double d[8];
@@ -409,9 +413,13 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // together with the attempt
             double sum = err_sum;
             if (s.device_ctl != 1) {
-                NK2D_TRY(nk2d_r_err_rhs(c, h));
-                NK2D_TRY(solve_systems(s, true, false, &buf));
-                NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
+                if (s.m_real <= 2) {
+                    NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf));
+                } else {
+                    NK2D_TRY(nk2d_r_err_rhs(c, h));
+                    NK2D_TRY(solve_systems(s, true, false, &buf));
+                    NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
+                }
                 NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
             }
             err = rms_from_sum(sum, s.n_total);
