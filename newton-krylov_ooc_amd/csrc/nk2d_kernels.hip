@@ -1328,6 +1328,41 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     store_col<E>(out, task, lane, ff);
 }
 
+// accepted step: y_new = y + Z2 and f_new = fun(t_new, y_new) in one pass (radau.py:509-521); the
+// lateral neighbours' y_new are formed on the fly, each wave stores its own column
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK)
+    k_commit_tend(DevP P, const double* __restrict__ y, const double* __restrict__ z2, const double* __restrict__ kvp,
+                  double* __restrict__ ynew, double* __restrict__ f) {
+    TASK_PROLOGUE(P.ncol)
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double c[E], cs[E], cn[E], t0[E], kv[E], ff[E];
+    load_col<E>(y, task, lane, c);
+    load_col<E>(z2, task, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
+    store_col<E>(ynew, task, lane, c);
+    load_col<E>(y, cs_col, lane, cs);
+    load_col<E>(z2, cs_col, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) cs[e] = cs[e] + t0[e];
+    load_col<E>(y, cn_col, lane, cn);
+    load_col<E>(z2, cn_col, lane, t0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
+    load_col<E>(kvp, j, lane, kv);
+    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    if constexpr (KIND == 1) {
+        double po4[E], dop[E], pop[E];
+        load_trio<E>(P, y, z2, j, lane, po4, dop, pop);
+        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, ff);
+    }
+    store_col<E>(f, task, lane, ff);
+}
+
 // sum((err / (atol + max(|y|, |y + Z2|) rtol))^2)  (radau.py:480-481)
 template <int E>
 __global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
@@ -1560,6 +1595,16 @@ int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
     DevP P = make_devp(c);
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_err_rhs2<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
                                                c->Y, err, c->KV[3], c->Z, c->nv, h, c->BR));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+// y_new = Y + Z[2] -> YOLD (the spare buffer), F = fun(., y_new) with the plane kv
+int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv) {
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_commit_tend<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P,
+                                               c->Y, c->Z + 2 * c->nv, kv, c->YOLD, c->F));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;

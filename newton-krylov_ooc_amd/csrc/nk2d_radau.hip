@@ -335,10 +335,12 @@ int initial_step(Ctl& s, double* h_out) {
     return 0;
 }
 
-// commit an accepted step: y_old <- y, y <- y + Z2, Z_prev <- Z
-int commit_step(Ctl& s, double t, double t_new) {
+// commit an accepted step: y_old <- y, y <- y + Z2, Z_prev <- Z.  with_tend: also F <- fun(t_new,
+// y_new) in the same launch; KV[3] must then hold the vertical mixing plane at t_new.
+int commit_step(Ctl& s, double t, double t_new, bool with_tend = false) {
     nk2d_ctx* c = s.c;
-    NK2D_TRY(nk2d_r_axpy(c, c->Y, 1.0, c->Z + 2 * c->nv, c->YOLD));  // y_new into the spare buffer
+    if (with_tend) NK2D_TRY(nk2d_r_commit_tend(c, c->KV[3]));
+    else NK2D_TRY(nk2d_r_axpy(c, c->Y, 1.0, c->Z + 2 * c->nv, c->YOLD));  // y_new into the spare buffer
     std::swap(c->Y, c->YOLD);                                          // Y = y_new, YOLD = y
     std::swap(c->Z, c->ZP);                                            // ZP = Z of this step
     s.have_dense = true;
@@ -455,12 +457,11 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         }
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
-        NK2D_TRY(commit_step(s, t, t_new));
-        if (c->hist_n > 0) NK2D_TRY(nk2d_hist_sample(c, t, t_new, nrec == 1));
         if (t + h == t_new) std::swap(c->KV[3], c->KV[2]);  // stage-3 plane is the plane at t_new
         else NK2D_TRY(eval_kv(c, t_new, 3));
-        NK2D_TRY(nk2d_k_tend(c, c->Y, c->KV[3], c->F));
+        NK2D_TRY(commit_step(s, t, t_new, true));
         c->st.nfev++;
+        if (c->hist_n > 0) NK2D_TRY(nk2d_hist_sample(c, t, t_new, nrec == 1));
         if (recompute_jac) {
             NK2D_TRY(refresh_jac(s, t_new, true));
             c->st.njev++;
