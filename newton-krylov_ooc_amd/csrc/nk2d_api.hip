@@ -287,6 +287,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
     c->part_on_host = 0;
     c->speculate = 1;
+    c->factor_pending = 0;
+    c->lu_cre = c->lu_ccr = c->lu_cci = 0.0;
     c->rcoef_elems = 0;
     c->RCOEF = nullptr;
     c->hRCOEF = nullptr;

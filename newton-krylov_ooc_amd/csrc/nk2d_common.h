@@ -85,6 +85,8 @@ struct nk2d_ctx {
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
     int part_on_host;
+    int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch
+    double lu_cre, lu_ccr, lu_cci;  // shifts of the current line factorisation
     int speculate;   // 1: queue the next Newton iteration's front launches before reading the norm
     // freed state vectors kept for reuse (nk2d_vec_alloc / nk2d_vec_free)
     std::vector<double*> vec_pool;

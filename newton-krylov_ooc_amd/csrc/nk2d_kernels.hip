@@ -491,6 +491,31 @@ __device__ __forceinline__ void line_offdiag(const DevP& P, int tr, int lane, co
     }
 }
 
+// real part of the diagonal of the column tridiagonal: shift - JC + module terms; identity rows
+// past the column end
+template <int E, int KIND>
+__device__ __forceinline__ void line_diag(const DevP& P, const double* __restrict__ JC, int tr, int j, int lane,
+                                          double shift_re, double (&dre)[E]) {
+    double jc[E], upr[E], dzr[E];
+    load_col<E>(JC, j, lane, jc);
+    if constexpr (KIND == 1) {
+        load_col<E>(P.UPR, j, lane, upr);
+        load_col<E>(P.DZR, 0, lane, dzr);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        double d = (shift_re - jc[e]) + P.decay[tr];
+        if (k == 0) d = d + P.surf[tr];
+        if constexpr (KIND == 1) {
+            if (tr == 0) d = d + upr[e];
+            else if (tr == 1) d = d + P.ph_rd;
+            else d = d + (P.ph_rp + ((k < P.nz - 1) ? P.ph_vs * dzr[e] : 0.0));
+        }
+        dre[e] = (k < P.nz) ? d : 1.0;
+    }
+}
+
 // coupling between the tracers of the phosphorus module, kept on the right-hand side of the
 // line relaxation: r += (d tend[tr] / d other tracers) * x_old  (phosphorus.py:119-140)
 template <int E>
@@ -562,30 +587,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     const bool is_c = var >= A.nreal / P.ny;
     const int tr = is_c ? var - A.nreal / P.ny : var;
     const int col = tr * P.ny + j;
-    double jl[E], ju[E], jc[E], a[E], cc[E], dre[E];
+    double jl[E], ju[E], a[E], cc[E], dre[E];
     load_col<E>(A.JL, j, lane, jl);
     load_col<E>(A.JU, j, lane, ju);
-    load_col<E>(A.JC, j, lane, jc);
     line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
-    double upr[E], dzr[E];
-    if constexpr (KIND == 1) {
-        load_col<E>(P.UPR, j, lane, upr);
-        load_col<E>(P.DZR, 0, lane, dzr);
-    }
-    const double shift_re = is_c ? A.ccr : A.cre;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int k = lane * E + e;
-        const bool valid = k < P.nz;
-        double d = (shift_re - jc[e]) + P.decay[tr];
-        if (k == 0) d = d + P.surf[tr];
-        if constexpr (KIND == 1) {
-            if (tr == 0) d = d + upr[e];
-            else if (tr == 1) d = d + P.ph_rd;
-            else d = d + (P.ph_rp + ((k < P.nz - 1) ? P.ph_vs * dzr[e] : 0.0));
-        }
-        dre[e] = valid ? d : 1.0;
-    }
+    line_diag<E, KIND>(P, A.JC, tr, j, lane, is_c ? A.ccr : A.cre, dre);
     if (!is_c) {
         double inv[E], tab[NK2D_TAB];
         tridiag_factor<E, double>(a, cc, dre, inv, tab, lane);
@@ -704,6 +710,7 @@ int nk2d_k_jac_apply(nk2d_ctx* c, const double* v, double* out) {
 }
 
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci) {
+    c->factor_pending = 0;
     SweepArgs A = {};
     fill_factor_args(c, A);
     A.cre = cre; A.ccr = ccr; A.cci = cci;
@@ -1010,7 +1017,7 @@ struct FusedArgs {
     int delta;
 };
 
-template <int E, int KIND>
+template <int E, int KIND, int FACTOR>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
     GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
@@ -1102,11 +1109,22 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             phos_couple<E>(P, tr, j, lane, A.sw.xci_old, upr, fci);
         }
     }
-    // real system
+    // real system.  FACTOR: this launch is the first one after SciPy's "LU" event -- the pivots and
+    // PCR tables are computed here and stored for the launches that follow (no k_factor launch)
     {
         double inv[E], tab[NK2D_TAB];
-        load_col<E>(A.sw.fr_inv, task, lane, inv);
-        load_tab<E>(A.sw.fr_tab, task, lane, tab);
+        if constexpr (FACTOR) {
+            double dre[E];
+            line_diag<E, KIND>(P, A.sw.JC, tr, j, lane, A.sw.cre, dre);
+            tridiag_factor<E, double>(a, cc, dre, inv, tab, lane);
+            store_col<E>(A.sw.fr_inv, task, lane, inv);
+            double* p = A.sw.fr_tab + (size_t)task * (NK2D_TAB * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
+        } else {
+            load_col<E>(A.sw.fr_inv, task, lane, inv);
+            load_tab<E>(A.sw.fr_tab, task, lane, tab);
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) fr[e] = ((lane * E + e) < P.nz) ? fr[e] : 0.0;
         tridiag_apply<E, double>(a, cc, inv, tab, fr, lane);
@@ -1114,19 +1132,38 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     // complex system
     {
         cplx r[E], inv[E], tab[NK2D_TAB];
-        double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
-        load_col<E>(A.sw.fc_invr, task, lane, t0);
-        load_col<E>(A.sw.fc_invi, task, lane, t1);
-        load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
-        load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+        if constexpr (FACTOR) {
+            double dre[E];
+            cplx d[E];
+            line_diag<E, KIND>(P, A.sw.JC, tr, j, lane, A.sw.ccr, dre);
+#pragma unroll
+            for (int e = 0; e < E; ++e) d[e] = c_make(dre[e], ((lane * E + e) < P.nz) ? A.sw.cci : 0.0);
+            tridiag_factor<E, cplx>(a, cc, d, inv, tab, lane);
+            double re[E], im[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { re[e] = inv[e].re; im[e] = inv[e].im; }
+            store_col<E>(A.sw.fc_invr, task, lane, re);
+            store_col<E>(A.sw.fc_invi, task, lane, im);
+            double* pr = A.sw.fc_tabr + (size_t)task * (NK2D_TAB * 64) + lane;
+            double* pi = A.sw.fc_tabi + (size_t)task * (NK2D_TAB * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; }
+        } else {
+            double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
+            load_col<E>(A.sw.fc_invr, task, lane, t0);
+            load_col<E>(A.sw.fc_invi, task, lane, t1);
+            load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
+            load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) inv[e] = c_make(t0[e], t1[e]);
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool valid = (lane * E + e) < P.nz;
-            inv[e] = c_make(t0[e], t1[e]);
             r[e] = c_make(valid ? fcr[e] : 0.0, valid ? fci[e] : 0.0);
         }
-#pragma unroll
-        for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
         tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
 #pragma unroll
         for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
@@ -1501,6 +1538,14 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     A.do_stage = do_stage ? 1 : 0;
     A.do_update = do_update ? 1 : 0;
     A.delta = delta ? 1 : 0;
+    // pivots / PCR tables of a new (h, J): computed inside the first launch that uses them
+    bool do_factor = c->factor_pending != 0;
+    if (do_factor && !do_stage) {  // not expected: the first launch after an "LU" event evaluates the stages
+        NK2D_TRY(nk2d_k_factor(c, true, true, c->lu_cre, c->lu_ccr, c->lu_cci));
+        do_factor = false;
+    }
+    A.sw.cre = c->lu_cre; A.sw.ccr = c->lu_ccr; A.sw.cci = c->lu_cci;
+    c->factor_pending = 0;
     DevP P = make_devp(c);
     {
         // algorithmic (unique) bytes of this launch, P = nz*ny cells, N = tc*P values:
@@ -1514,7 +1559,8 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
         double words = 0.0;
         if (do_stage) words += 7.0 * N + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * N);
-        words += (first ? 2.0 : 4.0) * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N;
+        words += (first ? 2.0 : 4.0) * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N;  // factor read, or written when computed here
+        if (do_factor) words += Pc;                                             // JC
         if (!do_stage && !delta) words += 3.0 * N;
         if (!first) words += 3.0 * N;
         if (!do_update) words += 3.0 * N;
@@ -1525,7 +1571,11 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
             c->win_bytes += 8.0 * words;
         }
     }
-    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    if (do_factor) {
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    } else {
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    }
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     c->st.nsweeps++;

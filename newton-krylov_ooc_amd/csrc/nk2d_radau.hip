@@ -70,7 +70,10 @@ int set_lu(Ctl& s, double h) {
     s.m_real = nk2d_sweeps_for(s.c, MU_REAL / h);
     s.m_cplx = nk2d_sweeps_for(s.c, MU_CR / h);
     s.c->st.nlu += 2;
-    return nk2d_k_factor(s.c, true, true, MU_REAL / h, MU_CR / h, MU_CI / h);
+    // the factorisation itself happens inside the first fused Newton launch that needs it
+    s.c->lu_cre = MU_REAL / h; s.c->lu_ccr = MU_CR / h; s.c->lu_cci = MU_CI / h;
+    s.c->factor_pending = 1;
+    return 0;
 }
 
 // x = ((mu/h_lu) I - J)^-1 b for the real and/or the complex system; result in
