@@ -172,8 +172,7 @@ __device__ __forceinline__ double ramp2(double x, double x0, double x1, double y
 }
 
 template <int E>
-__global__ void k_vmix(DevP P, VmixArgs A, int nt) {
-    TASK_PROLOGUE(P.ny * nt)
+__device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int task, int lane) {
     const int ti = task / P.ny, j = task - ti * P.ny;
     const double frac = A.frac[ti];
     const double bld = A.bldmin + (P.BLDMAX[j] - A.bldmin) * frac;
@@ -219,6 +218,12 @@ __global__ void k_vmix(DevP P, VmixArgs A, int nt) {
         kv[e] = val;
     }
     store_col<E>(A.out[ti], j, lane, kv);
+}
+
+template <int E>
+__global__ void k_vmix(DevP P, VmixArgs A, int nt) {
+    TASK_PROLOGUE(P.ny * nt)
+    vmix_body<E>(P, A, task, lane);
 }
 
 int nk2d_k_vmix(nk2d_ctx* c, int nt, const double* times, double* const* out) {
@@ -948,11 +953,22 @@ int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8) {
 // Radau IIA elementwise kernels (scipy/integrate/_ivp/radau.py)
 // ---------------------------------------------------------------------------------
 // Z0 from the previous step's collocation polynomial, W = TI Z0 (radau.py:445-448,95)
+struct PredictArgs {
+    const double *y, *yold, *zp;
+    double *z, *w;
+    size_t nv;
+    double x0, x1, x2;
+};
+
 template <int E>
-__global__ void k_predict(int ncol, const double* __restrict__ y, const double* __restrict__ yold,
-                          const double* __restrict__ zp, size_t nv, double x0, double x1, double x2,
-                          double* __restrict__ z, double* __restrict__ w) {
-    TASK_PROLOGUE(ncol)
+__device__ __forceinline__ void predict_body(const PredictArgs& A, int task, int lane) {
+    const double* __restrict__ y = A.y;
+    const double* __restrict__ yold = A.yold;
+    const double* __restrict__ zp = A.zp;
+    double* __restrict__ z = A.z;
+    double* __restrict__ w = A.w;
+    const size_t nv = A.nv;
+    const double x0 = A.x0, x1 = A.x1, x2 = A.x2;
     double yy[E], yo[E], z0[E], z1[E], z2[E];
     load_col<E>(y, task, lane, yy);
     load_col<E>(yold, task, lane, yo);
@@ -982,6 +998,27 @@ __global__ void k_predict(int ncol, const double* __restrict__ y, const double* 
 #pragma unroll
         for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
         store_col<E>(w + r * nv, task, lane, wv);
+    }
+}
+
+template <int E>
+__global__ void k_predict(int ncol, PredictArgs A) {
+    TASK_PROLOGUE(ncol)
+    predict_body<E>(A, task, lane);
+}
+
+// start of a step attempt in one launch: the vertical mixing planes at the three stage times
+// (first blocks) and the predicted stage values (remaining blocks) are independent of each other
+template <int E>
+__global__ void k_attempt_setup(DevP P, VmixArgs V, int nblk_vmix, PredictArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if ((int)blockIdx.x < nblk_vmix) {
+        const int task = blockIdx.x * wpb + wave;
+        if (task < P.ny * 3) vmix_body<E>(P, V, task, lane);
+    } else {
+        const int task = (blockIdx.x - nblk_vmix) * wpb + wave;
+        if (task < P.ncol) predict_body<E>(A, task, lane);
     }
 }
 
@@ -1513,9 +1550,35 @@ int nk2d_r_dense(nk2d_ctx* c, double x, double* out) {
 }
 
 // --- host wrappers used by the Radau driver --------------------------------------
+static PredictArgs predict_args(nk2d_ctx* c, double x0, double x1, double x2) {
+    PredictArgs A;
+    A.y = c->Y; A.yold = c->YOLD; A.zp = c->ZP; A.z = c->Z; A.w = c->W;
+    A.nv = c->nv;
+    A.x0 = x0; A.x1 = x1; A.x2 = x2;
+    return A;
+}
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
+    PredictArgs A = predict_args(c, x0, x1, x2);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_predict<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
-                                               c->ncol, c->Y, c->YOLD, c->ZP, c->nv, x0, x1, x2, c->Z, c->W));
+                                               c->ncol, A));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+// stage planes at times[0..2] into out[0..2] and the predicted Z, W in one launch
+int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2) {
+    VmixArgs V;
+    for (int i = 0; i < 3; ++i) {
+        nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
+        V.out[i] = out[i];
+    }
+    V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
+    V.hw = c->d.vmix_half_width;
+    PredictArgs A = predict_args(c, x0, x1, x2);
+    DevP P = make_devp(c);
+    const int nblk_vmix = nk2d_grid(c->ny * 3);
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_attempt_setup<EE>, dim3(nblk_vmix + nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0,
+                                              c->stream, P, V, nblk_vmix, A));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;

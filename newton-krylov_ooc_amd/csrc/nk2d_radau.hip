@@ -110,6 +110,19 @@ int predict(Ctl& s, double t, double h) {
     return nk2d_r_predict(c, x[0], x[1], x[2]);
 }
 
+// stage planes + predicted stage values of a step attempt in one launch (needs the dense output
+// of a previous step; the very first step falls back to the two separate calls)
+int setup_attempt(Ctl& s, double t, double h) {
+    nk2d_ctx* c = s.c;
+    double times[3], x[3];
+    for (int i = 0; i < 3; ++i) {
+        times[i] = t + (h * RC[i]);
+        x[i] = ((t + h * RC[i]) - s.dense_t_old) / s.dense_h;
+    }
+    double* out[3] = {c->KV[0], c->KV[1], c->KV[2]};
+    return nk2d_r_attempt_setup(c, times, out, x[0], x[1], x[2]);
+}
+
 int stage_planes(Ctl& s, double t, double h) {
     double times[3];
     for (int i = 0; i < 3; ++i) times[i] = t + (h * RC[i]);
@@ -387,7 +400,14 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             if (t_new - s.t1 > 0) t_new = s.t1;
             h = t_new - t;
             h_abs = std::fabs(h);
-            NK2D_TRY(stage_planes(s, t, h));
+            // host control: planes and prediction of the first try in one launch
+            bool predicted = false;
+            if (s.device_ctl == 0 && s.have_dense) {
+                NK2D_TRY(setup_attempt(s, t, h));
+                predicted = true;
+            } else {
+                NK2D_TRY(stage_planes(s, t, h));
+            }
             bool converged = false;
             double err_sum = 0.0;
             int buf = 0;
@@ -398,7 +418,8 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 } else if (s.device_ctl == 2) {
                     NK2D_TRY(attempt_pipelined(s, t, h, &converged, &n_iter, &rate, &have_rate));
                 } else {
-                    NK2D_TRY(predict(s, t, h));
+                    if (!predicted) NK2D_TRY(predict(s, t, h));
+                    predicted = false;
                     NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate));
                 }
                 if (!converged) {
