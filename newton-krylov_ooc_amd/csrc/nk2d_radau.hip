@@ -204,7 +204,14 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
         double sum = 0.0;
         if (speculate) {
             NK2D_CHECK(c, hipEventRecord(c->snap_ev[0], c->stream));
-            if (k + 1 < kmax) {
+            // queue the next iteration's front launches unless the last known contraction rate says
+            // that the iteration now in flight will pass SciPy's convergence test
+            bool likely_last = false;
+            if (has_rate && rate < 1.0) {
+                const double next_norm = rate * dW_norm_old;
+                likely_last = rate / (1.0 - rate) * next_norm < s.newton_tol;
+            }
+            if (k + 1 < kmax && !likely_last) {
                 NK2D_TRY(newton_front(s, mreal, mcr, mci));
                 front_queued = true;
             }
