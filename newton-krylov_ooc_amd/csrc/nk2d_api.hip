@@ -285,6 +285,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->sweep_wpb = 4;
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART2, sizeof(double) * c->ncol));
     c->part_on_host = 0;
     c->speculate = 1;
     c->factor_pending = 0;
@@ -382,6 +383,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hPART) (void)hipHostFree(c->hPART);
+    if (c->hPART2) (void)hipHostFree(c->hPART2);
     if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
     if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
     if (c->hCTL) (void)hipHostFree(c->hCTL);

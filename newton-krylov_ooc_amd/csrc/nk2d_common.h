@@ -84,6 +84,7 @@ struct nk2d_ctx {
     double* RED;     // reduced scalars (device)
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
+    double* hPART2;  // same, for an error estimate queued behind a Newton iteration not yet judged
     int part_on_host;
     int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch
     double lu_cre, lu_ccr, lu_cci;  // shifts of the current line factorisation
@@ -419,8 +420,8 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
                  const double* br, const double* bcr, const double* bci, int src);
 int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double ccr, double cci);
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
-int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out);
-int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf);
+int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part);
+int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part);
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2);
 int nk2d_prof_window_begin(nk2d_ctx* c);

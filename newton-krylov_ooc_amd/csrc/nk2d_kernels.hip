@@ -812,11 +812,12 @@ __global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, 
 // sum of the per-column partials the producing kernel wrote into pinned host memory; the caller
 // has waited for that kernel.  Same association as k_reduce (strided partial sums, then a
 // binary tree), so that the host- and the device-controlled integrators see bit-identical norms.
-int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out) {
+int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part) {
+    if (part == nullptr) part = c->hPART;
     double sh[NK2D_BLOCK];
     for (int t = 0; t < NK2D_BLOCK; ++t) {
         double acc = 0.0;
-        for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += c->hPART[i];
+        for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += part[i];
         sh[t] = acc;
     }
     for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1)
@@ -829,7 +830,7 @@ int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
     if (c->part_on_host && host_out && nout == 1) {
         // host-controlled integrator: no reduction launch
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-        return nk2d_part_sum(c, ntasks, host_out);
+        return nk2d_part_sum(c, ntasks, host_out, nullptr);
     }
     // a result the host waits for goes straight into the pinned, device-visible host buffer: no
     // separate device-to-host copy (a blit kernel of its own on this runtime) behind the reduction
@@ -1679,13 +1680,13 @@ int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
 }
 // error estimate of a solve with m <= 2 sweeps in m launches; the solution ends in XR[*buf] and
 // its norm partials in PART / hPART
-int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf) {
+int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part) {
     ErrArgs A = {};
     fill_factor_args(c, A.sw);
     A.f = c->F; A.z = c->Z; A.y = c->Y;
     A.nv = c->nv;
     A.h = h;
-    A.part = c->part_on_host ? c->hPART : c->PART;
+    A.part = part ? part : (c->part_on_host ? c->hPART : c->PART);
     DevP P = make_devp(c);
     int src = 0;
     for (int it = 0; it < m; ++it) {

@@ -179,7 +179,11 @@ int newton_back(Ctl& s, double mreal, double mcr, double mci) {
 // for them the device already runs the front launches of the NEXT iteration; if the iteration
 // stops here they were wasted work on buffers nobody reads.  force_iters is unused here (replay
 // has newton_fixed) but kept for symmetry.
-int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, double* rate_out, bool* have_rate) {
+// err_buf != nullptr: when the known contraction rate predicts that the iteration in flight is the
+// last one, the error estimate is queued right behind it (partials into hPART2); *err_buf >= 0 on
+// return then names the ping-pong buffer holding it, and the caller only has to wait for snap_ev[1].
+int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, double* rate_out, bool* have_rate,
+           int* err_buf = nullptr) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
     double dW_norm_old = 0.0, rate = 0.0;
@@ -188,8 +192,10 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     const int kmax = force_iters >= 0 ? force_iters : NEWTON_MAXITER;
     const bool speculate = c->part_on_host && force_iters < 0 && c->speculate;
     bool front_queued = false;
+    if (err_buf) *err_buf = -1;
     int k = -1;
     for (k = 0; k < kmax; ++k) {
+        if (err_buf) *err_buf = -1;   // an estimate queued behind a non-final iteration is void
         const bool timed = !front_queued;   // front and back launches are queued back to back
         if (timed) {
             NK2D_TRY(nk2d_prof_window_begin(c));
@@ -214,9 +220,12 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             if (k + 1 < kmax && !likely_last) {
                 NK2D_TRY(newton_front(s, mreal, mcr, mci));
                 front_queued = true;
+            } else if (likely_last && err_buf && s.m_real <= 2) {
+                NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, c->hPART2));
+                NK2D_CHECK(c, hipEventRecord(c->snap_ev[1], c->stream));
             }
             NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[0]));
-            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum));
+            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, nullptr));
         } else {
             NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
         }
@@ -257,7 +266,7 @@ int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* ra
     }
     c->cur_guard = c->ICTL + 5;  // skip_err (cleared by a converged Newton iteration)
     if (s.m_real <= 2) {
-        NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf));
+        NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, nullptr));
     } else {
         NK2D_TRY(nk2d_r_err_rhs(c, h));
         NK2D_TRY(solve_systems(s, true, false, err_buf));
@@ -418,6 +427,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             bool converged = false;
             double err_sum = 0.0;
             int buf = 0;
+            int queued_err = -1;   // >= 0: the error estimate is already queued, in XR[queued_err]
             while (!converged) {
                 if (!s.have_lu) NK2D_TRY(set_lu(s, h));
                 if (s.device_ctl == 1) {
@@ -427,7 +437,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 } else {
                     if (!predicted) NK2D_TRY(predict(s, t, h));
                     predicted = false;
-                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate));
+                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate, &queued_err));
                 }
                 if (!converged) {
                     if (s.current_jac) break;
@@ -445,9 +455,13 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // error estimate (radau.py:477-487); with device control its first pass was queued
             // together with the attempt
             double sum = err_sum;
-            if (s.device_ctl != 1) {
+            if (s.device_ctl == 0 && queued_err >= 0) {
+                buf = queued_err;
+                NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[1]));
+                NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, c->hPART2));
+            } else if (s.device_ctl != 1) {
                 if (s.m_real <= 2) {
-                    NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf));
+                    NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf, nullptr));
                 } else {
                     NK2D_TRY(nk2d_r_err_rhs(c, h));
                     NK2D_TRY(solve_systems(s, true, false, &buf));
