@@ -133,7 +133,7 @@ def main():
 
         if args.warmup > 0:
             run(args.warmup, "krylov_warm")
-        eng.profile_reset(8)
+        eng.profile_reset(1)
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -190,7 +190,7 @@ def main():
                 },
                 "roofline": {
                     "bound": "hbm",
-                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}>",
+                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}, 0, 0>",
                     "achieved": achieved,
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",

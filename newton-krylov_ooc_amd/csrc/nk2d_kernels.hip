@@ -1654,6 +1654,9 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
 int nk2d_prof_window_begin(nk2d_ctx* c) {
     c->win_open = 0;
     if (c->prof_every <= 0 || c->prof_used + 2 > c->prof_ev.size()) return 0;
+    // windows whose first launch also factorises (k_newton_fused<E, KIND, 1>, a different and heavier
+    // kernel) are not timed: the windows measure k_newton_fused<E, KIND, 0> only
+    if (c->factor_pending) return 0;
     if ((c->win_seq++ % c->prof_every) != 0) return 0;
     NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], c->stream));
     c->win_open = 1;
