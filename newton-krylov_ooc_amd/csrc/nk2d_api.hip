@@ -124,6 +124,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
+    if (key == "factor_fp32") { c->factor_fp32 = value != 0.0; return 0; }
     if (key == "sweep_wpb") {
         const int w = (int)value;
         if (w != 1 && w != 2 && w != 4) return nk2d_fail(c, "nk2d_set_option: sweep_wpb must be 1, 2 or 4");
@@ -266,6 +267,13 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->FR_TAB, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABR, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABI, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FR32_INV, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FC32_INVR, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FC32_INVI, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FR32_TAB, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FC32_TABR, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FC32_TABI, (size_t)c->ncol * 14 * 64));
+    c->factor_fp32 = 1;
     NK2D_TRY(dev_alloc(c, &c->TMP, c->nv));
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
@@ -379,6 +387,9 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     for (double* b : c->vec_pool) (void)hipFree(b);
+    float* fbufs[] = {c->FR32_INV, c->FC32_INVR, c->FC32_INVI, c->FR32_TAB, c->FC32_TABR, c->FC32_TABI};
+    for (float* b : fbufs)
+        if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);

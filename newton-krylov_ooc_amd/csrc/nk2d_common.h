@@ -67,6 +67,11 @@ struct nk2d_ctx {
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
     double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
     double *FR_TAB, *FC_TABR, *FC_TABI;   // ncol * NK2D_TAB * 64 each
+    // single precision copies for the fused Newton launches: the line factorisation is an approximate
+    // inverse inside an iteration that re-evaluates the exact residual, its storage precision only
+    // touches the contraction rate (nk2d_set_option "factor_fp32")
+    float *FR32_INV, *FC32_INVR, *FC32_INVI, *FR32_TAB, *FC32_TABR, *FC32_TABI;
+    int factor_fp32;
     // device-side Newton control block (see nk2d_kernels.hip, k_reduce_newton):
     //   DCTL: [0] dW_norm_old [1] rate [2] dW_norm [3] err_sum [4] newton_tol [5] 3n [6] n
     //   ICTL: [0] k [1] has_old [2] has_rate [3] done [4] converged [5] skip_err [6] n_iter

@@ -466,6 +466,9 @@ struct SweepArgs {
     double *xr_new, *xcr_new, *xci_new;
     // cached factorisation (k_factor)
     double *fr_inv, *fc_invr, *fc_invi, *fr_tab, *fc_tabr, *fc_tabi;
+    // single precision copies read by the fused Newton launches (see nk2d_set_option "factor_fp32")
+    float *fr_inv32, *fc_invr32, *fc_invi32, *fr_tab32, *fc_tabr32, *fc_tabi32;
+    int f32;
     double cre, ccr, cci;
     int nreal, ntasks, first;
 };
@@ -475,6 +478,30 @@ __device__ __forceinline__ void load_tab(const double* __restrict__ tab, int col
     const double* p = tab + (size_t)col * (NK2D_TAB * 64) + lane;
 #pragma unroll
     for (int i = 0; i < NK2D_TAB; ++i) t[i] = p[i * 64];
+}
+
+// fp32-stored copies of the factorisation, widened on load
+template <int E>
+__device__ __forceinline__ void load_col32(const float* __restrict__ base, size_t col, int lane, double (&o)[E]) {
+    const float* p = base + col * (size_t)(E * 64) + lane;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = (double)p[e * 64];
+}
+template <int E>
+__device__ __forceinline__ void store_col32(float* __restrict__ base, size_t col, int lane, const double (&v)[E]) {
+    float* p = base + col * (size_t)(E * 64) + lane;
+#pragma unroll
+    for (int e = 0; e < E; ++e) p[e * 64] = (float)v[e];
+}
+__device__ __forceinline__ void load_tab32(const float* __restrict__ tab, int col, int lane, double (&t)[NK2D_TAB]) {
+    const float* p = tab + (size_t)col * (NK2D_TAB * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < NK2D_TAB; ++i) t[i] = (double)p[i * 64];
+}
+__device__ __forceinline__ void store_tab32(float* __restrict__ tab, int col, int lane, const double (&t)[NK2D_TAB]) {
+    float* p = tab + (size_t)col * (NK2D_TAB * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = (float)t[i];
 }
 
 // sub / super diagonal of the column tridiagonal of tracer tr: -(JL + module part), -JU
@@ -604,6 +631,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
         double* p = A.fr_tab + (size_t)col * (NK2D_TAB * 64) + lane;
 #pragma unroll
         for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
+        store_col32<E>(A.fr_inv32, col, lane, inv);
+        store_tab32(A.fr_tab32, col, lane, tab);
     } else {
         cplx d[E], inv[E], tab[NK2D_TAB];
 #pragma unroll
@@ -616,8 +645,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
         store_col<E>(A.fc_invi, col, lane, im);
         double* pr = A.fc_tabr + (size_t)col * (NK2D_TAB * 64) + lane;
         double* pi = A.fc_tabi + (size_t)col * (NK2D_TAB * 64) + lane;
+        double tre[NK2D_TAB], tim[NK2D_TAB];
 #pragma unroll
-        for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; }
+        for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; tre[i] = tab[i].re; tim[i] = tab[i].im; }
+        store_col32<E>(A.fc_invr32, col, lane, re);
+        store_col32<E>(A.fc_invi32, col, lane, im);
+        store_tab32(A.fc_tabr32, col, lane, tre);
+        store_tab32(A.fc_tabi32, col, lane, tim);
     }
 }
 
@@ -702,6 +736,9 @@ static void fill_factor_args(const nk2d_ctx* c, SweepArgs& A) {
     A.JL = c->JL; A.JU = c->JU; A.JS = c->JS; A.JN = c->JN; A.JC = c->JC;
     A.fr_inv = c->FR_INV; A.fc_invr = c->FC_INVR; A.fc_invi = c->FC_INVI;
     A.fr_tab = c->FR_TAB; A.fc_tabr = c->FC_TABR; A.fc_tabi = c->FC_TABI;
+    A.fr_inv32 = c->FR32_INV; A.fc_invr32 = c->FC32_INVR; A.fc_invi32 = c->FC32_INVI;
+    A.fr_tab32 = c->FR32_TAB; A.fc_tabr32 = c->FC32_TABR; A.fc_tabi32 = c->FC32_TABI;
+    A.f32 = c->factor_fp32;
 }
 
 int nk2d_k_jac_apply(nk2d_ctx* c, const double* v, double* out) {
@@ -1159,6 +1196,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             double* p = A.sw.fr_tab + (size_t)task * (NK2D_TAB * 64) + lane;
 #pragma unroll
             for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
+            store_col32<E>(A.sw.fr_inv32, task, lane, inv);
+            store_tab32(A.sw.fr_tab32, task, lane, tab);
+        } else if (A.sw.f32) {
+            load_col32<E>(A.sw.fr_inv32, task, lane, inv);
+            load_tab32(A.sw.fr_tab32, task, lane, tab);
         } else {
             load_col<E>(A.sw.fr_inv, task, lane, inv);
             load_tab<E>(A.sw.fr_tab, task, lane, tab);
@@ -1184,14 +1226,26 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             store_col<E>(A.sw.fc_invi, task, lane, im);
             double* pr = A.sw.fc_tabr + (size_t)task * (NK2D_TAB * 64) + lane;
             double* pi = A.sw.fc_tabi + (size_t)task * (NK2D_TAB * 64) + lane;
+            double tre[NK2D_TAB], tim[NK2D_TAB];
 #pragma unroll
-            for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; }
+            for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; tre[i] = tab[i].re; tim[i] = tab[i].im; }
+            store_col32<E>(A.sw.fc_invr32, task, lane, re);
+            store_col32<E>(A.sw.fc_invi32, task, lane, im);
+            store_tab32(A.sw.fc_tabr32, task, lane, tre);
+            store_tab32(A.sw.fc_tabi32, task, lane, tim);
         } else {
             double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
-            load_col<E>(A.sw.fc_invr, task, lane, t0);
-            load_col<E>(A.sw.fc_invi, task, lane, t1);
-            load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
-            load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+            if (A.sw.f32) {
+                load_col32<E>(A.sw.fc_invr32, task, lane, t0);
+                load_col32<E>(A.sw.fc_invi32, task, lane, t1);
+                load_tab32(A.sw.fc_tabr32, task, lane, tr0);
+                load_tab32(A.sw.fc_tabi32, task, lane, ti0);
+            } else {
+                load_col<E>(A.sw.fc_invr, task, lane, t0);
+                load_col<E>(A.sw.fc_invi, task, lane, t1);
+                load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
+                load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) inv[e] = c_make(t0[e], t1[e]);
 #pragma unroll
@@ -1623,7 +1677,8 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
         double words = 0.0;
         if (do_stage) words += 7.0 * N + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * N);
-        words += (first ? 2.0 : 4.0) * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N;  // factor read, or written when computed here
+        const double fw = (c->factor_fp32 && !do_factor) ? 0.5 : 1.0;  // fp32 copies of the factorisation
+        words += (first ? 2.0 : 4.0) * Pc + fw * (3.0 * N + 3.0 * 14.0 / c->E * N);  // factor read, or written when computed here
         if (do_factor) words += Pc;                                             // JC
         if (!do_stage && !delta) words += 3.0 * N;
         if (!first) words += 3.0 * N;

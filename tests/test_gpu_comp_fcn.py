@@ -88,3 +88,23 @@ def test_controller_variants_take_identical_decisions():
     eng.set_option("jac_fresh", 0)
     assert np.allclose(eng.download(fx), results[0][0], rtol=1e-3, atol=1e-6)
     assert stats["njev"] == stats["nsteps"] + 1 or stats["njev"] >= stats["nsteps"]
+
+
+def test_factor_storage_precision_does_not_move_the_result(golden_dir):
+    """the line factorisation is an approximate inverse inside Newton iterations that re-evaluate
+    the exact residual: reading it from its single precision copy (default) or from the double
+    precision arrays gives the same step-replayed forward year to 1e-11, and both match the oracle"""
+    from oracle import radau
+
+    g = np.load(f"{golden_dir}/comp_fcn_26x26_bumpy.npz")
+    _, tm = oracle_iage(26, 26, 0.1, 1000.0)
+    want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
+    sched = np.array(solver.schedule, dtype=np.float64)
+    got = {}
+    for flag in (0.0, 1.0):
+        eng = make_engine(26, 26, 0.1, 1000.0)
+        eng.set_option("factor_fp32", flag)
+        fx, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=sched)
+        got[flag] = eng.download(fx).reshape(-1)
+        assert rel_err(got[flag], want) < 1e-10
+    assert rel_err(got[1.0], got[0.0]) < 1e-11
