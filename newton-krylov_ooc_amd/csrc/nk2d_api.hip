@@ -124,7 +124,11 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
-    if (key == "factor_fp32") { c->factor_fp32 = value != 0.0; return 0; }
+    if (key == "factor_fp32") {
+        // the single precision copy is written by the next factorisation: drop the cached one
+        c->factor_fp32 = value != 0.0;
+        return 0;
+    }
     if (key == "sweep_wpb") {
         const int w = (int)value;
         if (w != 1 && w != 2 && w != 4) return nk2d_fail(c, "nk2d_set_option: sweep_wpb must be 1, 2 or 4");
@@ -273,7 +277,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->FR32_TAB, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC32_TABR, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC32_TABI, (size_t)c->ncol * 14 * 64));
-    c->factor_fp32 = 1;
+    c->factor_fp32 = 0;
     NK2D_TRY(dev_alloc(c, &c->TMP, c->nv));
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));

@@ -631,8 +631,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
         double* p = A.fr_tab + (size_t)col * (NK2D_TAB * 64) + lane;
 #pragma unroll
         for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
-        store_col32<E>(A.fr_inv32, col, lane, inv);
-        store_tab32(A.fr_tab32, col, lane, tab);
+        if (A.f32) {
+            store_col32<E>(A.fr_inv32, col, lane, inv);
+            store_tab32(A.fr_tab32, col, lane, tab);
+        }
     } else {
         cplx d[E], inv[E], tab[NK2D_TAB];
 #pragma unroll
@@ -648,10 +650,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
         double tre[NK2D_TAB], tim[NK2D_TAB];
 #pragma unroll
         for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; tre[i] = tab[i].re; tim[i] = tab[i].im; }
-        store_col32<E>(A.fc_invr32, col, lane, re);
-        store_col32<E>(A.fc_invi32, col, lane, im);
-        store_tab32(A.fc_tabr32, col, lane, tre);
-        store_tab32(A.fc_tabi32, col, lane, tim);
+        if (A.f32) {
+            store_col32<E>(A.fc_invr32, col, lane, re);
+            store_col32<E>(A.fc_invi32, col, lane, im);
+            store_tab32(A.fc_tabr32, col, lane, tre);
+            store_tab32(A.fc_tabi32, col, lane, tim);
+        }
     }
 }
 
@@ -1196,8 +1200,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             double* p = A.sw.fr_tab + (size_t)task * (NK2D_TAB * 64) + lane;
 #pragma unroll
             for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = tab[i];
-            store_col32<E>(A.sw.fr_inv32, task, lane, inv);
-            store_tab32(A.sw.fr_tab32, task, lane, tab);
+            if (A.sw.f32) {
+                store_col32<E>(A.sw.fr_inv32, task, lane, inv);
+                store_tab32(A.sw.fr_tab32, task, lane, tab);
+            }
         } else if (A.sw.f32) {
             load_col32<E>(A.sw.fr_inv32, task, lane, inv);
             load_tab32(A.sw.fr_tab32, task, lane, tab);
@@ -1229,10 +1235,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             double tre[NK2D_TAB], tim[NK2D_TAB];
 #pragma unroll
             for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = tab[i].re; pi[i * 64] = tab[i].im; tre[i] = tab[i].re; tim[i] = tab[i].im; }
-            store_col32<E>(A.sw.fc_invr32, task, lane, re);
-            store_col32<E>(A.sw.fc_invi32, task, lane, im);
-            store_tab32(A.sw.fc_tabr32, task, lane, tre);
-            store_tab32(A.sw.fc_tabi32, task, lane, tim);
+            if (A.sw.f32) {
+                store_col32<E>(A.sw.fc_invr32, task, lane, re);
+                store_col32<E>(A.sw.fc_invi32, task, lane, im);
+                store_tab32(A.sw.fc_tabr32, task, lane, tre);
+                store_tab32(A.sw.fc_tabi32, task, lane, tim);
+            }
         } else {
             double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
             if (A.sw.f32) {

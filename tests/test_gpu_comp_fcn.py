@@ -92,8 +92,8 @@ def test_controller_variants_take_identical_decisions():
 
 def test_factor_storage_precision_does_not_move_the_result(golden_dir):
     """the line factorisation is an approximate inverse inside Newton iterations that re-evaluate
-    the exact residual: reading it from its single precision copy (default) or from the double
-    precision arrays gives the same step-replayed forward year to 1e-11, and both match the oracle"""
+    the exact residual: reading it from its single precision copy (option) or from the double
+    precision arrays (default) gives the same step-replayed forward year to 1e-11, and both match the oracle"""
     from oracle import radau
 
     g = np.load(f"{golden_dir}/comp_fcn_26x26_bumpy.npz")

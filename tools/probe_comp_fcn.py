@@ -15,7 +15,7 @@ for n in sizes:
     eng = iage_engine(grid)
     eng.set_option("device_ctl", DEVCTL)
     eng.set_option("jac_fresh", FRESH)
-    eng.set_option("factor_fp32", float(os.environ.get("NK2D_F32", "1")))
+    eng.set_option("factor_fp32", float(os.environ.get("NK2D_F32", "0")))
     col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
     x = eng.upload(y0)
