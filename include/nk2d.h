@@ -12,15 +12,24 @@
  *                                   nk_ooc/model_config.py:249-315
  *   nk2d_vec_*                      one tracer module's values (tracer, depth, ypos),
  *                                   nk_ooc/tracer_module_state_base.py:400-440
- *   nk2d_tend                       TracerModuleState.comp_tend + iage.comp_tend,
+ *   nk2d_tend                       TracerModuleState.comp_tend + iage / forced / phosphorus.comp_tend,
  *                                   nk_ooc/py_driver_2d/tracer_module_state.py:98-108,
- *                                   nk_ooc/py_driver_2d/iage.py:22-41
+ *                                   py_driver_2d/iage.py:22-41, forced.py:114-154, phosphorus.py:58-89
  *   nk2d_vmix_coeff                 VertMix.mixing_coeff, py_driver_2d/vert_mix.py:44-101
  *   nk2d_jacobian_diags             comp_jacobian (five diagonals of the CSR matrix),
  *                                   py_driver_2d/tracer_module_state.py:262-270, iage.py:43-64
  *   nk2d_comp_fcn                   ModelState.comp_fcn's solve_ivp("Radau") year,
  *                                   nk_ooc/py_driver_2d/model_state.py:95-121
- *   nk2d_precond_setup/apply        iage.apply_precond_jacobian, py_driver_2d/iage.py:66-93
+ *   nk2d_comp_fcn_hist              the same year with the 61-sample dense output of the history
+ *                                   file, py_driver_2d/model_state.py:80-83,141-233
+ *   nk2d_set_lin_state / nk2d_jacobian_apply
+ *                                   comp_jacobian(time, tracer_vals) @ v for state dependent modules,
+ *                                   py_driver_2d/phosphorus.py:105-172
+ *   nk2d_precond_setup/apply        iage.apply_precond_jacobian, py_driver_2d/iage.py:66-93 (also
+ *                                   forced.apply_precond_jacobian, forced.py:192-241)
+ *   nk2d_shift_factor/solve         sp_linalg.spsolve(mat - shift * mat_id, .) and the solves inside
+ *                                   sp_linalg.eigs of phosphorus.apply_precond_jacobian,
+ *                                   py_driver_2d/phosphorus.py:233-255
  *   nk2d_dot                        TracerModuleStateBase.dot_prod (weighted region mean),
  *                                   nk_ooc/tracer_module_state_base.py:379-388
  *   nk2d_axpby / nk2d_scale / nk2d_diff_scale
