@@ -1,0 +1,50 @@
+"""N > 1 path with the real engines: two ranks (tracer module per rank, as BASELINE config 4
+distributes them) against the single-process solves of the same modules, and the multi-rank leg of
+bench.py.  The box has one GPU: the ranks share it and the stopping-test collectives run over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(args, port, timeout=400):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NK2D_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return res
+
+
+def test_module_per_rank_matches_single_process(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_gpu_worker
+    from nk_ooc_amd.krylov_solver import KrylovSolver
+
+    _launch([os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path)], 29541)
+    for rank, module in enumerate(dist_gpu_worker.MODULES):
+        got = json.load(open(tmp_path / f"result{rank}.json"))
+        want = dist_gpu_worker.solve_one(str(tmp_path / f"single_{module}"), module, KrylovSolver)
+        assert got["module"] == module and got["iters"] == want["iters"] == 3
+        # same kernels, same decisions: the ranks reproduce the single-process numbers
+        assert np.allclose(got["beta"], want["beta"], rtol=1e-12, atol=0.0)
+        assert np.allclose(got["h_mat"], want["h_mat"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(got["inc_norm"], want["inc_norm"], rtol=1e-9)
+
+
+def test_bench_two_ranks():
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "26",
+                   "--cpu-baseline-seconds", "0"], 29542)
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0.0
+    assert out["config"]["parallelism"].endswith("x2")
+    for key in ("roofline", "metric", "unit", "ms_per_step", "dtype"):
+        assert key in out
+    assert "cpu_baseline" not in out        # timed on rank 0 of single-GPU runs only
