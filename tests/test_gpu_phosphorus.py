@@ -78,6 +78,28 @@ def test_phosphorus_comp_fcn(golden_dir):
     assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
 
 
+def test_phosphorus_preconditioner_with_regions(golden_dir):
+    """three ypos bands as regions: the null-space correction is applied region by region
+    (TracerModuleStateBase.mean / broadcast_region_vals semantics), as in the oracle"""
+    from oracle.krylov import Regions
+    from oracle.model import apply_precond_phosphorus
+
+    g, eng, tm = _setup(golden_dir, "22x9")
+    nz, ny = 22, 9
+    depth, ypos = default_axes(nz, ny)
+    weight = np.outer(depth.delta, ypos.delta)
+    mask = np.ones((nz, ny), dtype=np.int32)
+    mask[:, 3:6] = 2
+    mask[:, 6:] = 3
+    eng.set_region(mask, weight)
+    po4 = g["y"].reshape(3, nz, ny)[0]
+    v = np.random.default_rng(22).standard_normal(3 * nz * ny)
+    eng.precond_setup_state(po4)
+    want, _, _ = apply_precond_phosphorus(tm, Regions(mask, weight), po4, v)
+    got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert rel_err(got, want) < 1e-6
+
+
 @pytest.mark.parametrize("tag", ["22x9", "70x12"])
 def test_phosphorus_preconditioner(golden_dir, tag):
     """shifted block solves, the eigen-pair from shift-invert Arnoldi on the device
