@@ -1096,14 +1096,17 @@ struct FusedArgs {
     int delta;
 };
 
-template <int E, int KIND, int FACTOR>
+// STAGE = 0: instantiation for launches without the stage part.  For the phosphorus module the
+// full kernel needs more registers than two waves per SIMD leave while its 3 ny columns are more
+// waves than the chip has SIMDs; the stage-less instantiation fits and runs in one round.
+template <int E, int KIND, int FACTOR, int STAGE>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
     GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
-    if (A.do_stage) {
+    if (STAGE && A.do_stage) {
         ColCoef<E> cf;
         load_coef<E>(P, j, lane, cf);
         double y0[E], ys[E], yn[E];
@@ -1698,10 +1701,12 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
             c->win_bytes += 8.0 * words;
         }
     }
-    if (do_factor) {
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
-    } else {
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    if (do_factor) {  // always a launch with the stage part
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    } else if (do_stage || c->kind == 0) {
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    } else {          // phosphorus, sweep-only launch: the lean instantiation
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     }
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
