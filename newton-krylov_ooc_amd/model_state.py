@@ -18,6 +18,7 @@ snapshot cache keyed by file name serves re-opens from HBM instead of re-reading
 import logging
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -431,11 +432,22 @@ class ModelState:
             return type(self)(res_fname)
         mods, stats, hists = [], [], []
         t_eval = np.linspace(self.time_range[0], self.time_range[1], 61)
-        for tms in self.tracer_modules:
+
+        def forward_year(tms):
             if hist_fname is None:
-                fx, st, _ = tms.eng.comp_fcn(tms.vec)
-            else:
-                fx, st, hist = tms.eng.comp_fcn_hist(tms.vec, t_eval)
+                return tms.eng.comp_fcn(tms.vec)
+            return tms.eng.comp_fcn_hist(tms.vec, t_eval)
+
+        # the modules are independent (own context, own HIP stream, own host control loop): their
+        # years run concurrently, one host thread each -- a single module leaves most of the chip
+        # idle (less than one wave per SIMD), and the ctypes calls release the GIL
+        if len(self.tracer_modules) > 1 and not os.environ.get("NK2D_SERIAL_MODULES"):
+            with ThreadPoolExecutor(max_workers=len(self.tracer_modules)) as pool:
+                years = list(pool.map(forward_year, self.tracer_modules))
+        else:
+            years = [forward_year(tms) for tms in self.tracer_modules]
+        for tms, (fx, st, hist) in zip(self.tracer_modules, years):
+            if hist_fname is not None:
                 tracers = {name: dict(meta.get("attrs", {}))
                            for name, meta in tms._tracer_module_def["tracers"].items()}
                 if tms.eng.module_kind == 1:
