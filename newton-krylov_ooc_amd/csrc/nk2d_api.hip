@@ -471,9 +471,15 @@ extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* w
 extern "C" int nk2d_vec_alloc(nk2d_ctx* c, nk2d_vec* out) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     double* p = nullptr;
-    if (!c->vec_pool.empty()) {
-        p = c->vec_pool.back();
-        c->vec_pool.pop_back();
+    {
+        // handles may be released from another host thread (garbage collection of the caller)
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (!c->vec_pool.empty()) {
+            p = c->vec_pool.back();
+            c->vec_pool.pop_back();
+        }
+    }
+    if (p) {
         NK2D_CHECK(c, hipMemsetAsync(p, 0, sizeof(double) * c->nv, c->stream));
     } else {
         NK2D_TRY(dev_alloc(c, &p, c->nv));
@@ -484,11 +490,14 @@ extern "C" int nk2d_vec_alloc(nk2d_ctx* c, nk2d_vec* out) {
 extern "C" int nk2d_vec_free(nk2d_ctx* c, nk2d_vec v) {
     if (!v) return 0;
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    if (c->vec_pool.size() < NK2D_POOL_MAX) {
-        // work queued on the context's stream that still reads v finishes before any later use,
-        // which is queued on the same stream
-        c->vec_pool.push_back((double*)v);
-        return 0;
+    {
+        std::lock_guard<std::mutex> lock(c->pool_mutex);
+        if (c->vec_pool.size() < NK2D_POOL_MAX) {
+            // work queued on the context's stream that still reads v finishes before any later use,
+            // which is queued on the same stream
+            c->vec_pool.push_back((double*)v);
+            return 0;
+        }
     }
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     NK2D_CHECK(c, hipFree(v));

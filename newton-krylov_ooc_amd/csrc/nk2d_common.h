@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/nk2d.h"
@@ -96,6 +97,7 @@ struct nk2d_ctx {
     int speculate;   // 1: queue the next Newton iteration's front launches before reading the norm
     // freed state vectors kept for reuse (nk2d_vec_alloc / nk2d_vec_free)
     std::vector<double*> vec_pool;
+    std::mutex pool_mutex;
     // staging for host <-> device layout conversion
     double* STAGE;
     double* hSTAGE;  // pinned host twin of STAGE
