@@ -102,6 +102,13 @@ class PhosphorusPrecond:
             if used >= 8 and np.all(resid <= tol):
                 break
         tick = time.time()
+        if not np.all(resid <= tol):
+            logging.getLogger(__name__).warning(
+                "phosphorus preconditioner: Arnoldi stopped after %d solves with Ritz residuals %s", used, resid)
+        if abs(lam[0]) > 1.0e-6 * abs(lam[1]):
+            # mat = T J has an exact null vector (total P is conserved); without it the mean-preserving
+            # projection of the reference is undefined
+            raise RuntimeError(f"smallest eigenvalue {lam[0]} is not a null eigenvalue")
         lead = ritz[:, :3]
         vects = basis[:used].T @ lead.real + 1j * (basis[:used].T @ lead.imag)   # two real products
         clock["host"] += time.time() - tick
