@@ -74,6 +74,18 @@ def _merge_base_matrix_def(base_def, matrix_def):
             raise TypeError(f"base defn type {type(base_val)} not supported")
 
 
+def propagate_base_matrix_defs_to_all(matrix_defs):
+    """copy the entries of the `base` preconditioner-matrix definition into every other
+    definition (`nk_ooc/model_config.py:propagate_base_matrix_defs_to_all`): missing keys are
+    added, list options are appended unless an option with the same leading word is already
+    there, nothing a matrix defines itself is overridden"""
+    if "base" not in matrix_defs:
+        return
+    for name, matrix_def in matrix_defs.items():
+        if name != "base":
+            _merge_base_matrix_def(matrix_defs["base"], matrix_def)
+
+
 def gen_grid_vars(grid_vars_fname, region_mask_varname):
     """region_mask, grid_weight (both zeroed where either is), region_cnt"""
     data, _ = ncio.read_file(grid_vars_fname)
@@ -99,10 +111,7 @@ class ModelConfig:
         self.tracer_module_defs = contents["tracer_module_defs"]
         self.precond_matrix_defs = contents["precond_matrix_defs"]
         self._check_names(modelinfo["tracer_module_names"])
-        if "base" in self.precond_matrix_defs:
-            for name, matrix_def in self.precond_matrix_defs.items():
-                if name != "base":
-                    _merge_base_matrix_def(self.precond_matrix_defs["base"], matrix_def)
+        propagate_base_matrix_defs_to_all(self.precond_matrix_defs)
         modelinfo["tracer_module_names"] = self._expand_all(modelinfo["tracer_module_names"])
 
         mask_names = set()

@@ -158,3 +158,28 @@ def test_baseline_cmp(tmp_path):
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert subprocess.run(cmd, env=env, capture_output=True).returncode == 1
     assert subprocess.run(cmd + ["--rtol", "1e-3", "--atol", "1e-6"], env=env, capture_output=True).returncode == 0
+
+
+def test_propagate_base_matrix_defs_to_all(tmp_path):
+    """behaviour the reference pins in tests/test_model_config.py: base entries reach every
+    matrix definition, options are keyed by their leading word, nothing is overridden or doubled"""
+    from nk_ooc_amd.model_config import propagate_base_matrix_defs_to_all
+
+    cfg = make_config(str(tmp_path), 8, 8, tracer_module_names="phosphorus")
+    gen_grid_vars_file(cfg["modelinfo"])
+    defs = ModelConfig(cfg["modelinfo"]).precond_matrix_defs
+    base, phos = defs["base"], defs["phosphorus"]
+    for varname in base["hist_to_precond_varnames"]:
+        assert varname in phos["hist_to_precond_varnames"]
+    base["hist_to_precond_varnames"].append("new_hist_var")
+    propagate_base_matrix_defs_to_all(defs)
+    assert "new_hist_var" in phos["hist_to_precond_varnames"]
+    base["precond_matrices_opts"] = ["matrix_opt_A sub_opt"]
+    propagate_base_matrix_defs_to_all(defs)
+    assert "matrix_opt_A sub_opt" in phos["precond_matrices_opts"]
+    base["precond_matrices_opts"].append("matrix_opt_B sub_opt_base")
+    phos["precond_matrices_opts"].append("matrix_opt_B sub_opt_phosphorus")
+    propagate_base_matrix_defs_to_all(defs)
+    assert "matrix_opt_B sub_opt_phosphorus" in phos["precond_matrices_opts"]
+    assert "matrix_opt_B sub_opt_base" not in phos["precond_matrices_opts"]
+    assert phos["precond_matrices_opts"].count("matrix_opt_A sub_opt") == 1
