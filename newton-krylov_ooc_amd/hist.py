@@ -29,30 +29,67 @@ def bldepth(grid, time):
     return BLDEPTH_MIN + (grid.bldepth_max - BLDEPTH_MIN) * frac
 
 
-def _units_product(*units):
-    """units string of a product in the reference's canonical form (`utils.units_str_format`,
-    nk_ooc/utils.py:189-205, which lets pint multiply the factors): powers of a unit are merged,
-    numerator terms are separated by blanks, every denominator term follows a " / ", e.g.
-    ("years", "m", "m") -> "years m^2", ("mmol / m^3", "m") -> "mmol / m^2"."""
-    powers = {}
-    for unit in units:
-        sign = 1
-        for token in unit.replace("*", " * ").replace("/", " / ").split():
-            if token == "/":
-                sign = -1
-            elif token == "*":
-                sign = 1
-            elif token != "1":
-                name, _, exponent = token.partition("^")
-                # "a / b / c": every term after a slash stays in the denominator
-                powers[name] = powers.get(name, 0) + sign * (int(exponent) if exponent else 1)
+_PINT_SYMBOL = {"years": "a", "year": "a"}     # pint abbreviates the year as "a" and sorts by symbol
 
-    def term(name, power):
+
+def _parse_units(expr):
+    """{unit: power} of a units expression: blanks and `*` multiply, `/` divides the NEXT term
+    only, `^` raises, parentheses group (pint evaluates left to right)"""
+    powers = {}
+
+    def merge(other, sign):
+        for name, power in other.items():
+            powers[name] = powers.get(name, 0) + sign * power
+
+    pos, sign, n = 0, 1, len(expr)
+    while pos < n:
+        ch = expr[pos]
+        if ch.isspace() or ch == "*":
+            pos += 1
+        elif ch == "/":
+            sign = -1
+            pos += 1
+        elif ch == "(":
+            depth, end = 1, pos + 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(expr[end], 0)
+                end += 1
+            merge(_parse_units(expr[pos + 1:end - 1]), sign)
+            pos, sign = end, 1
+        else:
+            end = pos
+            while end < n and not expr[end].isspace() and expr[end] not in "*/()":
+                end += 1
+            name, _, exponent = expr[pos:end].partition("^")
+            if name != "1":
+                merge({name: int(exponent) if exponent else 1}, sign)
+            pos, sign = end, 1
+    return powers
+
+
+def units_str_format(units_str):
+    """units string in the reference's canonical format (`utils.units_str_format`,
+    nk_ooc/utils.py:189-205, which lets pint evaluate the expression): powers of a unit merged,
+    numerator terms separated by blanks, every denominator term after a " / ", terms ordered by
+    pint's symbol; a time unit (d, s) that would come first of two denominator terms goes last.
+    Pinned by the reference's tests/test_utils.py cases (tests/test_host.py)."""
+    powers = _parse_units(units_str)
+    order = sorted(powers, key=lambda name: _PINT_SYMBOL.get(name, name))
+
+    def term(name):
+        power = abs(powers[name])
         return name if power == 1 else f"{name}^{power}"
 
-    numer = [term(name, power) for name, power in powers.items() if power > 0]
-    denom = [term(name, -power) for name, power in powers.items() if power < 0]
-    return " / ".join([" ".join(numer) if numer else "1"] + denom)
+    numer = [term(name) for name in order if powers[name] > 0]
+    denom = [term(name) for name in order if powers[name] < 0]
+    parts = [" ".join(numer) if numer else "1"] + denom
+    if len(parts) == 3 and parts[1] in ("d", "s"):
+        parts[1], parts[2] = parts[2], parts[1]
+    return " / ".join(parts)
+
+
+def _units_product(*units):
+    return units_str_format(" ".join(f"({unit})" for unit in units))
 
 
 def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):

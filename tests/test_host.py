@@ -183,3 +183,26 @@ def test_propagate_base_matrix_defs_to_all(tmp_path):
     assert "matrix_opt_B sub_opt_phosphorus" in phos["precond_matrices_opts"]
     assert "matrix_opt_B sub_opt_base" not in phos["precond_matrices_opts"]
     assert phos["precond_matrices_opts"].count("matrix_opt_A sub_opt") == 1
+
+
+@pytest.mark.parametrize("units_str, expected", [
+    ("years m", "years m"), ("mmol / m^3 m", "mmol / m^2"), ("mmol / m^3 / d m", "mmol / m^2 / d"),
+    ("1 / d m", "m / d"), ("mol / m^3 m", "mol / m^2"), ("(years) (m)", "years m"),
+    ("(mmol / m^3) (m)", "mmol / m^2"), ("(mmol / m^3 / d) (m)", "mmol / m^2 / d"), ("(1 / d) (m)", "m / d"),
+    ("(mol / m^3) (m)", "mol / m^2"), ("m years", "years m"), ("m mmol / m^3", "mmol / m^2"),
+    ("m mmol / m^3 / d", "mmol / m^2 / d"), ("m 1 / d", "m / d"), ("m mol / m^3", "mol / m^2")])
+def test_units_str_format(units_str, expected):
+    """the cases the reference pins for its pint-based formatter (tests/test_utils.py:28-50)"""
+    from nk_ooc_amd.hist import units_str_format
+
+    assert units_str_format(units_str) == expected
+
+
+@pytest.mark.parametrize("expr, expected", [
+    ("1.0 + 2.0", 3.0), ("1.0 + 2.0 * 3.0", 7.0), ("(1.0 + 2.0) * 3.0", 9.0), ("(1.0 + 2.0) / 3.0", 1.0),
+    ("2.0 ** 3.0", 8.0), ("10.0 + -2.0", 8.0), ("10.0 - 2.0", 8.0)])
+def test_eval_expr(expr, expected):
+    """the cases the reference pins for utils.eval_expr (tests/test_utils.py:11-25)"""
+    from nk_ooc_amd.engine import _eval_number
+
+    assert _eval_number(expr) == expected
