@@ -41,6 +41,35 @@ def _interp2(x, x0, x1, y0, y1):
     return res
 
 
+def remap_two_knots(edges, delta_r, xv, yv):
+    """literal restatement of `SpatialAxis.remap_linear_interpolant` (spatial_axis.py:136-187) for an
+    interpolant with two knots: layer averages over [edges[k], edges[k+1]] of the piecewise linear
+    function through (xv, yv), constant outside the knots.  Pinned by the cases of the reference's
+    tests/test_spatial_axis.py:156-185 (tests/test_oracle_static.py)."""
+    edges = np.asarray(edges, dtype=np.float64)
+    ye = np.interp(edges, xv, yv)
+    res = 0.5 * (ye[:-1] + ye[1:])
+    lay = 0
+    iv = 0
+    while iv < 2:
+        if xv[iv] < edges[0]:
+            iv += 1
+            continue
+        if xv[iv] >= edges[-1]:
+            break
+        while xv[iv] >= edges[lay + 1]:
+            lay += 1
+        acc = (xv[iv] - edges[lay]) * (0.5 * (ye[lay] + yv[iv]))
+        while iv < 2 and xv[iv] < edges[lay + 1]:
+            if iv + 1 < 2 and xv[iv + 1] < edges[lay + 1]:
+                acc += (xv[iv + 1] - xv[iv]) * (0.5 * (yv[iv] + yv[iv + 1]))
+            else:
+                acc += (edges[lay + 1] - xv[iv]) * (0.5 * (yv[iv] + ye[lay + 1]))
+            iv += 1
+        res[lay] = acc * delta_r[lay]
+    return res
+
+
 class Py2dModel:
     """time-invariant fields of the py_driver_2d processes on a (depth, ypos) grid"""
 
@@ -130,33 +159,10 @@ class Py2dModel:
         return res
 
     def remap_ramp_loop(self, bld_val):
-        """literal restatement of the reference's remap loop for ONE column
+        """the reference's remap loop for ONE column of the vertical mixing ramp
         (spatial_axis.py:136-187), for checking `_remap_ramp` on small cases"""
-        edges = self.depth.mid
-        delta_r = self.depth.delta_mid_r
-        xv = [bld_val - 20.0, bld_val + 20.0]
-        yv = [np.log(1.0e1), np.log(5.0e-4)]
-        ye = np.interp(edges, xv, yv)
-        res = 0.5 * (ye[:-1] + ye[1:])
-        lay = 0
-        iv = 0
-        while iv < 2:
-            if xv[iv] < edges[0]:
-                iv += 1
-                continue
-            if xv[iv] >= edges[-1]:
-                break
-            while xv[iv] >= edges[lay + 1]:
-                lay += 1
-            acc = (xv[iv] - edges[lay]) * (0.5 * (ye[lay] + yv[iv]))
-            while iv < 2 and xv[iv] < edges[lay + 1]:
-                if iv + 1 < 2 and xv[iv + 1] < edges[lay + 1]:
-                    acc += (xv[iv + 1] - xv[iv]) * (0.5 * (yv[iv] + yv[iv + 1]))
-                else:
-                    acc += (edges[lay + 1] - xv[iv]) * (0.5 * (yv[iv] + ye[lay + 1]))
-                iv += 1
-            res[lay] = acc * delta_r[lay]
-        return res
+        return remap_two_knots(self.depth.mid, self.depth.delta_mid_r, [bld_val - 20.0, bld_val + 20.0],
+                               [np.log(1.0e1), np.log(5.0e-4)])
 
     # ---- vert_mix.py:44-87 --------------------------------------------------
     def vmix_coeff(self, time):

@@ -83,3 +83,18 @@ def test_forced_module_bitwise(golden_dir, tag):
         res, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
         assert np.array_equal(res, g["fcn"])
         assert (solver.stats.nfev, solver.stats.njev, solver.stats.nlu) == (int(g["nfev"]), int(g["njev"]), int(g["nlu"]))
+
+
+def test_remap_two_knots_reference_cases():
+    """the cases the reference pins for SpatialAxis.remap_linear_interpolant with two knots
+    (tests/test_spatial_axis.py:156-185): 5 uniform layers on [0, 50]"""
+    from oracle.model import remap_two_knots
+
+    edges = np.linspace(0.0, 50.0, 6)
+    delta_r = 1.0 / np.diff(edges)
+    cases = [([-15.0, -5.0], [1.0, 2.0], [2.0, 2.0, 2.0, 2.0, 2.0]),
+             ([-15.0, 25.0], [0.0, 8.0], [4.0, 6.0, 7.75, 8.0, 8.0]),
+             ([5.0, 25.0], [0.0, 8.0], [0.5, 4.0, 7.5, 8.0, 8.0]),
+             ([22.5, 27.5], [0.0, 8.0], [0.0, 0.0, 4.0, 8.0, 8.0])]
+    for xv, yv, expected in cases:
+        assert np.array_equal(remap_two_knots(edges, delta_r, xv, yv), np.array(expected))
