@@ -190,7 +190,7 @@ def main():
                 },
                 "roofline": {
                     "bound": "hbm",
-                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}, 0, 0>",
+                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}, 0, 0, 1>",
                     "achieved": achieved,
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
