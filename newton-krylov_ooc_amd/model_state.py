@@ -193,6 +193,7 @@ class ModelState:
     _engines = None
     _grid = None
     _resident = {}
+    RESIDENT_MAX = 256      # device snapshots kept by name (only trimmed when the files are on disk)
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
     _precond_state = {}     # precond file -> {module name: linearisation field}
     last_stats = None       # stats of the most recent comp_fcn, per module
@@ -297,7 +298,13 @@ class ModelState:
             return self
         if caller is None:
             raise ValueError("caller unknown")
-        self._resident[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
+        # device snapshot under the file's name: a later ModelState(fname) of this process skips the
+        # file read.  Oldest snapshots are dropped beyond RESIDENT_MAX (the files remain on disk).
+        cache = self._resident
+        cache.pop(os.path.abspath(fname), None)
+        cache[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
+        while len(cache) > self.RESIDENT_MAX and self.write_files:
+            cache.pop(next(iter(cache)))
         if self.write_files:
             tracer_vals = {}
             for tms in self.tracer_modules:
