@@ -25,7 +25,6 @@ import sys
 import tempfile
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -24,8 +24,7 @@ import numpy as np
 
 from . import hist as hist_mod
 from . import ncio
-from .engine import (PHOSPHORUS_PARAM_NAMES, ModuleEngine, forced_engine, iage_engine,
-                     phosphorus_engine)
+from .engine import PHOSPHORUS_PARAM_NAMES, forced_engine, iage_engine, phosphorus_engine
 from .grid import Grid2d, SpatialAxis
 
 YEAR = 365.0 * 86400.0
