@@ -1,4 +1,4 @@
-"""probe: Newton-Krylov on the phosphorus module, prints per-iteration norms and timings"""
+"""probe: Newton-Krylov to convergence (NK2D_MODULES, default phosphorus), per-iteration norms and timings"""
 import logging
 import os
 import sys
@@ -15,7 +15,7 @@ from nk_ooc_amd.setup_solver import make_config, setup  # noqa: E402
 nz, ny = int(sys.argv[1]), int(sys.argv[2])
 logging.basicConfig(level=logging.INFO, format="%(message)s", stream=sys.stdout)
 work = tempfile.mkdtemp()
-cfg = make_config(work, nz, ny, tracer_module_names="phosphorus",
+cfg = make_config(work, nz, ny, tracer_module_names=os.environ.get("NK2D_MODULES", "phosphorus"),
                   extra_solverinfo={"newton_max_iter": sys.argv[3] if len(sys.argv) > 3 else "6"})
 ModelState.write_files = True
 t0 = time.time()
