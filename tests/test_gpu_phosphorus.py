@@ -218,3 +218,46 @@ def test_phosphorus_newton(tmp_path):
     for name in ("iterate_norm_phosphorus", "fcn_norm_phosphorus", "Krylov_iterations", "po4", "pop_mean_ypos"):
         assert name in stats, name
     ModelState.reset_class()
+
+
+def test_phosphorus_newton_resume(tmp_path):
+    """phosphorus run killed inside the second Krylov iteration and resumed with fresh contexts: the
+    state dependent preconditioner is rebuilt from po4 in the preconditioner file and the run ends
+    at the same iterate"""
+    import os
+
+    from nk_ooc_amd import nk_driver
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import make_config, setup
+
+    class Interrupt(Exception):
+        pass
+
+    def run(workdir, interrupt):
+        cfg = make_config(workdir, 22, 9, tracer_module_names="phosphorus")
+        ModelState.write_files = True
+        setup(cfg, fp_cnt=1)
+        if not interrupt:
+            return nk_driver.run(cfg)
+        original = ModelState.comp_fcn
+
+        def guarded(self, res_fname, solver_state, hist_fname=None):
+            if "perturb_fcn_w_raw_01" in os.path.basename(res_fname):
+                raise Interrupt(res_fname)
+            return original(self, res_fname, solver_state, hist_fname)
+
+        ModelState.comp_fcn = guarded
+        try:
+            with pytest.raises(Interrupt):
+                nk_driver.run(cfg)
+        finally:
+            ModelState.comp_fcn = original
+        return nk_driver.run(cfg, resume=True)
+
+    straight = run(str(tmp_path / "a"), False)
+    x_a = straight.iterate.tracer_modules[0].get_tracer_vals_all()
+    resumed = run(str(tmp_path / "b"), True)
+    x_b = resumed.iterate.tracer_modules[0].get_tracer_vals_all()
+    assert resumed.get_iteration() == straight.get_iteration()
+    assert np.allclose(x_a, x_b, rtol=1e-10, atol=1e-13)
+    ModelState.reset_class()
