@@ -143,3 +143,69 @@ def test_krylov_arnoldi_identities_fullsize(tmp_path):
     finally:
         ModelState.write_files = True
         ModelState.reset_class()
+
+
+# ---- phosphorus at full size (BASELINE config 5's grid) --------------------------------------------
+@pytest.fixture(scope="module")
+def phos():
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    grid = Grid2d.default(N, N)
+    engine = phosphorus_engine(grid)
+    weight = np.outer(grid.depth.delta, grid.ypos.delta)
+    engine.set_region(np.ones((N, N), dtype=np.int32), weight)
+    engine.grid_weight = weight
+    prof = [np.interp(grid.depth.mid, zs, vs) for zs, vs in (([1.3e2, 2.6e2], [5.5e-3, 4.1e0]),
+                                                              ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                              ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+    rng = np.random.default_rng(3)
+    y = np.stack([np.broadcast_to(p[:, None], (N, N)) for p in prof]) * (1.0 + 0.2 * rng.random((3, N, N)))
+    engine.state = y
+    return engine
+
+
+def test_phosphorus_conservation_and_jacobian_fullsize(phos):
+    """uptake, remineralisation and sinking only move phosphorus between tracers and cells, transport is
+    in flux form: the weighted mean of the summed tendencies vanishes; and J v is the directional
+    derivative of the (nonlinear) tendency"""
+    t = 0.37 * YEAR
+    yd = phos.upload(phos.state)
+    ones = phos.upload(np.ones(phos.shape))
+    tend = phos.tend(t, yd)
+    scale = np.max(np.abs(phos.download(tend)))
+    assert abs(phos.dot(tend, ones)[0]) < 1e-12 * scale
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(phos.shape) * phos.state
+    phos.set_lin_state(yd)
+    jv = phos.download(phos.jacobian_apply(t, phos.upload(v)))
+    eps = 1.0e-6
+    plus = phos.download(phos.tend(t, phos.upload(phos.state + eps * v)))
+    minus = phos.download(phos.tend(t, phos.upload(phos.state - eps * v)))
+    fd = (plus - minus) / (2.0 * eps)
+    assert np.max(np.abs(fd - jv)) < 1e-6 * np.max(np.abs(jv))
+    # the Jacobian conserves too: column sums vanish in the weighted sense
+    assert abs(phos.dot(phos.upload(jv), ones)[0]) < 1e-11 * np.max(np.abs(jv))
+
+
+def test_phosphorus_solves_fullsize(phos):
+    """residuals of the coupled line relaxation (Radau shifts) and of the block elimination
+    (preconditioner shifts), formed with the device's own J v"""
+    t = 0.5 * YEAR
+    yd = phos.upload(phos.state)
+    phos.set_lin_state(yd)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(phos.shape)
+    bd = phos.upload(b)
+    h, mu = 2.0e5, 3.6378342527444957
+    phos.set_option("lin_tol", 1e-10)
+    x, _, sweeps = phos.shifted_solve(t, h, mu, bd)
+    phos.set_option("lin_tol", 1e-4)
+    resid = (mu / h) * phos.download(x) - phos.download(phos.jacobian_apply(t, x)) - b
+    assert np.max(np.abs(resid)) < 1e-8 * np.max(np.abs(b)) and sweeps > 2
+    for sigma in (0.02, -0.03):
+        phos.shift_factor(t, YEAR, [sigma])
+        sol = phos.shift_solve(0, bd)
+        resid = YEAR * phos.download(phos.jacobian_apply(t, sol)) - sigma * phos.download(sol) - b
+        # entries of mat = T J reach 1e6-1e7 (a year of vertical mixing in the boundary layer)
+        assert np.max(np.abs(resid)) < 1e-6 * np.max(np.abs(b)), sigma
