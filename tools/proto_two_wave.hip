@@ -111,6 +111,98 @@ __global__ void __launch_bounds__(256) kA_sweep(ArgsA A) {
     store_col<EA>(A.yci, task, lane, fci);
 }
 
+// variant A0: the loads and stores of variant A with no tridiagonal solve (memory floor of the launch)
+__global__ void __launch_bounds__(256) kA0_sweep(ArgsA A) {
+    const int lane = threadIdx.x & 63, task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= NCOL) return;
+    const int j = task % NY;
+    const int cs = (j > 0) ? task - 1 : task, cn = (j < NY - 1) ? task + 1 : task;
+    double a[EA], c[EA], js[EA], jn[EA], fr[EA], fcr[EA], fci[EA], xs[EA], xn[EA], t0[EA];
+    load_col<EA>(A.a, j, lane, a);
+    load_col<EA>(A.c, j, lane, c);
+    load_col<EA>(A.js, j, lane, js);
+    load_col<EA>(A.jn, j, lane, jn);
+    load_col<EA>(A.br, task, lane, fr);
+    load_col<EA>(A.bcr, task, lane, fcr);
+    load_col<EA>(A.bci, task, lane, fci);
+    load_col<EA>(A.xr, cs, lane, xs); load_col<EA>(A.xr, cn, lane, xn);
+    for (int e = 0; e < EA; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e])) + a[e];
+    load_col<EA>(A.xcr, cs, lane, xs); load_col<EA>(A.xcr, cn, lane, xn);
+    for (int e = 0; e < EA; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e])) + c[e];
+    load_col<EA>(A.xci, cs, lane, xs); load_col<EA>(A.xci, cn, lane, xn);
+    for (int e = 0; e < EA; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
+    load_col<EA>(A.inv_r, task, lane, t0);
+    for (int e = 0; e < EA; ++e) fr[e] += t0[e];
+    load_col<EA>(A.inv_cr, task, lane, t0);
+    for (int e = 0; e < EA; ++e) fcr[e] += t0[e];
+    load_col<EA>(A.inv_ci, task, lane, t0);
+    for (int e = 0; e < EA; ++e) fci[e] += t0[e];
+    double acc = 0.0;
+    for (int i = 0; i < NK2D_TAB; ++i)
+        acc += A.tab_r[((size_t)task * NK2D_TAB + i) * 64 + lane] + A.tab_cr[((size_t)task * NK2D_TAB + i) * 64 + lane] +
+               A.tab_ci[((size_t)task * NK2D_TAB + i) * 64 + lane];
+    fr[0] += acc;
+    store_col<EA>(A.yr, task, lane, fr);
+    store_col<EA>(A.ycr, task, lane, fcr);
+    store_col<EA>(A.yci, task, lane, fci);
+}
+
+__global__ void k_empty(int) {}
+
+// variant A0w: the same traffic as A0 with 16-byte loads / stores per lane (levels stored in pairs:
+// slot ((col * 4 + e / 2) * 64 + lane) * 2 + (e & 1), one padding level per lane for E = 7).  The data are
+// not re-laid out for this timing-only variant: the byte count per column is what matters.
+__device__ __forceinline__ void load_w(const double* base, size_t col, int lane, double (&o)[8]) {
+    const double2* p = reinterpret_cast<const double2*>(base + col * (size_t)(EA * 64)) + lane;
+    // 3.5 double2 per lane cover the 7 x 64 doubles of a column: read 3 full pairs and one half pair
+    for (int q = 0; q < 3; ++q) { double2 v = p[q * 64]; o[2 * q] = v.x; o[2 * q + 1] = v.y; }
+    o[6] = base[col * (size_t)(EA * 64) + 6 * 64 + lane];
+    o[7] = 0.0;
+}
+__device__ __forceinline__ void store_w(double* base, size_t col, int lane, const double (&v)[8]) {
+    double2* p = reinterpret_cast<double2*>(base + col * (size_t)(EA * 64)) + lane;
+    for (int q = 0; q < 3; ++q) p[q * 64] = make_double2(v[2 * q], v[2 * q + 1]);
+    base[col * (size_t)(EA * 64) + 6 * 64 + lane] = v[6];
+}
+__global__ void __launch_bounds__(256) kA0w_sweep(ArgsA A) {
+    const int lane = threadIdx.x & 63, task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= NCOL) return;
+    const int j = task % NY;
+    const int cs = (j > 0) ? task - 1 : task, cn = (j < NY - 1) ? task + 1 : task;
+    double a[8], c[8], js[8], jn[8], fr[8], fcr[8], fci[8], xs[8], xn[8], t0[8];
+    load_w(A.a, j, lane, a);
+    load_w(A.c, j, lane, c);
+    load_w(A.js, j, lane, js);
+    load_w(A.jn, j, lane, jn);
+    load_w(A.br, task, lane, fr);
+    load_w(A.bcr, task, lane, fcr);
+    load_w(A.bci, task, lane, fci);
+    load_w(A.xr, cs, lane, xs); load_w(A.xr, cn, lane, xn);
+    for (int e = 0; e < 7; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e])) + a[e];
+    load_w(A.xcr, cs, lane, xs); load_w(A.xcr, cn, lane, xn);
+    for (int e = 0; e < 7; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e])) + c[e];
+    load_w(A.xci, cs, lane, xs); load_w(A.xci, cn, lane, xn);
+    for (int e = 0; e < 7; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
+    load_w(A.inv_r, task, lane, t0);
+    for (int e = 0; e < 7; ++e) fr[e] += t0[e];
+    load_w(A.inv_cr, task, lane, t0);
+    for (int e = 0; e < 7; ++e) fcr[e] += t0[e];
+    load_w(A.inv_ci, task, lane, t0);
+    for (int e = 0; e < 7; ++e) fci[e] += t0[e];
+    double acc = 0.0;
+    const double2* tr = reinterpret_cast<const double2*>(A.tab_r + (size_t)task * NK2D_TAB * 64) + lane;
+    const double2* tcr = reinterpret_cast<const double2*>(A.tab_cr + (size_t)task * NK2D_TAB * 64) + lane;
+    const double2* tci = reinterpret_cast<const double2*>(A.tab_ci + (size_t)task * NK2D_TAB * 64) + lane;
+    for (int i = 0; i < NK2D_TAB / 2; ++i) {
+        double2 u = tr[i * 64], v = tcr[i * 64], w = tci[i * 64];
+        acc += (u.x + u.y) + (v.x + v.y) + (w.x + w.y);
+    }
+    fr[0] += acc;
+    store_w(A.yr, task, lane, fr);
+    store_w(A.ycr, task, lane, fcr);
+    store_w(A.yci, task, lane, fci);
+}
+
 // variant A2: variant A with the real and the complex solve advanced side by side (two independent
 // dependency chains in every loop body) instead of one after the other
 __global__ void __launch_bounds__(256) kA2_sweep(ArgsA A) {
@@ -488,13 +580,23 @@ int main() {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int reps = 400;
-    float msA = 0, msB = 0, msA2 = 0;
+    float msA = 0, msB = 0, msA2 = 0, msA0 = 0, msA0w = 0;
     for (int pass = 0; pass < 2; ++pass) {   // first pass warms up
         CHECK(hipEventRecord(e0, 0));
         for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kA_sweep, dim3((NCOL + 3) / 4), dim3(256), 0, 0, A);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&msA, e0, e1));
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kA0_sweep, dim3((NCOL + 3) / 4), dim3(256), 0, 0, A);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&msA0, e0, e1));
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kA0w_sweep, dim3((NCOL + 3) / 4), dim3(256), 0, 0, A);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&msA0w, e0, e1));
         CHECK(hipEventRecord(e0, 0));
         for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kA2_sweep, dim3((NCOL + 3) / 4), dim3(256), 0, 0, A);
         CHECK(hipEventRecord(e1, 0));
@@ -507,6 +609,15 @@ int main() {
         CHECK(hipEventElapsedTime(&msB, e0, e1));
     }
     CHECK(hipGetLastError());
+    {
+        float ms = 0;
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL(k_empty, dim3(208), dim3(256), 0, 0, i);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("empty kernel, 208 workgroups, back to back: %.2f us per launch\n", 1000.0 * ms / 2000);
+    }
     std::vector<double> ya(nA), yb(nB);
     double worst = 0.0, scale = 0.0;
     double* outA[3] = {A.yr, A.ycr, A.yci};
@@ -524,6 +635,8 @@ int main() {
     printf("columns %d, nz %d: one wave per column (E=7) %.2f us per launch; same with the two solves side by side %.2f us; "
            "two waves per column (E=4, LDS PCR) %.2f us per launch\n",
            NCOL, NZ, 1000.0 * msA / reps, 1000.0 * msA2 / reps, 1000.0 * msB / reps);
+    printf("loads and stores of the one-wave sweep without the solves: %.2f us per launch; with 16-byte accesses per lane: %.2f us\n",
+           1000.0 * msA0 / reps, 1000.0 * msA0w / reps);
     printf("max |xA - xB| = %.3e (scale %.3e)\n", worst, scale);
     return (worst <= 1e-9 * scale) ? 0 : 2;
 }
