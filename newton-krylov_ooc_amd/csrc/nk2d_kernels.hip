@@ -826,6 +826,9 @@ int nk2d_sweeps_for(nk2d_ctx* c, double c_real) {
     if (rho <= 0.0) return 1;  // no horizontal coupling: the line solve is exact
     if (rho >= 0.999) return 400;
     int m = (int)std::ceil(std::log(c->d.lin_tol) / std::log(rho));
+    // at least two sweeps whenever there is lateral coupling: with one, the stage part and the update
+    // would share a launch, and the update of one column would race with the stage reads of its
+    // neighbours (a single launch is only used when the columns do not couple at all, rho = 0)
     if (m < 2) m = 2;
     if (m > 400) m = 400;
     return m;

@@ -15,7 +15,7 @@ from .grid import BLDEPTH_MIN, YEAR, bldepth_time_knots
 
 
 # relative accuracy of the inner line-relaxation solves (inexact simplified Newton)
-DEFAULT_LIN_TOL = 1.0e-4
+DEFAULT_LIN_TOL = 1.0e-3
 
 
 class Nk2dError(RuntimeError):
