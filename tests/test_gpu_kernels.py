@@ -98,3 +98,39 @@ def test_shifted_solve(nz, ny, hfrac):
     x_re, x_im, sweeps = eng.shifted_solve(t_jac, h, radau.MU_COMPLEX, eng.upload(b), eng.upload(bi))
     got = eng.download(x_re).reshape(-1) + 1j * eng.download(x_im).reshape(-1)
     assert rel_err(got, wantc) < 1e-11, sweeps
+
+
+@pytest.mark.parametrize("nz", [64, 65, 150, 200, 257, 321, 390, 512])
+def test_every_levels_per_lane_instantiation(nz):
+    """one grid per template instantiation E = ceil(nz / 64) = 1 .. 8 (full and ragged last lanes):
+    tendency, shifted solves and a step-replayed year segment against the oracle"""
+    from oracle import radau
+
+    ny = 5
+    eng = make_engine(nz, ny, lin_tol=1.0e-12)
+    _, tm = oracle_iage(nz, ny)
+    rng = np.random.default_rng(nz)
+    y = 1.0 + rng.random(2 * nz * ny)
+    t = 0.3 * YEAR
+    assert rel_err(eng.download(eng.tend(t, eng.upload(y))).reshape(-1), tm.comp_tend(t, y)) < 1e-13
+    J = tm.comp_jacobian(t).tocsc()
+    n = J.shape[0]
+    b = rng.standard_normal(n)
+    bi = rng.standard_normal(n)
+    for h in (1.0e3, 3.0e5):
+        want = spl.splu((radau.MU_REAL / h * sparse.identity(n, format="csc") - J).tocsc()).solve(b)
+        x_re, _, _ = eng.shifted_solve(t, h, radau.MU_REAL, eng.upload(b))
+        assert rel_err(eng.download(x_re).reshape(-1), want) < 1e-10, h
+        wantc = spl.splu((radau.MU_COMPLEX / h * sparse.identity(n, format="csc") - J).tocsc()).solve(b + 1j * bi)
+        x_re, x_im, _ = eng.shifted_solve(t, h, radau.MU_COMPLEX, eng.upload(b), eng.upload(bi))
+        got = eng.download(x_re).reshape(-1) + 1j * eng.download(x_im).reshape(-1)
+        assert rel_err(got, wantc) < 1e-10, h
+    # the integrator kernels of this instantiation: a short span of the year in step-replay mode
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    span = (0.0, 0.02 * YEAR)
+    eng2 = iage_engine(Grid2d.default(nz, ny), time_range=span)
+    want, solver = radau.comp_fcn(tm, y, time_range=span, return_solver=True)
+    fx, _, _ = eng2.comp_fcn(eng2.upload(y), replay=np.array(solver.schedule))
+    assert rel_err(eng2.download(fx).reshape(-1), want) < 1e-9
