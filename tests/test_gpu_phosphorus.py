@@ -261,3 +261,37 @@ def test_phosphorus_newton_resume(tmp_path):
     assert resumed.get_iteration() == straight.get_iteration()
     assert np.allclose(x_a, x_b, rtol=1e-10, atol=1e-13)
     ModelState.reset_class()
+
+
+@pytest.mark.parametrize("nz", [130, 200, 300, 384, 512])
+def test_phosphorus_other_instantiations(nz):
+    """the phosphorus kernels at other levels-per-lane counts (E = 3, 4, 5, 6, 8): tendency, J v
+    and the coupled shifted solves against the oracle"""
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    ny = 4
+    eng = phosphorus_engine(Grid2d.default(nz, ny), lin_tol=1e-11)
+    depth, ypos = default_axes(nz, ny)
+    tm = Phosphorus(Py2dModel(depth, ypos))
+    rng = np.random.default_rng(nz)
+    prof = [np.interp(depth.mid, zs, vs) for zs, vs in (([1.3e2, 2.6e2], [5.5e-3, 4.1e0]),
+                                                        ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                        ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+    y = (np.stack([np.broadcast_to(p[:, None], (nz, ny)) for p in prof]) * (1.0 + 0.2 * rng.random((3, nz, ny)))).reshape(-1)
+    t = 0.6 * YEAR
+    yd = eng.upload(y)
+    eng.set_lin_state(yd)
+    assert rel_err(eng.download(eng.tend(t, yd)).reshape(-1), tm.comp_tend(t, y)) < 1e-14
+    jac = tm.comp_jacobian(t, y).tocsc()
+    n = y.size
+    v = rng.standard_normal(n)
+    assert rel_err(eng.download(eng.jacobian_apply(t, eng.upload(v))).reshape(-1), jac @ v) < 1e-13
+    h = 1.0e5
+    want = spsolve((radau.MU_REAL / h) * identity(n, format="csc") - jac, v)
+    x_re, _, _ = eng.shifted_solve(t, h, radau.MU_REAL, eng.upload(v))
+    assert rel_err(eng.download(x_re).reshape(-1), want) < 1e-9
+    v2 = rng.standard_normal(n)
+    want = spsolve(((radau.MU_COMPLEX / h) * identity(n, format="csc") - jac).astype(complex), v + 1j * v2)
+    x_re, x_im, _ = eng.shifted_solve(t, h, radau.MU_COMPLEX, eng.upload(v), eng.upload(v2))
+    assert rel_err(eng.download(x_re).reshape(-1) + 1j * eng.download(x_im).reshape(-1), want) < 1e-9
