@@ -335,25 +335,29 @@ __device__ __forceinline__ void phos_tend(const DevP& P, int tr, int j, int lane
     }
 }
 
-// the three tracers of the phosphorus module at ypos column j:  a (+ b when b != nullptr)
+// The wave of tracer tr already holds its own tracer at column j (`own`, formed as a + b by the
+// caller); the other two tracers of the module at that column are a (+ b when b != nullptr):
+//   tr 0 (po4): others dop, pop;  tr 1 (dop): others po4, pop;  tr 2 (pop): others po4, dop
 template <int E>
-__device__ __forceinline__ void load_trio(const DevP& P, const double* __restrict__ a, const double* __restrict__ b,
-                                          int j, int lane, double (&po4)[E], double (&dop)[E], double (&pop)[E]) {
-    load_col<E>(a, j, lane, po4);
-    load_col<E>(a, P.ny + j, lane, dop);
-    load_col<E>(a, 2 * P.ny + j, lane, pop);
-    if (b != nullptr) {
-        double t[E];
-        load_col<E>(b, j, lane, t);
+__device__ __forceinline__ void phos_load_others(const DevP& P, int tr, int j, int lane, const double* __restrict__ a,
+                                                 double (&u1)[E], double (&u2)[E]) {
+    const int o1 = (tr == 0) ? 1 : 0, o2 = (tr == 2) ? 1 : 2;
+    load_col<E>(a, o1 * P.ny + j, lane, u1);
+    load_col<E>(a, o2 * P.ny + j, lane, u2);
+}
+template <int E>
+__device__ __forceinline__ void phos_add(double (&u1)[E], double (&u2)[E], const double (&v1)[E], const double (&v2)[E]) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) po4[e] = po4[e] + t[e];
-        load_col<E>(b, P.ny + j, lane, t);
-#pragma unroll
-        for (int e = 0; e < E; ++e) dop[e] = dop[e] + t[e];
-        load_col<E>(b, 2 * P.ny + j, lane, t);
-#pragma unroll
-        for (int e = 0; e < E; ++e) pop[e] = pop[e] + t[e];
-    }
+    for (int e = 0; e < E; ++e) { u1[e] = u1[e] + v1[e]; u2[e] = u2[e] + v2[e]; }
+}
+// phosphorus sources of tracer tr from its own values and the two others (in the order above)
+template <int E>
+__device__ __forceinline__ void phos_sources(const DevP& P, int tr, int j, int lane, const double (&own)[E],
+                                             const double (&u1)[E], const double (&u2)[E], const double (&dzr)[E],
+                                             double (&out)[E]) {
+    if (tr == 0) phos_tend<E>(P, 0, j, lane, own, u1, u2, dzr, out);
+    else if (tr == 1) phos_tend<E>(P, 1, j, lane, u1, own, u2, dzr, out);
+    else phos_tend<E>(P, 2, j, lane, u1, u2, own, dzr, out);
 }
 
 template <int E, int KIND>
@@ -369,9 +373,9 @@ __global__ void k_tend(DevP P, const double* __restrict__ y, const double* __res
     load_col<E>(kvp, j, lane, kv);
     tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, out);
     if constexpr (KIND == 1) {
-        double po4[E], dop[E], pop[E];
-        load_trio<E>(P, y, nullptr, j, lane, po4, dop, pop);
-        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, out);
+        double u1[E], u2[E];
+        phos_load_others<E>(P, tr, j, lane, y, u1, u2);
+        phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, out);
     }
     store_col<E>(f, task, lane, out);
 }
@@ -1129,9 +1133,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
             tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
             if constexpr (KIND == 1) {
-                double po4[E], dop[E], pop[E];
-                load_trio<E>(P, A.st.y, A.st.z + i * A.st.nv, j, lane, po4, dop, pop);
-                phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, f);
+                double u1[E], u2[E], v1[E], v2[E];
+                phos_load_others<E>(P, tr, j, lane, A.st.y, u1, u2);
+                phos_load_others<E>(P, tr, j, lane, A.st.z + i * A.st.nv, v1, v2);
+                phos_add<E>(u1, u2, v1, v2);
+                phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, f);
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1455,9 +1461,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     load_col<E>(kvp, j, lane, kv);
     tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
     if constexpr (KIND == 1) {
-        double po4[E], dop[E], pop[E];
-        load_trio<E>(P, y, err, j, lane, po4, dop, pop);
-        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, ff);
+        double u1[E], u2[E], v1[E], v2[E];
+        phos_load_others<E>(P, tr, j, lane, y, u1, u2);
+        phos_load_others<E>(P, tr, j, lane, err, v1, v2);
+        phos_add<E>(u1, u2, v1, v2);
+        phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, ff);
     }
     double z0[E], z1[E], z2[E];
     load_col<E>(z, task, lane, z0);
@@ -1499,9 +1507,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     load_col<E>(kvp, j, lane, kv);
     tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
     if constexpr (KIND == 1) {
-        double po4[E], dop[E], pop[E];
-        load_trio<E>(P, y, z2, j, lane, po4, dop, pop);
-        phos_tend<E>(P, tr, j, lane, po4, dop, pop, cf.dzr, ff);
+        double u1[E], u2[E], v1[E], v2[E];
+        phos_load_others<E>(P, tr, j, lane, y, u1, u2);
+        phos_load_others<E>(P, tr, j, lane, z2, v1, v2);
+        phos_add<E>(u1, u2, v1, v2);
+        phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, ff);
     }
     store_col<E>(f, task, lane, ff);
 }
