@@ -136,6 +136,8 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_set_region(
             self._ctx, mask.ctypes.data_as(_lib.c_int32_p), _dp(weight), nreg))
         self.nreg = nreg
+        self._region = (mask, weight)
+        self._ones_vec = None       # cached by the host mirrors; its region scaling changed
 
     # ---- vectors ------------------------------------------------------------
     def new_vec(self):

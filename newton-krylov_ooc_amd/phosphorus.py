@@ -51,7 +51,7 @@ class PhosphorusPrecond:
         e_vect = eng.upload(null_vect.reshape(eng.shape))
         self.e_hat = eng.scale(e_vect, 1.0 / eng.dot(e_vect, self.ones))
         logging.getLogger(__name__).info(
-            "phosphorus preconditioner: %d Arnoldi solves (factor %.2f s, solves %.2f s, host algebra %.2f s), "
+            "phosphorus preconditioner: %d Arnoldi solves (factor %.2f s, solves + orthogonalisation %.2f s, host %.2f s), "
             "shift %.6e, factorisation of the two shifted systems %.2f s",
             self.eig_solves, self.clock["factor"], self.clock["solve"], self.clock["host"], self.shift,
             time.time() - wall1)
@@ -59,8 +59,10 @@ class PhosphorusPrecond:
     def _smallest_eigs(self, mu, tol, max_solves, start):
         """eigenvalues of mat closest to zero and the null vector by shift-invert Arnoldi: the
         Krylov space of (mat - mu I)^-1 is built with the device block solver (one solve per
-        basis vector, ~20 in all), orthogonalisation and the small Hessenberg eigenproblem run
-        on the host.  A Ritz pair (theta, s) of the inverse has residual |h[j+1,j] s[j]|."""
+        basis vector, ~20 in all) and orthogonalised on the device with the engine's Gram-Schmidt
+        kernels under a uniform inner product (one region, unit weights -- any inner product gives
+        the same Hessenberg eigenvalues); only the small Hessenberg eigenproblem runs on the host.
+        A Ritz pair (theta, s) of the inverse has residual |h[j+1,j] s[j]|."""
         eng = self.eng
         n = int(np.prod(eng.shape))
         clock = {"factor": -time.time(), "solve": 0.0, "host": 0.0}
@@ -69,56 +71,59 @@ class PhosphorusPrecond:
         clock["factor"] += time.time()
         if start is None or start.shape != (n,):
             start = np.random.default_rng(0).standard_normal(n)
-        basis = np.empty((max_solves + 1, n))          # one Krylov vector per (contiguous) row
-        hess = np.zeros((max_solves + 1, max_solves))
-        basis[0] = start / np.linalg.norm(start)
-        for col in range(max_solves):
-            tick = time.time()
-            sol = eng.shift_solve(0, eng.upload(basis[col].reshape(eng.shape)))
-            work = eng.download(sol).reshape(-1)
-            clock["solve"] += time.time() - tick
-            tick = time.time()
-            # classical Gram-Schmidt, repeated only when cancellation was severe (DGKS criterion)
-            before = np.linalg.norm(work)
-            for _ in range(2):
-                proj = basis[:col + 1] @ work
-                work -= proj @ basis[:col + 1]
-                hess[:col + 1, col] += proj
-                after = np.linalg.norm(work)
-                if after > 0.7 * before:
+        region = getattr(eng, "_region", None)
+        plane = (eng.nz, eng.ny)
+        eng.set_region(np.ones(plane, dtype=np.int32), np.ones(plane))
+        try:
+            first = eng.upload(start.reshape(eng.shape))
+            basis = [eng.scale(first, 1.0 / np.sqrt(eng.dot(first, first)))]
+            hess = np.zeros((max_solves + 1, max_solves))
+            for col in range(max_solves):
+                tick = time.time()
+                work = eng.shift_solve(0, basis[col])
+                # modified Gram-Schmidt, repeated only when cancellation was severe (DGKS criterion)
+                before = np.sqrt(eng.dot(work, work)[0])
+                for _ in range(2):
+                    hess[:col + 1, col] += eng.mgs(work, basis)[:, 0]
+                    after = np.sqrt(eng.dot(work, work)[0])
+                    if after > 0.7 * before:
+                        break
+                    before = after
+                hess[col + 1, col] = after
+                basis.append(eng.scale(work, 1.0 / after))
+                clock["solve"] += time.time() - tick
+                used = col + 1
+                if used % 4 and used != max_solves:
+                    continue
+                tick = time.time()
+                theta, ritz = np.linalg.eig(hess[:used, :used])       # theta ~ 1 / (lambda - mu)
+                lam = mu + 1.0 / theta
+                order = np.argsort(np.abs(lam))
+                lam, ritz, theta = lam[order], ritz[:, order], theta[order]
+                resid = abs(hess[used, used - 1]) * np.abs(ritz[used - 1, :3]) / np.abs(theta[:3])
+                clock["host"] += time.time() - tick
+                if used >= 8 and np.all(resid <= tol):
                     break
-                before = after
-            hess[col + 1, col] = after
-            basis[col + 1] = work / hess[col + 1, col]
-            clock["host"] += time.time() - tick
-            used = col + 1
-            if used % 4 and used != max_solves:
-                continue
-            theta, ritz = np.linalg.eig(hess[:used, :used])       # theta ~ 1 / (lambda - mu)
-            lam = mu + 1.0 / theta
-            order = np.argsort(np.abs(lam))
-            lam, ritz, theta = lam[order], ritz[:, order], theta[order]
-            resid = abs(hess[used, used - 1]) * np.abs(ritz[used - 1, :3]) / np.abs(theta[:3])
-            if used >= 8 and np.all(resid <= tol):
-                break
-        tick = time.time()
-        if not np.all(resid <= tol):
-            logging.getLogger(__name__).warning(
-                "phosphorus preconditioner: Arnoldi stopped after %d solves with Ritz residuals %s", used, resid)
-        if abs(lam[0]) > 1.0e-6 * abs(lam[1]):
-            # mat = T J has an exact null vector (total P is conserved); without it the mean-preserving
-            # projection of the reference is undefined
-            raise RuntimeError(f"smallest eigenvalue {lam[0]} is not a null eigenvalue")
-        lead = ritz[:, :3]
-        vects = basis[:used].T @ lead.real + 1j * (basis[:used].T @ lead.imag)   # two real products
-        clock["host"] += time.time() - tick
+            if not np.all(resid <= tol):
+                logging.getLogger(__name__).warning(
+                    "phosphorus preconditioner: Arnoldi stopped after %d solves with Ritz residuals %s", used, resid)
+            if abs(lam[0]) > 1.0e-6 * abs(lam[1]):
+                # mat = T J has an exact null vector (total P is conserved); without it the mean-preserving
+                # projection of the reference is undefined
+                raise RuntimeError(f"smallest eigenvalue {lam[0]} is not a null eigenvalue")
+            lead = ritz[:, :3]
+            null_coef = lead[:, 0]
+            if np.max(np.abs(null_coef.imag)) > 1.0e-10 * np.max(np.abs(null_coef.real)):
+                raise RuntimeError("1st eigenvector has non-trivial imaginary part")
+            null_vect = eng.download(eng.lin_comb(basis[:used], null_coef.real)).reshape(-1)
+            # start vector of the next preconditioner: the invariant subspace found here
+            restart_coef = lead[:, 0].real + lead[:, 1].real + lead[:, 1].imag
+            self.restart = eng.download(eng.lin_comb(basis[:used], restart_coef)).reshape(-1)
+        finally:
+            if region is not None:
+                eng.set_region(*region)
         self.clock = clock
-        null_comp = vects[:, 0]
-        if np.max(np.abs(null_comp.imag)) > 1.0e-10 * np.max(np.abs(null_comp.real)):
-            raise RuntimeError("1st eigenvector has non-trivial imaginary part")
-        # start vector of the next preconditioner: the invariant subspace found here
-        self.restart = vects[:, 0].real + vects[:, 1].real + vects[:, 1].imag
-        return lam, np.ascontiguousarray(null_comp.real), used
+        return lam, np.ascontiguousarray(null_vect), used
 
     def apply(self, v, out=None):
         eng = self.eng
