@@ -38,7 +38,6 @@ struct Precond {
     double* PJ;    // Jacobian planes, natural layout [nt][6][nz][ny]  (L, S, C, N, U, d uptake / d po4)
     double* SINV;  // [tc][nb][m][m]
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
-    double* PINV;  // inverted pivot blocks [tc][NB][NB]
     double* ROWS;  // scaled pivot rows    [tc][NB][m]
     double* YV;    // forward-sweep vectors [tc][nb][m]
     double* XV;    // solution vectors      [tc][nb][m]
@@ -138,42 +137,53 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
 
 // ---------------------------------------------------------------------------------
 // Blocked Gauss-Jordan inversion without pivoting (the Schur complements are M-matrices),
-// NB pivots per step, three launches per step, src -> dst ping-pong:
-//   k_pc_gj_pivot : Pinv = inverse of the NB x NB pivot block (one workgroup, in LDS)
+// NB pivots per step, two launches per step, src -> dst ping-pong:
 //   k_pc_gj_rows  : R = Pinv * src[pb, :]   with the pivot columns of R replaced by Pinv
 //   k_pc_gj_update: dst[i, :] = (src[i, :] with pivot columns zeroed) - src[i, pb] * R   (i not in pb)
 //                   dst[pb, :] = R
 // ---------------------------------------------------------------------------------
 #define PC_NB 32
 
-__global__ void k_pc_gj_pivot(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ pinv) {
+// R[p][c] for p < nb, c < m.  Every workgroup first inverts the nb x nb pivot block itself (in LDS, the
+// Gauss-Jordan without pivoting): redundant arithmetic on 1024 numbers instead of a launch of a
+// single workgroup that everything else would wait for.
+__global__ void __launch_bounds__(256) k_pc_gj_rows(int m, int p0, int nb, const double* __restrict__ src,
+                                                    double* __restrict__ rows) {
     __shared__ double a[PC_NB][PC_NB + 1];
-    const size_t base = (size_t)blockIdx.x * m * m;
-    const int r = threadIdx.y, c = threadIdx.x;
-    const bool in = r < nb && c < nb;
-    a[r][c] = in ? src[base + (size_t)(p0 + r) * m + (p0 + c)] : ((r == c) ? 1.0 : 0.0);
-    __syncthreads();
-    for (int p = 0; p < nb; ++p) {
-        const double piv = 1.0 / a[p][p];
+    const int tr = blockIdx.z;
+    {
+        const size_t base = (size_t)tr * m * m;
+        for (int idx = threadIdx.x; idx < PC_NB * PC_NB; idx += 256) {
+            const int r = idx / PC_NB, c = idx - r * PC_NB;
+            const bool in = r < nb && c < nb;
+            a[r][c] = in ? src[base + (size_t)(p0 + r) * m + (p0 + c)] : ((r == c) ? 1.0 : 0.0);
+        }
         __syncthreads();
-        const double prow = ((c == p) ? 1.0 : a[p][c]) * piv;
-        const double f = a[r][p];
-        const double old = (c == p) ? 0.0 : a[r][c];
-        __syncthreads();
-        a[r][c] = (r == p) ? prow : __builtin_fma(-f, prow, old);
-        __syncthreads();
+        for (int p = 0; p < nb; ++p) {
+            const double piv = 1.0 / a[p][p];
+            double upd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = threadIdx.x + 256 * q;
+                const int r = idx / PC_NB, c = idx - r * PC_NB;
+                const double prow = ((c == p) ? 1.0 : a[p][c]) * piv;
+                const double f = a[r][p];
+                const double old = (c == p) ? 0.0 : a[r][c];
+                upd[q] = (r == p) ? prow : __builtin_fma(-f, prow, old);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = threadIdx.x + 256 * q;
+                a[idx / PC_NB][idx % PC_NB] = upd[q];
+            }
+            __syncthreads();
+        }
     }
-    if (in) pinv[(size_t)blockIdx.x * PC_NB * PC_NB + r * PC_NB + c] = a[r][c];
-}
-
-// R[p][c] for p < nb, c < m
-__global__ void k_pc_gj_rows(int m, int p0, int nb, const double* __restrict__ src, const double* __restrict__ pinv,
-                             double* __restrict__ rows) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
-    const int tr = blockIdx.z;
     if (c >= m) return;
-    const double* pi = pinv + (size_t)tr * PC_NB * PC_NB + p * PC_NB;
+    const double* pi = a[p];
     double val;
     if (c >= p0 && c < p0 + nb) {
         val = pi[c - p0];
@@ -368,7 +378,7 @@ PcDev make_pcdev(const nk2d_ctx* c, const Precond* pc) {
 void nk2d_precond_free(nk2d_ctx* c) {
     Precond* pc = (Precond*)c->precond;
     if (!pc) return;
-    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->PINV, pc->ROWS};
+    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->ROWS};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     delete pc;
@@ -389,7 +399,7 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
         nk2d_precond_free(c);
         pc = new Precond();
         c->precond = pc;
-        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->PINV = pc->ROWS = nullptr;
+        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->ROWS = nullptr;
         pc->cap_sys = std::max(nsys, mode == 1 ? 2 : nsys);
     }
     pc->mode = mode;
@@ -408,7 +418,6 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
         NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * PL_COUNT * P));
         NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * cap * pc->nb * mm));
         NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * cap * mm));
-        NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * cap * PC_NB * PC_NB));
         NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * cap * PC_NB * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * cap * pc->nb * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * cap * pc->nb * pc->m));
@@ -441,9 +450,8 @@ int precond_eliminate(nk2d_ctx* c) {
             const int nbk = std::min(PC_NB, m - p0);
             const double* from = pc->BUF + (size_t)src * nsys * mm;
             double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
-            hipLaunchKernelGGL(k_pc_gj_pivot, dim3(nsys), dim3(PC_NB, PC_NB), 0, c->stream, m, p0, nbk, from, pc->PINV);
             hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, c->stream, m, p0, nbk, from,
-                               pc->PINV, pc->ROWS);
+                               pc->ROWS);
             hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream, m, p0,
                                nbk, from, pc->ROWS, to);
             src = 1 - src;
