@@ -254,38 +254,44 @@ __global__ void __launch_bounds__(256) k_pc_gj_update(int m, int p0, int nb, con
     }
 }
 
-// dense mat-vec with the block-Thomas epilogues; one wave per row
+// dense mat-vec with the block-Thomas epilogues; one wave per row, eight 512-byte requests per wave in flight
 //   mode 0 (forward):  out[r] = rhs[r] - l[r] * sum_c M[r][c] a[c]
-//   mode 1 (backward): out[r] = sum_c M[r][c] (a[c] - u[c] b[c])      (b may be null)
-__global__ void k_pc_gemv(PcDev P, int mode, int j, const double* __restrict__ M, size_t m_tr_stride,
-                          const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ rhs,
-                          size_t v_tr_stride, double* __restrict__ out) {
+//   mode 1 (backward): out[r] = x_j[r] = sum_c M[r][c] a[c], where a = y_j - U_j x_{j+1} was left behind by the
+//                      launch of block j+1: this one turns y_{j-1} into y_{j-1} - U_{j-1} x_j in place (prev; the
+//                      couplings are diagonal, every row touches its own entry only)
+__global__ void __launch_bounds__(256) k_pc_gemv(PcDev P, int mode, int j, const double* __restrict__ M,
+                                                 size_t m_tr_stride, const double* __restrict__ a,
+                                                 const double* __restrict__ rhs, size_t v_tr_stride,
+                                                 double* __restrict__ out, double* __restrict__ prev) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int tr = blockIdx.y;
     if (r >= P.m) return;
     const double* row = M + (size_t)tr * m_tr_stride + (size_t)r * P.m;
     const double* av = a + (size_t)tr * v_tr_stride;
-    const double* bv = b ? b + (size_t)tr * v_tr_stride : nullptr;
-    double acc = 0.0;
-    for (int c = lane; c < P.m; c += 64) {
-        double x = av[c];
-        if (mode == 1 && bv) {
-            const int tc_ = c / P.nz, kc = c - tc_ * P.nz;
-            const double u = lat_u(P, tc_, kc, j);
-            x = x - u * bv[c];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = lane; c0 < P.m; c0 += 512) {
+        double mv[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = c0 + 64 * q;
+            const bool in = c < P.m;
+            mv[q] = in ? row[c] : 0.0;
+            xv[q] = in ? av[c] : 0.0;
         }
-        acc = __builtin_fma(row[c], x, acc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q & 3] = __builtin_fma(mv[q], xv[q], acc[q & 3]);
     }
-    acc = wave_sum(acc);
+    const double sum = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
     if (lane == 0) {
-        double res = acc;
+        const int slot = r / P.nz, k = r - slot * P.nz;
+        const size_t at = (size_t)tr * v_tr_stride + r;
         if (mode == 0) {
-            const int tau = r / P.nz, k = r - tau * P.nz;
-            const double l = lat_l(P, tau, k, j);
-            res = rhs[(size_t)tr * v_tr_stride + r] - l * acc;
+            out[at] = rhs[at] - lat_l(P, slot, k, j) * sum;
+        } else {
+            out[at] = sum;
+            if (prev) prev[at] = prev[at] - lat_u(P, slot, k, j - 1) * sum;
         }
-        out[(size_t)tr * v_tr_stride + r] = res;
     }
 }
 
@@ -485,13 +491,13 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
                                      hipMemcpyDeviceToDevice, c->stream));
     for (int j = 1; j < nb; ++j)
         hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
-                           yv + (size_t)(j - 1) * m, (const double*)nullptr, xv + (size_t)j * m, vstride,
-                           yv + (size_t)j * m);
-    // backward: x_j = Sinv_j (y_j - U_j x_{j+1})
+                           yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
+                           (double*)nullptr);
+    // backward: x_j = Sinv_j (y_j - U_j x_{j+1}); each launch leaves y_{j-1} - U_{j-1} x_j behind for the next
     for (int j = nb - 1; j >= 0; --j)
         hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
-                           yv + (size_t)j * m, (j < nb - 1) ? xv + (size_t)(j + 1) * m : (const double*)nullptr,
-                           (const double*)nullptr, vstride, xv + (size_t)j * m);
+                           yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
+                           (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
     NK2D_CHECK(c, hipGetLastError());
     return 0;
 }
