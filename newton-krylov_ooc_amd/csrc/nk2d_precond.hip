@@ -149,48 +149,52 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
 // single workgroup that everything else would wait for.
 __global__ void __launch_bounds__(256) k_pc_gj_rows(int m, int p0, int nb, const double* __restrict__ src,
                                                     double* __restrict__ rows) {
-    __shared__ double a[PC_NB][PC_NB + 1];
+    __shared__ double ab[2][PC_NB][PC_NB + 1];   // ping-pong: one barrier per pivot
     const int tr = blockIdx.z;
-    {
-        const size_t base = (size_t)tr * m * m;
-        for (int idx = threadIdx.x; idx < PC_NB * PC_NB; idx += 256) {
-            const int r = idx / PC_NB, c = idx - r * PC_NB;
-            const bool in = r < nb && c < nb;
-            a[r][c] = in ? src[base + (size_t)(p0 + r) * m + (p0 + c)] : ((r == c) ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        for (int p = 0; p < nb; ++p) {
-            const double piv = 1.0 / a[p][p];
-            double upd[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = threadIdx.x + 256 * q;
-                const int r = idx / PC_NB, c = idx - r * PC_NB;
-                const double prow = ((c == p) ? 1.0 : a[p][c]) * piv;
-                const double f = a[r][p];
-                const double old = (c == p) ? 0.0 : a[r][c];
-                upd[q] = (r == p) ? prow : __builtin_fma(-f, prow, old);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = threadIdx.x + 256 * q;
-                a[idx / PC_NB][idx % PC_NB] = upd[q];
-            }
-            __syncthreads();
-        }
-    }
+    const size_t base = (size_t)tr * m * m;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = blockIdx.y;
+    // this thread's column of the pivot rows, requested first: it arrives while the block is inverted
+    double col[PC_NB];
+#pragma unroll
+    for (int q = 0; q < PC_NB; ++q) col[q] = (c < m && q < nb) ? src[base + (size_t)(p0 + q) * m + c] : 0.0;
+    // the thread's four entries of the pivot block: column cc, rows r0 + 8 q
+    const int r0 = threadIdx.x / PC_NB, cc = threadIdx.x - r0 * PC_NB;
+    double mine[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 8 * q;
+        mine[q] = (r < nb && cc < nb) ? src[base + (size_t)(p0 + r) * m + (p0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab[0][r0 + 8 * q][cc] = mine[q];
+    __syncthreads();
+    int cur = 0;
+    for (int pp = 0; pp < nb; ++pp) {
+        double (*a)[PC_NB + 1] = ab[cur];
+        const double piv = 1.0 / a[pp][pp];
+        const double prow = ((cc == pp) ? 1.0 : a[pp][cc]) * piv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 8 * q;
+            const double f = a[r][pp];
+            const double old = (cc == pp) ? 0.0 : mine[q];
+            mine[q] = (r == pp) ? prow : __builtin_fma(-f, prow, old);
+            ab[1 - cur][r][cc] = mine[q];
+        }
+        cur = 1 - cur;
+        __syncthreads();
+    }
+    double (*a)[PC_NB + 1] = ab[cur];
     if (c >= m) return;
     const double* pi = a[p];
     double val;
     if (c >= p0 && c < p0 + nb) {
         val = pi[c - p0];
     } else {
-        const double* col = src + (size_t)tr * m * m + (size_t)p0 * m + c;
         double acc = 0.0;
-        for (int q = 0; q < nb; ++q) acc = __builtin_fma(pi[q], col[(size_t)q * m], acc);
+#pragma unroll
+        for (int q = 0; q < PC_NB; ++q) acc = __builtin_fma(pi[q], col[q], acc);   // col[q] = 0 beyond nb
         val = acc;
     }
     rows[((size_t)tr * PC_NB + p) * m + c] = val;
@@ -205,18 +209,37 @@ __global__ void __launch_bounds__(256) k_pc_gj_update(int m, int p0, int nb, con
     const size_t base = (size_t)tr * m * m;
     const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * PC_NB; idx += 256) {
+    const int ty = tid / 16, tx = tid - ty * 16;   // thread owns rows ty*4.., columns tx + 16*k
+    // every request of the workgroup goes out before the first use: operands, then the tile itself
+    double lf[8], lr[8], tile[4][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
         const int ii = idx / PC_NB, q = idx - ii * PC_NB;
         const int i = i0 + ii;
-        sf[ii][q] = (i < m && q < nb) ? src[base + (size_t)i * m + p0 + q] : 0.0;
+        lf[k] = (i < m && q < nb) ? src[base + (size_t)i * m + p0 + q] : 0.0;
     }
-    for (int idx = tid; idx < PC_NB * 64; idx += 256) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
         const int q = idx / 64, cc = idx - q * 64;
         const int c = c0 + cc;
-        sr[q][cc] = (c < m && q < nb) ? rows[((size_t)tr * PC_NB + q) * m + c] : 0.0;
+        lr[k] = (c < m && q < nb) ? rows[((size_t)tr * PC_NB + q) * m + c] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + ty * 4 + a, c = c0 + tx + 16 * b;
+            tile[a][b] = (i < m && c < m) ? src[base + (size_t)i * m + c] : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        sf[idx / PC_NB][idx % PC_NB] = lf[k];
+        sr[idx / 64][idx % 64] = lr[k];
     }
     __syncthreads();
-    const int ty = tid / 16, tx = tid - ty * 16;   // thread owns rows ty*4.., columns tx + 16*k
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -247,7 +270,7 @@ __global__ void __launch_bounds__(256) k_pc_gj_update(int m, int p0, int nb, con
                 val = sr[i - p0][tx + 16 * b];
             } else {
                 const bool pivot_col = c >= p0 && c < p0 + nb;
-                val = (pivot_col ? 0.0 : src[base + (size_t)i * m + c]) - acc[a][b];
+                val = (pivot_col ? 0.0 : tile[a][b]) - acc[a][b];
             }
             dst[base + (size_t)i * m + c] = val;
         }
