@@ -92,7 +92,8 @@ typedef struct nk2d_desc {
     double rtol, atol;         /* Radau tolerances (1e-6, 1e-6) */
     double max_step_frac;      /* max_step = frac*(t1-t0) (0.01) */
     double lin_tol;            /* target relative accuracy of the inner line-relaxation solves */
-    /* module kind: 0 = linear sources above (iage, forced); 1 = phosphorus (po4, dop, pop;
+    /* module kind: 0 = linear sources above (iage, forced); 2 = forced with forcing files (below);
+       1 = phosphorus (po4, dop, pop;
        nk_ooc/py_driver_2d/phosphorus.py:17-172), then tc = 3 and
        phos_params = {po4_halfsat, max_uptake_rate, sigma, dop_remin_rate, pop_remin_rate,
        pop_sink_vel} (phosphorus.py:42-58), light_lim [nz][ny] (phosphorus.py:26-29) */
@@ -100,6 +101,22 @@ typedef struct nk2d_desc {
     int32_t reserved0;
     double phos_params[6];
     const double* light_lim;
+    /* module kind 2 = forced module with file-driven forcing (nk_ooc/py_driver_2d/forced.py:42-56,
+       125-153,188-202): tc = 1.  The records are the file's fields already interpolated to the
+       model axes (nk_ooc/utils.py:488-533); the library interpolates them linearly in time with
+       linear extrapolation beyond the first / last record, as scipy's interp1d(fill_value=
+       "extrapolate") does.  restore_nrec > 0: tend[0][0][:] += surf_rate[0]*(restore(t) - c[0][:])
+       with restore(t) from the records instead of surf_target[0].  sms_nrec > 0: tend += sms(t),
+       and with sink_thres > 0 sms is multiplied by c/sink_thres where sms < 0 and 0 < c/sink_thres < 1
+       (then the Jacobian has the state-dependent diagonal of forced.py:188-202).  decay_rate[0] and
+       const_src keep their meaning (forced_sms_opt = decay / const). */
+    int32_t restore_nrec;
+    int32_t sms_nrec;
+    const double* restore_times; /* [restore_nrec], seconds, increasing */
+    const double* restore_vals;  /* [restore_nrec][ny] */
+    const double* sms_times;     /* [sms_nrec] */
+    const double* sms_vals;      /* [sms_nrec][nz][ny] */
+    double sink_thres;           /* 0: no threshold */
 } nk2d_desc;
 
 typedef struct nk2d_stats {
@@ -159,6 +176,10 @@ int nk2d_comp_fcn_hist(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats
 
 /* preconditioner  M^-1 v = (I - prod_k (I - dt J(t_k)))^-1 v - v */
 int nk2d_precond_setup(nk2d_ctx* ctx);
+/* the same for a forced module whose Jacobian depends on the state (file source with sink_thres):
+   states[i] = the tracer at the end of the i-th third of [t0, t1], as forced.apply_precond_jacobian
+   reads it from the preconditioner file (py_driver_2d/forced.py:222-236) */
+int nk2d_precond_setup_states(nk2d_ctx* ctx, const nk2d_vec* states);
 int nk2d_precond_apply(nk2d_ctx* ctx, nk2d_vec v, nk2d_vec out);
 /* shifted systems of the phosphorus preconditioner (phosphorus.py:233-255): factorise
    A_i = scale * J(t, lin_state) - shifts[i] * I (all tracers of the module coupled, nshift <=

@@ -53,6 +53,13 @@ class Desc(ctypes.Structure):
         ("reserved0", ctypes.c_int32),
         ("phos_params", ctypes.c_double * 6),
         ("light_lim", c_double_p),
+        ("restore_nrec", ctypes.c_int32),
+        ("sms_nrec", ctypes.c_int32),
+        ("restore_times", c_double_p),
+        ("restore_vals", c_double_p),
+        ("sms_times", c_double_p),
+        ("sms_vals", c_double_p),
+        ("sink_thres", ctypes.c_double),
     ]
 
 
@@ -105,6 +112,7 @@ SIGNATURES = {
                             c_double_p, _i64, c_int64_p]),
     "nk2d_comp_fcn_hist": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), _i32, c_double_p, c_double_p]),
     "nk2d_precond_setup": (_ci, [_vp]),
+    "nk2d_precond_setup_states": (_ci, [_vp, ctypes.POINTER(_vp)]),
     "nk2d_precond_apply": (_ci, [_vp, _vp, _vp]),
     "nk2d_dot": (_ci, [_vp, _vp, _vp, c_double_p]),
     "nk2d_axpby": (_ci, [_vp, _vp, c_double_p, _vp, c_double_p, _vp]),

@@ -212,7 +212,27 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->d = *desc;
     c->nz = desc->nz; c->ny = desc->ny; c->tc = desc->tc;
     c->kind = desc->module_kind;
-    if (c->kind != 0 && c->kind != 1) return nk2d_fail(c, "nk2d_create: unknown module_kind");
+    if (c->kind != 0 && c->kind != 1 && c->kind != 2) return nk2d_fail(c, "nk2d_create: unknown module_kind");
+    c->SMSREC = c->RESTREC = nullptr;
+    c->sms_t = c->rest_t = nullptr;
+    if (c->kind == 2) {
+        if (c->tc != 1) return nk2d_fail(c, "nk2d_create: the forced module has 1 tracer");
+        if (desc->restore_nrec < 0 || desc->sms_nrec < 0 || desc->restore_nrec == 1 || desc->sms_nrec == 1)
+            return nk2d_fail(c, "nk2d_create: a forcing set needs at least 2 records");
+        if (desc->restore_nrec == 0 && desc->sms_nrec == 0)
+            return nk2d_fail(c, "nk2d_create: module_kind 2 without forcing records (use module_kind 0)");
+        if ((desc->restore_nrec > 0 && (!desc->restore_times || !desc->restore_vals)) ||
+            (desc->sms_nrec > 0 && (!desc->sms_times || !desc->sms_vals)))
+            return nk2d_fail(c, "nk2d_create: forcing records missing");
+        if (desc->sink_thres < 0.0) return nk2d_fail(c, "nk2d_create: sink_thres < 0");
+        for (int i = 1; i < desc->restore_nrec; ++i)
+            if (!(desc->restore_times[i] > desc->restore_times[i - 1])) return nk2d_fail(c, "nk2d_create: restore_times not increasing");
+        for (int i = 1; i < desc->sms_nrec; ++i)
+            if (!(desc->sms_times[i] > desc->sms_times[i - 1])) return nk2d_fail(c, "nk2d_create: sms_times not increasing");
+    } else {
+        c->d.restore_nrec = c->d.sms_nrec = 0;
+        c->d.sink_thres = 0.0;
+    }
     if (c->kind == 1 && (c->tc != 3 || desc->light_lim == nullptr))
         return nk2d_fail(c, "nk2d_create: the phosphorus module has 3 tracers and needs light_lim");
     if (c->nz < 2 || c->ny < 1 || c->tc < 1 || c->tc > NK2D_MAX_TRACERS) return nk2d_fail(c, "nk2d_create: bad grid / tracer count");
@@ -222,6 +242,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->ncol = c->tc * c->ny;
     c->nv = (size_t)c->ncol * c->nzp;
     c->np = (size_t)c->ny * c->nzp;
+    c->kv_len = (c->kind == 2) ? 2 * c->np + (size_t)c->ny : c->np;
     c->nreg = 0;
     c->dev = desc->device_id;
     NK2D_CHECK(c, hipSetDevice(c->dev));
@@ -250,7 +271,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->UPR, c->np));
     c->YLIN = nullptr;
     c->ylin_set = 0;
-    for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->KV[i], c->np));
+    for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->KV[i], c->kv_len));
     NK2D_TRY(dev_alloc(c, &c->Y, c->nv));
     NK2D_TRY(dev_alloc(c, &c->YOLD, c->nv));
     NK2D_TRY(dev_alloc(c, &c->F, c->nv));
@@ -339,10 +360,26 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipMemcpy(c->DYR, dyr.data(), sizeof(double) * ny, hipMemcpyHostToDevice));
     NK2D_CHECK(c, hipMemcpy(c->BLDMAX, desc->bldepth_max, sizeof(double) * ny, hipMemcpyHostToDevice));
     if (c->kind == 1) NK2D_TRY(upload_plane(c, desc->light_lim, nz, ny, c->LIGHT));
+    if (c->kind == 2) {
+        if (desc->sms_nrec > 0) {
+            NK2D_TRY(dev_alloc(c, &c->SMSREC, (size_t)desc->sms_nrec * c->np));
+            for (int r = 0; r < desc->sms_nrec; ++r)
+                NK2D_TRY(upload_plane(c, desc->sms_vals + (size_t)r * nz * ny, nz, ny, c->SMSREC + (size_t)r * c->np));
+            c->sms_t = new double[desc->sms_nrec];
+            std::memcpy(c->sms_t, desc->sms_times, sizeof(double) * desc->sms_nrec);
+        }
+        if (desc->restore_nrec > 0) {
+            NK2D_TRY(dev_alloc(c, &c->RESTREC, (size_t)desc->restore_nrec * ny));
+            NK2D_CHECK(c, hipMemcpy(c->RESTREC, desc->restore_vals, sizeof(double) * desc->restore_nrec * ny, hipMemcpyHostToDevice));
+            c->rest_t = new double[desc->restore_nrec];
+            std::memcpy(c->rest_t, desc->restore_times, sizeof(double) * desc->restore_nrec);
+        }
+    }
     build_front(c, dzr, dyr);
     // the descriptor's pointers are not kept
     c->d.depth_edges = c->d.ypos_edges = c->d.vvel = c->d.wvel = c->d.hmix_coeff = c->d.bldepth_max = nullptr;
     c->d.light_lim = nullptr;
+    c->d.restore_times = c->d.restore_vals = c->d.sms_times = c->d.sms_vals = nullptr;
     // default region: everything in region 1 with unit weights until nk2d_set_region is called
     {
         std::vector<int32_t> m((size_t)nz * ny, 1);
@@ -387,9 +424,12 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF,
-                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN};
+                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN,
+                      c->SMSREC, c->RESTREC};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
+    delete[] c->sms_t;
+    delete[] c->rest_t;
     for (double* b : c->vec_pool) (void)hipFree(b);
     float* fbufs[] = {c->FR32_INV, c->FC32_INVR, c->FC32_INVI, c->FR32_TAB, c->FC32_TABR, c->FC32_TABI};
     for (float* b : fbufs)
@@ -551,7 +591,7 @@ extern "C" int nk2d_vmix_coeff(nk2d_ctx* c, double t, double* host_out) {
 }
 
 // linearisation state of the stand-alone Jacobian entry points (state dependent modules only)
-static const double* lin_state(nk2d_ctx* c) { return (c->kind == 1 && c->ylin_set) ? c->YLIN : nullptr; }
+static const double* lin_state(nk2d_ctx* c) { return (c->kind != 0 && c->ylin_set) ? c->YLIN : nullptr; }
 
 extern "C" int nk2d_set_lin_state(nk2d_ctx* c, nk2d_vec y) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
@@ -575,11 +615,17 @@ extern "C" int nk2d_jacobian_diags(nk2d_ctx* c, double t, double* host_out) {
     if (c->kind == 1) return nk2d_fail(c, "nk2d_jacobian_diags: the phosphorus Jacobian is not five diagonals; use nk2d_jacobian_apply");
     double* out[1] = {c->KV[4]};
     NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
-    NK2D_TRY(nk2d_k_jac(c, c->KV[4], nullptr));
+    NK2D_TRY(nk2d_k_jac(c, c->KV[4], lin_state(c)));
     const size_t P = (size_t)c->nz * c->ny;
     NK2D_TRY(ensure_stage(c, P));
     const double* planes[5] = {c->JL, c->JS, c->JC, c->JN, c->JU};
-    std::vector<double> tmp(P);
+    std::vector<double> tmp(P), extra;
+    if (c->kind == 2) {
+        // state dependent part of the diagonal (sink threshold, forced.py:188-202); zero without it
+        extra.resize(P);
+        NK2D_TRY(nk2d_k_unpack_plane(c, c->UPR, c->nz, c->ny, c->STAGE));
+        NK2D_TRY(stage_out(c, extra.data(), P));
+    }
     for (int d = 0; d < 5; ++d) {
         NK2D_TRY(nk2d_k_unpack_plane(c, planes[d], c->nz, c->ny, c->STAGE));
         NK2D_TRY(stage_out(c, tmp.data(), P));
@@ -591,6 +637,8 @@ extern "C" int nk2d_jacobian_diags(nk2d_ctx* c, double t, double* host_out) {
                 for (int j = 0; j < c->ny; ++j) dst[j] = dst[j] + (-c->d.surf_rate[tr]);
                 if (c->d.decay_rate[tr] != 0.0)
                     for (size_t i = 0; i < P; ++i) dst[i] = dst[i] + (-c->d.decay_rate[tr]);
+                if (!extra.empty())
+                    for (size_t i = 0; i < P; ++i) dst[i] = dst[i] - extra[i];
             }
         }
     }

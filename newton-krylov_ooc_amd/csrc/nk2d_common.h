@@ -32,7 +32,7 @@
 struct nk2d_ctx {
     nk2d_desc d;
     int nz, ny, tc, E, nzp, ncol, nreg;
-    int kind;   // module kind: 0 linear sources (iage, forced), 1 phosphorus
+    int kind;   // module kind: 0 linear sources (iage, forced), 1 phosphorus, 2 forced with forcing files
     size_t nv;  // doubles per state vector  (tc*ny*nzp)
     size_t np;  // doubles per (depth, ypos) plane (ny*nzp)
     int dev;
@@ -59,6 +59,12 @@ struct nk2d_ctx {
     // phosphorus module: light limitation [np], d uptake / d po4 at the linearisation state [np],
     // linearisation state of the stand-alone Jacobian entry points [nv]
     double *LIGHT, *UPR, *YLIN;
+    // kind 2: forcing records on the device (packed planes / rows), their times on the host, and the length
+    // of a KV buffer: the vertical mixing plane, then (kind 2) the source plane and the restoring targets of
+    // the same time -- whatever is a function of time alone travels in one bundle
+    double *SMSREC, *RESTREC;
+    double *sms_t, *rest_t;
+    size_t kv_len;
     int ylin_set;
     // vertical mixing planes: 3 stage times, current t, scratch
     double* KV[5];
@@ -176,10 +182,13 @@ static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK 
         default: break;                                              \
     }
 
-// as above, plus a compile-time module kind KK (0: linear sources, 1: phosphorus)
+// as above, plus a compile-time module kind KK (0: linear sources, 1: phosphorus, 2: forcing files)
 #define NK2D_DISPATCH_EK(Eval, kind, ...)                                        \
     if ((kind) == 1) {                                                            \
         constexpr int KK = 1;                                                     \
+        NK2D_DISPATCH_E(Eval, __VA_ARGS__)                                        \
+    } else if ((kind) == 2) {                                                     \
+        constexpr int KK = 2;                                                     \
         NK2D_DISPATCH_E(Eval, __VA_ARGS__)                                        \
     } else {                                                                      \
         constexpr int KK = 0;                                                     \

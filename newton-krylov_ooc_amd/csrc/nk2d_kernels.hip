@@ -20,6 +20,12 @@ struct DevP {
     // phosphorus module (kind 1): parameters, light limitation plane, d uptake / d po4 at t_jac
     double ph_hs, ph_mu, ph_sig, ph_rd, ph_rp, ph_vs;
     const double *LIGHT, *UPR;
+    // forced module with forcing files (kind 2): record sets, flags, 1 / sink_thres (0: none); np = doubles per
+    // plane = offset of the source plane inside a KV bundle (the restoring targets follow at 2 np)
+    const double *SMSREC, *RESTREC;
+    int f_sms, f_restore;
+    double f_thres_r;
+    size_t np;
 };
 
 static DevP make_devp(const nk2d_ctx* c) {
@@ -37,6 +43,11 @@ static DevP make_devp(const nk2d_ctx* c) {
     p.ph_hs = c->d.phos_params[0]; p.ph_mu = c->d.phos_params[1]; p.ph_sig = c->d.phos_params[2];
     p.ph_rd = c->d.phos_params[3]; p.ph_rp = c->d.phos_params[4]; p.ph_vs = c->d.phos_params[5];
     p.LIGHT = c->LIGHT; p.UPR = c->UPR;
+    p.SMSREC = c->SMSREC; p.RESTREC = c->RESTREC;
+    p.f_sms = (c->kind == 2) ? c->d.sms_nrec : 0;
+    p.f_restore = (c->kind == 2) ? c->d.restore_nrec : 0;
+    p.f_thres_r = (c->kind == 2 && c->d.sink_thres > 0.0) ? 1.0 / c->d.sink_thres : 0.0;
+    p.np = c->np;
     return p;
 }
 
@@ -161,7 +172,31 @@ struct VmixArgs {
     double frac[4];
     double* out[4];
     double bldmin, y0, y1, hw;
+    // kind 2: bracketing records of the forcing sets at each time, x_new - x_lo and x_hi - x_lo
+    int srec[4], rrec[4];
+    double sdx[4], sden[4], rdx[4], rden[4];
 };
+
+// host: bracketing interval of x in the increasing knots xs[0..n) as scipy's interp1d picks it
+// (searchsorted, clipped to [1, n-1]: the end intervals extrapolate)
+static void forcing_bracket(int n, const double* xs, double x, int* lo, double* dx, double* den) {
+    int hi = 0;
+    while (hi < n && xs[hi] < x) ++hi;   // searchsorted(xs, x), side = "left"
+    if (hi < 1) hi = 1;
+    if (hi > n - 1) hi = n - 1;
+    *lo = hi - 1;
+    *dx = x - xs[hi - 1];
+    *den = xs[hi] - xs[hi - 1];
+}
+static void vmix_forcing_args(const nk2d_ctx* c, int nt, const double* times, VmixArgs& A) {
+    for (int i = 0; i < 4; ++i) { A.srec[i] = A.rrec[i] = 0; A.sdx[i] = A.rdx[i] = 0.0; A.sden[i] = A.rden[i] = 1.0; }
+    if (c->kind != 2) return;
+    for (int i = 0; i < nt; ++i) {
+        if (c->d.sms_nrec > 0) forcing_bracket(c->d.sms_nrec, c->sms_t, times[i], &A.srec[i], &A.sdx[i], &A.sden[i]);
+        if (c->d.restore_nrec > 0)
+            forcing_bracket(c->d.restore_nrec, c->rest_t, times[i], &A.rrec[i], &A.rdx[i], &A.rden[i]);
+    }
+}
 
 __device__ __forceinline__ double ramp2(double x, double x0, double x1, double y0, double y1, double slope) {
     if (x > x1) return y1;
@@ -218,6 +253,24 @@ __device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int 
         kv[e] = val;
     }
     store_col<E>(A.out[ti], j, lane, kv);
+    // forcing fields of the same time (kind 2), linear in time between two records:
+    // slope = (y_hi - y_lo) / (x_hi - x_lo), y = slope (x - x_lo) + y_lo  (scipy interp1d, utils.py:529-531)
+    if (P.f_sms > 0) {
+        double lo[E], hi[E], val[E];
+        load_col<E>(P.SMSREC + (size_t)A.srec[ti] * P.np, j, lane, lo);
+        load_col<E>(P.SMSREC + (size_t)(A.srec[ti] + 1) * P.np, j, lane, hi);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double slope = (hi[e] - lo[e]) / A.sden[ti];
+            val[e] = ((lane * E + e) < P.nz) ? slope * A.sdx[ti] + lo[e] : 0.0;
+        }
+        store_col<E>(A.out[ti] + P.np, j, lane, val);
+    }
+    if (P.f_restore > 0 && lane == 0) {
+        const double lo = P.RESTREC[(size_t)A.rrec[ti] * P.ny + j], hi = P.RESTREC[(size_t)(A.rrec[ti] + 1) * P.ny + j];
+        const double slope = (hi - lo) / A.rden[ti];
+        A.out[ti][2 * P.np + j] = slope * A.rdx[ti] + lo;
+    }
 }
 
 template <int E>
@@ -233,6 +286,7 @@ int nk2d_k_vmix(nk2d_ctx* c, int nt, const double* times, double* const* out) {
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &A.frac[i]);
         A.out[i] = out[i];
     }
+    vmix_forcing_args(c, nt, times, A);
     A.bldmin = c->d.bldepth_min; A.y0 = c->d.vmix_log_shallow; A.y1 = c->d.vmix_log_deep;
     A.hw = c->d.vmix_half_width;
     DevP P = make_devp(c);
@@ -266,7 +320,7 @@ __device__ __forceinline__ void load_coef(const DevP& P, int j, int lane, ColCoe
 
 // c: own column, cs / cn: columns j-1 / j+1 (any finite values at the walls, their
 // face coefficients are zero), kv: vertical mixing coeff between level k and k+1
-template <int E>
+template <int E, int KIND = 0>
 __device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, const double (&c)[E],
                                          const double (&cs)[E], const double (&cn)[E], const double (&kv)[E],
                                          int tr, int lane, double (&out)[E]) {
@@ -293,10 +347,42 @@ __device__ __forceinline__ void tend_col(const DevP& P, const ColCoef<E>& cf, co
         const double hT = kvprev[e] * (c[e] - cprev[e]);
         const double hB = kv[e] * (cnext[e] - c[e]);
         t = t + cf.dzr[e] * (hB - hT);
-        // module sources (iage.py:31-39, forced.py:114-139)
-        if (k == 0 && surf != 0.0) t = t + surf * (starget - c[e]);
-        if (decay != 0.0) t = t + (-decay * c[e]);
+        // module sources (iage.py:31-39, forced.py:114-139); kind 2 adds them in forced_sources
+        if constexpr (KIND != 2) {
+            if (k == 0 && surf != 0.0) t = t + surf * (starget - c[e]);
+            if (decay != 0.0) t = t + (-decay * c[e]);
+            if (P.csrc != 0.0) t = t + P.csrc;
+        }
+        out[e] = (k < P.nz) ? t : 0.0;
+    }
+}
+
+// sources of the forced module with forcing files, in the reference's order (forced.py:125-153): surface
+// restoring towards the constant or the time-dependent target, then the constant / decay / file source,
+// the latter scaled down where it is a sink and the tracer is below the threshold.  kvb: the KV bundle of
+// the evaluation time (source plane at np, restoring targets at 2 np).
+template <int E>
+__device__ __forceinline__ void forced_sources(const DevP& P, const double* __restrict__ kvb, int j, int lane,
+                                               const double (&c)[E], double (&out)[E]) {
+    double sms[E];
+    if (P.f_sms > 0) load_col<E>(kvb + P.np, j, lane, sms);
+    const double surf = P.surf[0], decay = P.decay[0];
+    const double target = (P.f_restore > 0) ? kvb[2 * P.np + j] : P.starget[0];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        double t = out[e];
+        if (k == 0 && surf != 0.0) t = t + surf * (target - c[e]);
         if (P.csrc != 0.0) t = t + P.csrc;
+        if (decay != 0.0) t = t + (-decay * c[e]);
+        if (P.f_sms > 0) {
+            double s = sms[e];
+            if (P.f_thres_r != 0.0) {
+                const double tmp = P.f_thres_r * c[e];
+                if (s < 0.0 && tmp > 0.0 && tmp < 1.0) s = s * tmp;
+            }
+            t = t + s;
+        }
         out[e] = (k < P.nz) ? t : 0.0;
     }
 }
@@ -371,7 +457,8 @@ __global__ void k_tend(DevP P, const double* __restrict__ y, const double* __res
     load_col<E>(y, (j > 0) ? task - 1 : task, lane, cs);
     load_col<E>(y, (j < P.ny - 1) ? task + 1 : task, lane, cn);
     load_col<E>(kvp, j, lane, kv);
-    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, out);
+    tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, out);
+    if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, out);
     if constexpr (KIND == 1) {
         double u1[E], u2[E];
         phos_load_others<E>(P, tr, j, lane, y, u1, u2);
@@ -430,7 +517,20 @@ __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict
     store_col<E>(JS, j, lane, so);
     store_col<E>(JN, j, lane, no);
     store_col<E>(JC, j, lane, ce);
-    if (ylin != nullptr) {
+    if (ylin != nullptr && P.f_sms > 0) {
+        // forced module, file source with a sink threshold: UPR = -d sms / d tracer at the linearisation state
+        // and the time of the bundle (forced.py:188-202); zero without a threshold
+        double cc[E], sms[E], upr[E];
+        load_col<E>(ylin, j, lane, cc);
+        load_col<E>(kvp + P.np, j, lane, sms);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double tmp = P.f_thres_r * cc[e];
+            const bool on = P.f_thres_r != 0.0 && sms[e] < 0.0 && tmp > 0.0 && tmp < 1.0;
+            upr[e] = (on && (lane * E + e) < P.nz) ? -(P.f_thres_r * sms[e]) : 0.0;
+        }
+        store_col<E>(UPR, j, lane, upr);
+    } else if (ylin != nullptr) {
         // d uptake / d po4 at the linearisation state (phosphorus.py:97-103)
         double po4[E], light[E], upr[E];
         load_col<E>(ylin, j, lane, po4);
@@ -449,7 +549,9 @@ __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict
 int nk2d_k_jac(nk2d_ctx* c, const double* kv, const double* ylin) {
     DevP P = make_devp(c);
     if (c->kind == 1 && ylin == nullptr) return nk2d_fail(c, "nk2d_k_jac: the phosphorus Jacobian needs a linearisation state");
-    if (c->kind != 1) ylin = nullptr;
+    if (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0 && ylin == nullptr)
+        return nk2d_fail(c, "nk2d_k_jac: a forced module with a sink threshold needs a linearisation state");
+    if (c->kind == 0 || (c->kind == 2 && !(c->d.sms_nrec > 0 && c->d.sink_thres > 0.0))) ylin = nullptr;
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_jac<EE>, dim3(nk2d_grid(c->ny)), dim3(NK2D_BLOCK), 0, c->stream, P, kv,
                                                c->JL, c->JU, c->JS, c->JN, c->JC, ylin, c->UPR));
     NK2D_CHECK(c, hipGetLastError());
@@ -538,11 +640,13 @@ __device__ __forceinline__ void line_diag(const DevP& P, const double* __restric
         load_col<E>(P.UPR, j, lane, upr);
         load_col<E>(P.DZR, 0, lane, dzr);
     }
+    if constexpr (KIND == 2) load_col<E>(P.UPR, j, lane, upr);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = lane * E + e;
         double d = (shift_re - jc[e]) + P.decay[tr];
         if (k == 0) d = d + P.surf[tr];
+        if constexpr (KIND == 2) d = d + upr[e];
         if constexpr (KIND == 1) {
             if (tr == 0) d = d + upr[e];
             else if (tr == 1) d = d + P.ph_rd;
@@ -594,11 +698,13 @@ __global__ void k_jac_apply(DevP P, SweepArgs A, const double* __restrict__ v, d
         load_col<E>(P.UPR, j, lane, upr);
         load_col<E>(P.DZR, 0, lane, dzr);
     }
+    if constexpr (KIND == 2) load_col<E>(P.UPR, j, lane, upr);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = lane * E + e;
         double d = jc[e] - P.decay[tr];
         if (k == 0) d = d - P.surf[tr];
+        if constexpr (KIND == 2) d = d - upr[e];
         if constexpr (KIND == 1) {
             if (tr == 0) d = d - upr[e];
             else if (tr == 1) d = d - P.ph_rd;
@@ -1131,7 +1237,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
             load_col<E>(A.st.kv[i], j, lane, kv);
 #pragma unroll
             for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
-            tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, f);
+            tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
+            if constexpr (KIND == 2) forced_sources<E>(P, A.st.kv[i], j, lane, c, f);
             if constexpr (KIND == 1) {
                 double u1[E], u2[E], v1[E], v2[E];
                 phos_load_others<E>(P, tr, j, lane, A.st.y, u1, u2);
@@ -1459,7 +1566,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
 #pragma unroll
     for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
     load_col<E>(kvp, j, lane, kv);
-    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, ff);
     if constexpr (KIND == 1) {
         double u1[E], u2[E], v1[E], v2[E];
         phos_load_others<E>(P, tr, j, lane, y, u1, u2);
@@ -1505,7 +1613,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
 #pragma unroll
     for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
     load_col<E>(kvp, j, lane, kv);
-    tend_col<E>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, ff);
     if constexpr (KIND == 1) {
         double u1[E], u2[E], v1[E], v2[E];
         phos_load_others<E>(P, tr, j, lane, y, u1, u2);
@@ -1651,6 +1760,7 @@ int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, d
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
         V.out[i] = out[i];
     }
+    vmix_forcing_args(c, 3, times, V);
     V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
     V.hw = c->d.vmix_half_width;
     PredictArgs A = predict_args(c, x0, x1, x2);
@@ -1716,7 +1826,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     }
     if (do_factor) {  // always a launch with the stage part
         NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
-    } else if (do_stage || c->kind == 0) {
+    } else if (do_stage || c->kind != 1) {
         NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     } else {          // phosphorus, sweep-only launch: the lean instantiation
         NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));

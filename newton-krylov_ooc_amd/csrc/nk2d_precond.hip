@@ -117,6 +117,7 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
         if (kc == k) {
             double jc = pj(P, tau, PL_C, k, j) - P.decay[tr];
             if (k == 0) jc = jc - P.surf[tr];
+            if (P.kind == 2) jc = jc - pj(P, tau, PL_UPR, k, j);   // sink threshold of the forced module
             val = 1.0 - P.dt * jc;
         } else if (kc == k - 1) {
             val = -(P.dt * pj(P, tau, PL_L, k, j));
@@ -418,7 +419,8 @@ namespace {
 
 // allocate for `nsys` systems of block size m = nslot * nz, load the Jacobian planes at the
 // `nt` times and run the block elimination (Schur complements + their explicit inverses)
-int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const double* times, const double* ylin) {
+// ylin: linearisation state of every time level (state dependent modules), or null
+int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const double* times, const double* const* ylin) {
     Precond* pc = (Precond*)c->precond;
     const int m = nslot * c->nz;
     // gigabytes of Schur inverses: keep the allocation when the next factorisation fits in it (the
@@ -455,7 +457,7 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
         double t = times[tau];
         double* out[1] = {c->KV[4]};
         NK2D_TRY(nk2d_k_vmix(c, 1, &t, out));
-        NK2D_TRY(nk2d_k_jac(c, c->KV[4], ylin));
+        NK2D_TRY(nk2d_k_jac(c, c->KV[4], ylin ? ylin[tau] : nullptr));
         const double* planes[PL_COUNT] = {c->JL, c->JS, c->JC, c->JN, c->JU, c->UPR};
         for (int pl = 0; pl < PL_COUNT; ++pl)
             NK2D_TRY(nk2d_k_unpack_plane(c, planes[pl], c->nz, c->ny, pc->PJ + ((size_t)tau * PL_COUNT + pl) * P));
@@ -527,13 +529,31 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
 
 }  // namespace
 
+static int precond_setup_levels(nk2d_ctx* c, const double* const* states);
+
 extern "C" int nk2d_precond_setup(nk2d_ctx* c) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    if (c->kind != 0) return nk2d_fail(c, "nk2d_precond_setup: state dependent modules use nk2d_shift_factor / nk2d_shift_solve");
+    if (c->kind == 1) return nk2d_fail(c, "nk2d_precond_setup: the phosphorus module uses nk2d_shift_factor / nk2d_shift_solve");
+    if (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0)
+        return nk2d_fail(c, "nk2d_precond_setup: a forced module with a sink threshold needs nk2d_precond_setup_states");
+    return precond_setup_levels(c, nullptr);
+}
+
+// states[i]: the tracer at the end of the i-th third of the year (forced.apply_precond_jacobian,
+// forced.py:222-236); they enter through the sink threshold only
+extern "C" int nk2d_precond_setup_states(nk2d_ctx* c, const nk2d_vec* states) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->kind != 2) return nk2d_fail(c, "nk2d_precond_setup_states: forced modules with forcing files only");
+    if (!states || !states[0] || !states[1] || !states[2]) return nk2d_fail(c, "nk2d_precond_setup_states: three states needed");
+    const double* lv[3] = {(const double*)states[0], (const double*)states[1], (const double*)states[2]};
+    return precond_setup_levels(c, lv);
+}
+
+static int precond_setup_levels(nk2d_ctx* c, const double* const* states) {
     // Jacobian planes at the three mid-interval times (iage.py:85-89)
     const double dt = (c->d.t1 - c->d.t0) / 3;
     const double times[3] = {c->d.t0 + 0.5 * dt, c->d.t0 + 1.5 * dt, c->d.t0 + 2.5 * dt};
-    NK2D_TRY(precond_build(c, 0, 3, 3, c->tc, times, nullptr));
+    NK2D_TRY(precond_build(c, 0, 3, 3, c->tc, times, states));
     return precond_eliminate(c);
 }
 
@@ -546,7 +566,7 @@ extern "C" int nk2d_shift_factor(nk2d_ctx* c, double t, double scale, int32_t ns
         if (!c->ylin_set) return nk2d_fail(c, "nk2d_shift_factor: call nk2d_set_lin_state first");
         ylin = c->YLIN;
     }
-    NK2D_TRY(precond_build(c, 1, 1, c->tc, nshift, &t, ylin));
+    NK2D_TRY(precond_build(c, 1, 1, c->tc, nshift, &t, ylin ? &ylin : nullptr));
     Precond* pc = (Precond*)c->precond;
     pc->scale = scale;
     for (int i = 0; i < nshift; ++i) pc->sigma[i] = shifts[i];

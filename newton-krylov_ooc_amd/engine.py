@@ -56,7 +56,8 @@ class ModuleEngine:
     def __init__(self, grid, tc, surf_rate=(), decay_rate=(), const_src=0.0, surf_target=(),
                  device_id=0,
                  time_range=(0.0, YEAR), rtol=1.0e-6, atol=1.0e-6, max_step_frac=0.01,
-                 lin_tol=None, module_kind=0, phos_params=None, light_lim=None):
+                 lin_tol=None, module_kind=0, phos_params=None, light_lim=None,
+                 restore_series=None, sms_series=None, sink_thres=None):
         self._lib = _lib.load()
         self._ctx = None
         self.grid = grid
@@ -98,6 +99,20 @@ class ModuleEngine:
             assert keep[-1].shape == (self.nz, self.ny)
             desc.light_lim = _dp(keep[-1])
             desc.phos_params = (ctypes.c_double * 6)(*[float(v) for v in phos_params])
+        if module_kind == 2:
+            # forcing records on the model axes (forcing.load_forcing): (times, values)
+            if restore_series is not None:
+                times, vals = [np.ascontiguousarray(a, dtype=np.float64) for a in restore_series]
+                assert vals.shape == (len(times), self.ny)
+                keep += [times, vals]
+                desc.restore_nrec, desc.restore_times, desc.restore_vals = len(times), _dp(times), _dp(vals)
+            if sms_series is not None:
+                times, vals = [np.ascontiguousarray(a, dtype=np.float64) for a in sms_series]
+                assert vals.shape == (len(times), self.nz, self.ny)
+                keep += [times, vals]
+                desc.sms_nrec, desc.sms_times, desc.sms_vals = len(times), _dp(times), _dp(vals)
+            desc.sink_thres = 0.0 if sink_thres is None else float(sink_thres)
+        self.state_dependent_precond = module_kind == 2 and sms_series is not None and bool(sink_thres)
         self.module_kind = int(module_kind)
         self.light_lim = keep[-1] if module_kind == 1 else None
         self.phos = dict(zip(PHOSPHORUS_PARAM_NAMES, phos_params)) if module_kind == 1 else None
@@ -251,6 +266,13 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_precond_setup(self._ctx))
         self._precond_ready = True
 
+    def precond_setup_states(self, states):
+        """preconditioner of a forced module whose Jacobian depends on the state: `states` = the
+        tracer (device vectors) at the end of each third of the year (forced.py:222-236)"""
+        ptrs = (ctypes.c_void_p * 3)(*[v.ptr for v in states])
+        self._chk(self._lib.nk2d_precond_setup_states(self._ctx, ptrs))
+        self._precond_ready = True
+
     def shift_factor(self, t, scale, shifts):
         """factorise scale * J(t, lin_state) - shift * I for every shift (block elimination)"""
         arr = np.ascontiguousarray(shifts, dtype=np.float64)
@@ -348,26 +370,41 @@ def iage_engine(grid, device_id=0, **kwargs):
 
 
 def forced_engine(grid, modelinfo, device_id=0, **kwargs):
-    """engine of a `forced_{suff}` tracer module (one tracer) for the state-independent
-    option combinations of forced.py:57-139: surface restoring none / const, source-minus-sink
-    none / const / decay.  The file-driven options need the forcing readers of the Newton
-    driver row and are not on the Krylov hot path yet."""
+    """engine of a `forced_{suff}` tracer module (one tracer, forced.py:57-153): surface
+    restoring none / const / file, source-minus-sink none / const / decay / file (the file source
+    optionally with a sink threshold).  The file fields are read and put on the model axes here
+    (`forcing.load_forcing`); the device interpolates them in time."""
+    from .forcing import load_forcing
+
     restore_opt = modelinfo["forced_surf_restore_opt"]
     sms_opt = modelinfo["forced_sms_opt"]
-    if restore_opt not in ("none", "const") or sms_opt not in ("none", "const", "decay"):
-        raise NotImplementedError(
-            f"forced module with surf_restore_opt={restore_opt}, sms_opt={sms_opt} has no HIP engine yet")
+    if restore_opt not in ("none", "const", "file"):
+        raise ValueError(f"unknown forced_surf_restore_opt={restore_opt}")
+    if sms_opt not in ("none", "const", "decay", "file"):
+        raise ValueError(f"unknown forced_sms_opt={sms_opt}")
     if restore_opt == "none" and sms_opt != "decay":
         raise ValueError("forced_sms_opt must be decay if forced_surf_restore_opt == none")
     surf_rate, surf_target = 0.0, 0.0
-    if restore_opt == "const":
-        rate_10m = float(modelinfo.get("forced_surf_restore_rate_10m", 24.0 / 86400.0))
+    if restore_opt != "none":
+        rate_10m = _eval_number(modelinfo.get("forced_surf_restore_rate_10m", 24.0 / 86400.0))
         surf_rate = 10.0 / grid.depth.delta[0] * rate_10m
-        surf_target = float(modelinfo["forced_surf_restore_const"])
-    decay = float(modelinfo["forced_sms_decay_rate"]) if sms_opt == "decay" else 0.0
-    const_src = float(modelinfo["forced_sms_const"]) if sms_opt == "const" else 0.0
+    if restore_opt == "const":
+        surf_target = _eval_number(modelinfo["forced_surf_restore_const"])
+    decay = _eval_number(modelinfo["forced_sms_decay_rate"]) if sms_opt == "decay" else 0.0
+    const_src = _eval_number(modelinfo["forced_sms_const"]) if sms_opt == "const" else 0.0
+    files = {}
+    if restore_opt == "file":
+        files["restore_series"] = load_forcing(
+            modelinfo["forced_surf_restore_fname"], modelinfo["forced_surf_restore_varname"], [grid.ypos.mid])
+    if sms_opt == "file":
+        scalef = _eval_number(modelinfo["forced_sms_scalef"]) if "forced_sms_scalef" in modelinfo else 1.0
+        files["sms_series"] = load_forcing(
+            modelinfo["forced_sms_fname"], modelinfo["forced_sms_varname"], [grid.depth.mid, grid.ypos.mid], scalef)
+        if "forced_sink_thres" in modelinfo:
+            files["sink_thres"] = _eval_number(modelinfo["forced_sink_thres"])
     return ModuleEngine(grid, tc=1, surf_rate=(surf_rate,), surf_target=(surf_target,),
-                        decay_rate=(decay,), const_src=const_src, device_id=device_id, **kwargs)
+                        decay_rate=(decay,), const_src=const_src, device_id=device_id,
+                        module_kind=2 if files else 0, **files, **kwargs)
 
 
 PHOSPHORUS_PARAM_NAMES = ("po4_halfsat", "max_uptake_rate", "sigma", "dop_remin_rate",

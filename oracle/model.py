@@ -23,7 +23,7 @@ Reference lines restated here
 """
 
 import numpy as np
-from scipy import sparse
+from scipy import interpolate, sparse
 from scipy.sparse import linalg as sp_linalg
 
 YEAR = 365.0 * 86400.0
@@ -340,45 +340,107 @@ class Iage(TracerModule):
 
 
 class Forced(TracerModule):
-    """forced_{suff} module, one tracer, state-independent option combinations
-    (reference `py_driver_2d/forced.py:57-139,141-190`): surface restoring to a constant
-    (or none), source-minus-sink constant / first-order decay (or none)"""
+    """forced_{suff} module, one tracer (reference `py_driver_2d/forced.py:57-202`): surface
+    restoring to a constant or to a field read from a file (or none); source-minus-sink
+    constant / first-order decay / field read from a file (or none), the file source scaled
+    down where it is a sink and the tracer is below `sink_thres`.  File fields are given as
+    `(times, values)` already on the model axes (`forcing_on_model_axes`); they are interpolated
+    in time as `utils.gen_forcing_fcn` does (utils.py:529-531: scipy's linear interp1d with
+    extrapolation)."""
 
     tc = 1
 
     def __init__(self, model, surf_restore_opt="none", surf_restore_const=0.0, sms_opt="decay",
-                 sms_decay_rate=0.0, sms_const=0.0, surf_restore_rate_10m=24.0 / 86400.0):
+                 sms_decay_rate=0.0, sms_const=0.0, surf_restore_rate_10m=24.0 / 86400.0,
+                 surf_restore_series=None, sms_series=None, sink_thres=None):
         super().__init__(model)
-        if surf_restore_opt not in ("none", "const") or sms_opt not in ("none", "const", "decay"):
-            raise NotImplementedError("file-driven forced options are outside the oracle")
+        if surf_restore_opt not in ("none", "const", "file") or sms_opt not in ("none", "const", "decay", "file"):
+            raise ValueError("unknown forced option")
+        if surf_restore_opt == "none" and sms_opt != "decay":
+            raise ValueError("forced_sms_opt must be decay if forced_surf_restore_opt == none")   # forced.py:32-38
         self.surf_restore_opt = surf_restore_opt
         self.sms_opt = sms_opt
         self.surf_restore_rate = 10.0 / model.depth.delta[0] * surf_restore_rate_10m
         self.surf_restore_const = surf_restore_const
         self.sms_decay_rate = sms_decay_rate
         self.sms_const = sms_const
+        self.sink_thres = sink_thres if sms_opt == "file" else None
+        self.surf_restore_fcn = self.sms_fcn = None
+        if surf_restore_opt == "file":
+            self.surf_restore_fcn = interpolate.interp1d(
+                surf_restore_series[0], surf_restore_series[1], axis=0, fill_value="extrapolate", assume_sorted=True)
+        if sms_opt == "file":
+            self.sms_fcn = interpolate.interp1d(
+                sms_series[0], sms_series[1], axis=0, fill_value="extrapolate", assume_sorted=True)
+
+    @property
+    def state_dependent(self):
+        return self.sink_thres is not None
 
     def _add_sources(self, time, c, tend):
         if self.surf_restore_opt != "none":
-            tend[0, 0, :] += self.surf_restore_rate * (self.surf_restore_const - c[0, 0, :])
+            target = self.surf_restore_const if self.surf_restore_opt == "const" else self.surf_restore_fcn(time)
+            tend[0, 0, :] += self.surf_restore_rate * (target - c[0, 0, :])
         if self.sms_opt == "const":
             tend[0, :] += self.sms_const
         if self.sms_opt == "decay":
             tend[0, :] += -self.sms_decay_rate * c[0, :]
+        if self.sms_opt == "file":
+            sms = np.array(self.sms_fcn(time))
+            if self.sink_thres is not None:
+                tmp = (1.0 / self.sink_thres) * c[0, :]
+                sms *= np.where((sms < 0.0) & (tmp > 0.0) & (tmp < 1.0), tmp, 1.0)   # forced.py:141-152
+            tend[0, :] += sms
         return tend
 
-    def diag_extra(self, tr):
+    def diag_extra(self, tr, time=None, y=None):
         ex = np.zeros((self.model.nz, self.model.ny))
         if self.surf_restore_opt != "none":
             ex[0, :] += -self.surf_restore_rate
         if self.sms_opt == "decay":
             ex += -self.sms_decay_rate
+        if self.sink_thres is not None:
+            # forced.py:188-202
+            sms = self.sms_fcn(time)
+            sink_thres_r = 1.0 / self.sink_thres
+            tmp = sink_thres_r * np.asarray(y).reshape(self.model.nz, self.model.ny)
+            ex += np.where((sms < 0.0) & (tmp > 0.0) & (tmp < 1.0), sink_thres_r * sms, 0.0)
         return ex
 
-    # same three-step product formula as iage (forced.py:192-241; the Jacobian of these
-    # option combinations does not depend on the tracer values read from the precond file)
-    precond_matrix = Iage.precond_matrix
-    apply_precond = Iage.apply_precond
+    def comp_jacobian(self, time, y=None):
+        m = self.model
+        up, south, center, north, dn = m.jac_diags(time)
+        return m.diags_to_csr(up, south, center + self.diag_extra(0, time, y), north, dn)
+
+    # same three-step product formula as iage (forced.py:204-241); with a sink threshold the Jacobian
+    # of time level k is evaluated at `states[k]`, the tracer at the end of that third of the year
+    def precond_matrix(self, time_range=(0.0, YEAR), states=None):
+        n = self.model.nz * self.model.ny
+        time_n = 3
+        time_delta = (time_range[1] - time_range[0]) / time_n
+        mat_id = sparse.identity(n)
+        mat = sparse.identity(n)
+        for time_ind in range(time_n):
+            time = time_range[0] + (time_ind + 0.5) * time_delta
+            state = states[time_ind] if states is not None else np.zeros(n)
+            mat_tmp = time_delta * self.comp_jacobian(time, state)
+            mat = mat * (mat_id - mat_tmp)
+        return mat_id - mat
+
+    def apply_precond(self, v, time_range=(0.0, YEAR), states=None):
+        return sp_linalg.spsolve(self.precond_matrix(time_range, states), v) - v
+
+
+def forcing_on_model_axes(data, dims_in, dims_out, scalef=1.0):
+    """the spatial part of `utils.gen_forcing_fcn` (utils.py:511-527): scale the field
+    [time, dims...] and interpolate it linearly (with extrapolation) along every non-time axis
+    whose coordinate differs from the model's"""
+    data = scalef * np.asarray(data, dtype=np.float64)
+    for axis in range(1, data.ndim):
+        dim_in, dim_out = np.asarray(dims_in[axis - 1]), np.asarray(dims_out[axis - 1])
+        if len(dim_in) != len(dim_out) or (dim_in != dim_out).any():
+            data = interpolate.interp1d(dim_in, data, axis=axis, fill_value="extrapolate", assume_sorted=True)(dim_out)
+    return data
 
 
 class Phosphorus(TracerModule):
@@ -455,7 +517,7 @@ class Phosphorus(TracerModule):
         return jac.tocsr()
 
 
-def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3):
+def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3, states=None):
     """The SAME operator as `Iage.apply_precond`, M^-1 = (I - A_0 A_1 A_2)^-1 - I with
     A_k = I - dt J(t_k), evaluated without forming the triple product: with
     u_1 = A_0^-1 u_0, u_2 = A_1^-1 u_1, u_3 = A_2^-1 u_2 and u_0 - u_3 = v one gets the
@@ -473,7 +535,8 @@ def apply_precond_stable(module, v, time_range=(0.0, YEAR), time_n=3):
     n = v.size
     dt = (time_range[1] - time_range[0]) / time_n
     eye = sparse.identity(n, format="csr")
-    A = [eye - dt * module.comp_jacobian(time_range[0] + (k + 0.5) * dt)
+    A = [eye - dt * (module.comp_jacobian(time_range[0] + (k + 0.5) * dt) if states is None else
+                     module.comp_jacobian(time_range[0] + (k + 0.5) * dt, states[k]))
          for k in range(time_n)]
     rows = []
     for k in range(time_n):

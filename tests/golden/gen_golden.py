@@ -225,6 +225,85 @@ def gen_forced(tag, nz, ny, params, seed, with_fcn=False):
     print("wrote forced", tag)
 
 
+def synthetic_forcing(nz, ny, seed):
+    """seeded forcing records on the model axes: 12 records from day 15 to day 345 (both ends of the
+    year are extrapolated), restoring targets around 1, sources of both signs around 1e-8"""
+    rng = np.random.default_rng(seed)
+    times = (15.0 + 30.0 * np.arange(12)) * 86400.0
+    phase = 2.0 * np.pi * times / (365.0 * 86400.0)
+    restore = 1.0 + 0.3 * np.sin(phase)[:, None] * np.linspace(0.5, 1.5, ny)[None, :] \
+        + 0.05 * rng.standard_normal((12, ny))
+    sms = 2.0e-8 * (np.cos(phase)[:, None, None] * np.exp(-np.arange(nz) / (0.3 * nz))[None, :, None]
+                    + 0.5 * rng.standard_normal((12, nz, ny)))
+    return times, restore, sms
+
+
+def gen_forced_file(tag, nz, ny, restore_opt, sms_opt, sink_thres, seed, with_fcn=False):
+    """reference forced module with file-driven options.  The reference builds its forcing functions
+    with utils.gen_forcing_fcn, which reads a NetCDF file (netCDF4, absent here) and ends in
+    `interpolate.interp1d(dim0_in, data, axis=0, fill_value="extrapolate", assume_sorted=True)`
+    (utils.py:529-531); the generator makes that same call on seeded records that are already on the
+    model axes and hands the functions to the genuine comp_tend / comp_jacobian."""
+    from scipy import integrate, interpolate
+    from scipy import sparse
+    from scipy.sparse import linalg as sp_linalg
+
+    from nk_ooc.py_driver_2d.forced import forced
+
+    params = {"surf_restore_opt": restore_opt, "sms_opt": sms_opt}
+    if restore_opt == "const":
+        params["surf_restore_const"] = 1.5
+    if sms_opt == "decay":
+        params["sms_decay_rate"] = 1.0e-8
+    if sms_opt == "file":
+        params["sms_scalef"] = 1.0
+        if sink_thres is not None:
+            params["sink_thres"] = sink_thres
+    depth, ypos, processes, tm = ref_forced(nz, ny, params)
+    times_rec, restore, sms = synthetic_forcing(nz, ny, seed)
+    if restore_opt == "file":
+        forced.surf_restore_fcn = interpolate.interp1d(times_rec, restore, axis=0, fill_value="extrapolate",
+                                                        assume_sorted=True)
+    if sms_opt == "file":
+        forced.sms_fcn = interpolate.interp1d(times_rec, sms, axis=0, fill_value="extrapolate", assume_sorted=True)
+    year = 365.0 * 86400.0
+    times = [0.0, 0.3 * year, 0.66 * year, year]
+    rng = np.random.default_rng(seed + 1)
+    y = 0.4 + 0.4 * rng.standard_normal(nz * ny)      # below and above the threshold, some negative
+    out = {"nz": nz, "ny": ny, "times": np.asarray(times), "y": y, "surf_restore_opt": restore_opt,
+           "sms_opt": sms_opt, "sink_thres": -1.0 if sink_thres is None else sink_thres,
+           "surf_restore_const": params.get("surf_restore_const", 0.0),
+           "sms_decay_rate": params.get("sms_decay_rate", 0.0),
+           "rec_times": times_rec, "restore_vals": restore, "sms_vals": sms}
+    out["tend"] = np.stack([tm.comp_tend(t, y, processes).copy() for t in times])
+    for i, t in enumerate(times):
+        jac = sparse.csr_matrix(tm.comp_jacobian(t, y, processes))
+        jac.sum_duplicates()
+        jac.sort_indices()
+        out[f"jac{i}_data"], out[f"jac{i}_indices"], out[f"jac{i}_indptr"] = jac.data, jac.indices, jac.indptr
+    # the preconditioner formula of forced.apply_precond_jacobian (forced.py:222-241) with the tracer
+    # of the three time levels given directly (the reference reads them from the precond file)
+    states = [0.4 + 0.4 * np.random.default_rng(seed + 10 + k).standard_normal(nz * ny) for k in range(3)]
+    v = np.random.default_rng(seed + 20).standard_normal(nz * ny)
+    time_delta = year / 3
+    mat_id = sparse.identity(v.size)
+    mat = sparse.identity(v.size)
+    for k in range(3):
+        mat_tmp = time_delta * tm.comp_jacobian((k + 0.5) * time_delta, states[k], processes)
+        mat *= mat_id - mat_tmp
+    mat = mat_id - mat
+    out.update(precond_states=np.stack(states), precond_v=v, precond_res=sp_linalg.spsolve(sparse.csc_matrix(mat), v) - v)
+    if with_fcn:
+        y0 = 0.6 + 0.2 * np.random.default_rng(seed + 100).standard_normal(nz * ny)
+        time_range = (0.0, year)
+        sol = integrate.solve_ivp(
+            tm.comp_tend, time_range, y0, "Radau", np.array(time_range), max_step=year * 0.01,
+            atol=1.0e-6, rtol=1.0e-6, args=(processes,), jac=tm.comp_jacobian)
+        out.update(y0=y0, fcn=sol.y[:, -1] - y0, nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu)
+    np.savez_compressed(os.path.join(HERE, f"forced_{tag}.npz"), **out)
+    print("wrote forced", tag)
+
+
 def gen_phosphorus(tag, nz, ny, seed, with_fcn=False):
     """reference phosphorus module: tendencies, Jacobian, one forward year"""
     from scipy import integrate
@@ -293,9 +372,18 @@ def gen_lstsq(seed):
     print("wrote lstsq")
 
 
+def gen_forced_file_all():
+    gen_forced_file("file_restore_sms_22x9", 22, 9, "file", "file", None, 11, with_fcn=True)
+    gen_forced_file("file_sink_thres_22x9", 22, 9, "const", "file", 0.5, 12, with_fcn=True)
+    gen_forced_file("file_restore_decay_70x5", 70, 5, "file", "decay", None, 13)
+
+
 def main():
     _install_placeholders()
     sys.path.insert(0, REF)
+    if sys.argv[1:] == ["forced_file"]:      # only the fixtures of the file-driven forced options
+        gen_forced_file_all()
+        return
     year = 365.0 * 86400.0
     times = [0.0, 0.3 * year, 0.5 * year, 0.7 * year, 0.2613 * year]
     gen_static("26x26", 26, 26, 0.1, 1000.0, times, 0)
@@ -311,6 +399,7 @@ def main():
                                      "sms_decay_rate": 1.0e-8}, 7, with_fcn=True)
     gen_forced("restore_const_22x9", 22, 9, {"surf_restore_opt": "const", "surf_restore_const": 1.5,
                                              "sms_opt": "const", "sms_const": -2.0e-9}, 8)
+    gen_forced_file_all()
     gen_comp_fcn("20x3_columns", 20, 3, 0.0, 0.0)
     gen_comp_fcn("26x26", 26, 26, 0.1, 1000.0)
     gen_comp_fcn("26x26_bumpy", 26, 26, 0.1, 1000.0, init="bumpy")

@@ -102,3 +102,85 @@ def test_two_module_krylov(tmp_path):
     data, _ = ncio.read_file(os.path.join(str(tmp_path), "increment_00.nc"))
     assert {"iage", "iage_slow_rest", "dye"} <= set(data)
     ModelState.reset_class()
+
+
+FILE_TAGS = ["file_restore_sms_22x9", "file_sink_thres_22x9", "file_restore_decay_70x5"]
+
+
+def _file_modelinfo(g, tmp_path):
+    """modelinfo of the file-driven options with the fixture's records written to NetCDF files"""
+    from nk_ooc_amd import ncio
+
+    nz, ny = int(g["nz"]), int(g["ny"])
+    depth, ypos = default_axes(nz, ny)
+    info = {"forced_surf_restore_opt": str(g["surf_restore_opt"]), "forced_sms_opt": str(g["sms_opt"])}
+    nrec = len(g["rec_times"])
+    if info["forced_surf_restore_opt"] == "const":
+        info["forced_surf_restore_const"] = repr(float(g["surf_restore_const"]))
+    if info["forced_surf_restore_opt"] == "file":
+        fname = str(tmp_path / "restore.nc")
+        ncio.write_vars_file(fname, {"time": nrec, "ypos": ny},
+                             {"time": (("time",), "f8", {}, g["rec_times"]), "ypos": (("ypos",), "f8", {}, ypos.mid),
+                              "target": (("time", "ypos"), "f8", {}, g["restore_vals"])}, "fixture")
+        info.update(forced_surf_restore_fname=fname, forced_surf_restore_varname="target")
+    if info["forced_sms_opt"] == "decay":
+        info["forced_sms_decay_rate"] = repr(float(g["sms_decay_rate"]))
+    if info["forced_sms_opt"] == "file":
+        fname = str(tmp_path / "sms.nc")
+        # stored at half the amplitude and read back with forced_sms_scalef = 2 (a power of two: exact)
+        ncio.write_vars_file(fname, {"time": nrec, "depth": nz, "ypos": ny},
+                             {"time": (("time",), "f8", {}, g["rec_times"]), "depth": (("depth",), "f8", {}, depth.mid),
+                              "ypos": (("ypos",), "f8", {}, ypos.mid),
+                              "sms": (("time", "depth", "ypos"), "f8", {}, 0.5 * g["sms_vals"])}, "fixture")
+        info.update(forced_sms_fname=fname, forced_sms_varname="sms", forced_sms_scalef="2.0")
+        if float(g["sink_thres"]) > 0.0:
+            info["forced_sink_thres"] = repr(float(g["sink_thres"]))
+    return info
+
+
+@pytest.mark.parametrize("tag", FILE_TAGS)
+def test_forced_file_kernels(golden_dir, tmp_path, tag):
+    """file-driven restoring / source fields and the sink threshold (forced.py:125-153,188-241): tendencies
+    against the reference's, Jacobian and preconditioner against the oracle, one forward year"""
+    from scipy import sparse
+
+    from nk_ooc_amd.engine import forced_engine
+    from nk_ooc_amd.grid import Grid2d
+    from test_oracle_forced_file import oracle_forced
+
+    g = np.load(f"{golden_dir}/forced_{tag}.npz")
+    nz, ny = int(g["nz"]), int(g["ny"])
+    eng = forced_engine(Grid2d.default(nz, ny), _file_modelinfo(g, tmp_path))
+    assert eng.module_kind == 2
+    tm = oracle_forced(g)
+    yd = eng.upload(g["y"])
+    eng.set_lin_state(yd)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(nz * ny)
+    for i, t in enumerate(g["times"]):
+        assert rel_err(eng.download(eng.tend(t, yd)).reshape(-1), g["tend"][i]) < 1e-13
+        want = sparse.csr_matrix((g[f"jac{i}_data"], g[f"jac{i}_indices"], g[f"jac{i}_indptr"]), shape=(nz * ny, nz * ny))
+        assert rel_err(eng.download(eng.jacobian_apply(t, eng.upload(v))).reshape(-1), want @ v) < 1e-12
+        diags = eng.jacobian_diags(t)
+        up, south, center, north, dn = tm.model.jac_diags(t)
+        assert np.max(np.abs(diags[2, 0] - (center + tm.diag_extra(0, t, g["y"])))) < 1e-13 * np.max(np.abs(center))
+    states = [eng.upload(s) for s in g["precond_states"]]
+    if eng.state_dependent_precond:
+        with pytest.raises(Exception, match="nk2d_precond_setup_states"):
+            eng.precond_setup()
+        eng.precond_setup_states(states)
+    else:
+        eng.precond_setup()
+    got = eng.download(eng.precond_apply(eng.upload(g["precond_v"]))).reshape(-1)
+    assert rel_err(got, apply_precond_stable(tm, g["precond_v"], states=list(g["precond_states"]))) < 1e-9
+    if "fcn" in g:
+        want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
+        fx, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=np.array(solver.schedule))
+        assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
+        fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]))
+        # free-running controller: differences of the order of the integrator's tolerance (1e-6 per step);
+        # the kink of the sink threshold makes the map less smooth than the linear modules'
+        atol = 5e-5 if eng.state_dependent_precond else 1e-6
+        err = np.abs(eng.download(fx).reshape(-1) - g["fcn"])
+        assert np.all(err <= atol + 1e-3 * np.abs(g["fcn"])), err.max()
+        assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
