@@ -26,7 +26,9 @@
  *                                   comp_jacobian(time, tracer_vals) @ v for state dependent modules,
  *                                   py_driver_2d/phosphorus.py:105-172
  *   nk2d_precond_setup/apply        iage.apply_precond_jacobian, py_driver_2d/iage.py:66-93 (also
- *                                   forced.apply_precond_jacobian, forced.py:192-241)
+ *                                   forced.apply_precond_jacobian, forced.py:204-241)
+ *   nk2d_precond_setup_states       the same with the tracer of the three time levels it reads from the
+ *                                   precond file, forced.py:222-236 (file source with a sink threshold)
  *   nk2d_shift_factor/solve         sp_linalg.spsolve(mat - shift * mat_id, .) and the solves inside
  *                                   sp_linalg.eigs of phosphorus.apply_precond_jacobian,
  *                                   py_driver_2d/phosphorus.py:233-255

@@ -464,6 +464,10 @@ class ModelState:
                     uptake = tms.eng.po4_uptake(hist[:, 0])
                     hist = np.concatenate((hist, uptake[:, np.newaxis]), axis=1)
                     type(self)._hist_end.setdefault(os.path.abspath(hist_fname), {})[tms.name] = hist[-1, 0].copy()
+                elif tms.eng.state_dependent_precond:
+                    # forced module with a sink threshold: the tracer at the end of each third of the year
+                    type(self)._hist_end.setdefault(os.path.abspath(hist_fname), {})[tms.name] = \
+                        hist[self._third_end_indices(t_eval), 0].copy()
                 hists.append((tracers, hist))
             mods.append(tms._like(fx))
             stats.append(st)
@@ -559,10 +563,33 @@ class ModelState:
         for tms in self.tracer_modules:
             if tms.eng.module_kind == 1:
                 self._ensure_state_precond(tms, precond_fname)
+            elif tms.eng.state_dependent_precond:
+                self._ensure_forced_precond(tms, precond_fname)
         res_ms = self._new([tms._like(tms.eng.precond_apply(tms.vec)) for tms in self.tracer_modules])
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
         return res_ms.dump(res_fname, f"{_class_name(self)}.apply_precond_jacobian")
+
+    def _third_end_indices(self, time_vals):
+        """samples of the precond file closest to the end of each third of the year (forced.py:222-233)"""
+        t0, t1 = self.time_range
+        return [int(np.argmin(abs(t0 + (k + 1.0) * (t1 - t0) / 3 - np.asarray(time_vals)))) for k in range(3)]
+
+    def _ensure_forced_precond(self, tms, precond_fname):
+        """preconditioner of a forced module whose Jacobian depends on the tracer (file source with a
+        sink threshold): factorised once per precond file from the tracer at three times"""
+        key = os.path.abspath(precond_fname)
+        if getattr(tms.eng, "_state_precond_key", None) == key:
+            return
+        fields = self._precond_state.get(key, {}).get(tms.name)
+        if fields is None:
+            # resumed run: read the samples back from the precond file
+            name = tms.tracer_names[0]
+            data, _ = ncio.read_file(precond_fname, ["time", name])
+            fields = data[name][self._third_end_indices(data["time"])]
+        states = [tms.eng.upload(np.asarray(f, dtype=np.float64)[np.newaxis]) for f in fields]
+        tms.eng.precond_setup_states(states)
+        tms.eng._state_precond_key = key
 
     def _ensure_state_precond(self, tms, precond_fname):
         """factorise the state dependent (phosphorus) preconditioner of `precond_fname` once; the

@@ -97,7 +97,9 @@ class OracleModule:
             return apply_precond_phosphorus(self.tm, self.reg, self.precond_po4, v)[0]
         from .model import apply_precond_stable
 
-        return apply_precond_stable(self.tm, v)
+        # self.precond_states: tracer at the end of each third of the year, for modules whose Jacobian
+        # depends on the state (forced module with a sink threshold; set by the caller)
+        return apply_precond_stable(self.tm, v, states=getattr(self, "precond_states", None))
 
 
 # ---- model-state level helpers (lists over modules, scalars [ntm, nreg]) -----------

@@ -30,6 +30,7 @@ class FakeEngine:
         self.shape = (tc, nz, ny)
         self.nreg = 1
         self.module_kind = 0
+        self.state_dependent_precond = False
         rng = np.random.default_rng(seed)
         n = tc * nz * ny
         self.A = 0.3 * rng.standard_normal((n, n)) / np.sqrt(n)
