@@ -90,3 +90,28 @@ def test_forcing_reader_matches_interp1d(tmp_path):
                        rtol=1e-13, atol=1e-15)
     with pytest.raises(ValueError):
         load_forcing(fname, "sms", [depth_out])
+
+
+REF_INPUT = "/root/reference/input/py_driver_2d"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(f"{REF_INPUT}/po4_sms.nc"), reason="reference input files absent")
+def test_forcing_reader_on_reference_files():
+    """the forcing files the reference ships (input/py_driver_2d/po4_surf.nc, po4_sms.nc: 61 records on
+    its 40 x 50 default grid): untouched on that grid, interp1d-equal on another"""
+    from nk_ooc_amd.forcing import load_forcing
+    from oracle.grid import default_axes
+    from oracle.model import forcing_on_model_axes
+    from nk_ooc_amd import ncio
+
+    depth, ypos = default_axes(40, 50)
+    times, surf = load_forcing(f"{REF_INPUT}/po4_surf.nc", "po4", [ypos.mid])
+    raw, _ = ncio.read_file(f"{REF_INPUT}/po4_surf.nc")
+    assert surf.shape == (61, 50) and np.allclose(surf, raw["po4"], rtol=1e-13)
+    assert np.array_equal(times, raw["time"]) and np.all(np.diff(times) > 0.0)
+    depth2, ypos2 = default_axes(26, 30)
+    raw, _ = ncio.read_file(f"{REF_INPUT}/po4_sms.nc")
+    times, sms = load_forcing(f"{REF_INPUT}/po4_sms.nc", "po4_sms", [depth2.mid, ypos2.mid], scalef=0.5)
+    want = forcing_on_model_axes(raw["po4_sms"], [raw["depth"], raw["ypos"]], [depth2.mid, ypos2.mid], scalef=0.5)
+    assert sms.shape == (61, 26, 30)
+    assert np.allclose(sms, want, rtol=1e-12, atol=1e-18 + 1e-13 * np.abs(want).max())
