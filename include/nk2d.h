@@ -163,7 +163,8 @@ int nk2d_shifted_solve(nk2d_ctx* ctx, double t_jac, double h, double mu_re, doub
                        int32_t* sweeps_out);
 
 /* one forward year: fx = y(t1) - x, region-masked.
-   replay: optional schedule [replay_n][NK2D_SCHED_WIDTH] to consume (step-replay mode);
+   replay: optional schedule [replay_n][NK2D_SCHED_WIDTH] to consume (step-replay mode; the inner
+           tolerance is then min(lin_tol, 1e-3): the schedule fixes the Newton iteration counts);
    record: optional buffer [record_cap][NK2D_SCHED_WIDTH] receiving the accepted steps. */
 int nk2d_comp_fcn(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats,
                   const double* replay, int64_t replay_n,

