@@ -26,7 +26,7 @@ else:
     make = phosphorus_engine
 ref = None
 for lin_tol in (1e-8, 1e-3, 1e-2, 3e-2, 1e-1, 3e-1):
-    for fresh in ((0, 1) if module == "iage" else (0,)):
+    for fresh in (0, 1):
         eng = make(grid, lin_tol=lin_tol)
         eng.set_option("jac_fresh", fresh)
         x = eng.upload(y0)
