@@ -90,7 +90,6 @@ struct nk2d_ctx {
     const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
     int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
     int jac_fresh;          // 1: re-evaluate the Jacobian at every step start (see nk2d_set_option)
-    double jac_shift;       // with jac_fresh: J is evaluated at t + jac_shift * h instead of t
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials

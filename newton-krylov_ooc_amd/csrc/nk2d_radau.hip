@@ -397,8 +397,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         if (c->jac_fresh && !s.current_jac) {
             // evaluating J costs two small launches here (SciPy pays a Python double loop and two
             // SuperLU factorisations, hence its reuse heuristics): never start a step on a stale J
-            if (c->jac_shift > 0.0) NK2D_TRY(refresh_jac(s, std::min(t + c->jac_shift * h_abs, s.t1), false));
-            else NK2D_TRY(refresh_jac(s, t, true));
+            NK2D_TRY(refresh_jac(s, t, true));
             c->st.njev++;
             s.current_jac = true;
             s.have_lu = false;
