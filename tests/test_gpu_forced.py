@@ -235,3 +235,37 @@ def test_forced_file_krylov(golden_dir, tmp_path):
         assert rel_err(h_mat, trace["h_mat"][-1]) < 1.5e-1
     finally:
         ModelState.reset_class()
+
+
+@pytest.mark.parametrize("nz", [130, 416, 500])
+def test_forced_file_tall_columns(nz):
+    """the kind-2 instantiations for more levels per lane (E = 3, 7, 8): tendencies, Jacobian-vector products
+    and a few replayed Radau steps against the oracle, synthetic records (one ends inside the year)"""
+    from nk_ooc_amd.engine import ModuleEngine
+    from nk_ooc_amd.grid import Grid2d
+
+    ny = 5
+    rng = np.random.default_rng(nz)
+    depth, ypos = default_axes(nz, ny)
+    times = np.array([-10.0, 40.0, 95.0, 200.0, 300.0]) * 86400.0
+    restore = 1.0 + 0.2 * rng.standard_normal((5, ny))
+    sms = 3.0e-8 * rng.standard_normal((5, nz, ny))
+    tm = Forced(Py2dModel(depth, ypos), "file", 0.0, "file", 0.0, 0.0,
+                surf_restore_series=(times, restore), sms_series=(times, sms), sink_thres=0.4)
+    eng = ModuleEngine(Grid2d.default(nz, ny), tc=1, surf_rate=(tm.surf_restore_rate,), module_kind=2,
+                       restore_series=(times, restore), sms_series=(times, sms), sink_thres=0.4)
+    y = 0.3 + 0.3 * rng.standard_normal(nz * ny)
+    v = rng.standard_normal(nz * ny)
+    yd = eng.upload(y)
+    eng.set_lin_state(yd)
+    for t in (0.0, 0.27 * YEAR, 0.9 * YEAR, YEAR):
+        assert rel_err(eng.download(eng.tend(t, yd)).reshape(-1), tm.comp_tend(t, y)) < 1e-13
+        assert rel_err(eng.download(eng.jacobian_apply(t, eng.upload(v))).reshape(-1), tm.comp_jacobian(t, y) @ v) < 1e-12
+    # the first Radau steps of a year (oracle: SciPy's controller on the restated module), replayed on the device
+    short = (0.0, 2.0 * 86400.0)
+    y0 = 0.6 + 0.2 * rng.standard_normal(nz * ny)
+    want, solver = radau.comp_fcn(tm, y0, time_range=short, return_solver=True)
+    eng2 = ModuleEngine(Grid2d.default(nz, ny), tc=1, surf_rate=(tm.surf_restore_rate,), module_kind=2,
+                        restore_series=(times, restore), sms_series=(times, sms), sink_thres=0.4, time_range=short)
+    fx, _, _ = eng2.comp_fcn(eng2.upload(y0), replay=np.array(solver.schedule))
+    assert rel_err(eng2.download(fx).reshape(-1), want) < 1e-10
