@@ -187,8 +187,8 @@ def test_forced_file_kernels(golden_dir, tmp_path, tag):
 
 
 def test_forced_file_krylov(golden_dir, tmp_path):
-    """tracer_module_names = forced_{suff}:dye with file restoring-free options: constant restoring, file
-    source with a sink threshold -- through ModelState / KrylovSolver: the forcing files are read by the
+    """tracer_module_names = forced_{suff}:dye with constant restoring and a file source with a sink
+    threshold, through ModelState / KrylovSolver: the forcing files are read by the
     host, the preconditioner is linearised about the history samples at the end of each third of the year
     (forced.py:222-236); Hessenberg / beta against the oracle with the same linearisation states"""
     from nk_ooc_amd import ncio
