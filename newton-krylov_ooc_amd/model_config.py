@@ -105,6 +105,9 @@ class ModelConfig:
     """tracer-module definitions + grid variables for one run"""
 
     def __init__(self, modelinfo):
+        # own copy: the tracer module names are expanded below, and the caller's dictionary may configure
+        # another ModelConfig later (set-up, then the driver)
+        modelinfo = dict(modelinfo)
         self.modelinfo = modelinfo
         with open(modelinfo["tracer_module_defs_fname"], mode="r") as fptr:
             contents = yaml.safe_load(fptr)

@@ -269,3 +269,79 @@ def test_forced_file_tall_columns(nz):
                         restore_series=(times, restore), sms_series=(times, sms), sink_thres=0.4, time_range=short)
     fx, _, _ = eng2.comp_fcn(eng2.upload(y0), replay=np.array(solver.schedule))
     assert rel_err(eng2.download(fx).reshape(-1), want) < 1e-10
+
+
+def _reference_like_forcing_files(tmp_path):
+    """forcing files shaped like the ones the reference ships (input/py_driver_2d/po4_surf.nc, po4_sms.nc):
+    61 records over the year on the 40 x 50 default grid -- not the grid of the run, so the reader interpolates"""
+    from nk_ooc_amd import ncio
+
+    depth, ypos = default_axes(40, 50)
+    time = np.linspace(0.0, YEAR, 61)
+    season = np.cos(2.0 * np.pi * time / YEAR)
+    light = np.exp(-((ypos.mid - 2.5e6) / 1.5e6) ** 2)
+    surf = 0.3 + 1.2 * (1.0 - light)[None, :] * (1.0 + 0.2 * season[:, None])
+    uptake = -2.0e-8 * np.exp(-depth.mid / 60.0)[None, :, None] * light[None, None, :] * (1.0 - 0.5 * season)[:, None, None]
+    remin = 1.5e-9 * np.exp(-depth.mid / 700.0)[None, :, None] * (0.5 + light)[None, None, :] * np.ones(61)[:, None, None]
+    fnames = {"surf": str(tmp_path / "po4_surf.nc"), "sms": str(tmp_path / "po4_sms.nc")}
+    axes = {"time": (("time",), "f8", {}, time), "depth": (("depth",), "f8", {}, depth.mid),
+            "ypos": (("ypos",), "f8", {}, ypos.mid)}
+    ncio.write_vars_file(fnames["surf"], {"time": 61, "ypos": 50},
+                         {"time": axes["time"], "ypos": axes["ypos"], "po4": (("time", "ypos"), "f8", {}, surf)}, "test")
+    ncio.write_vars_file(fnames["sms"], {"time": 61, "depth": 40, "ypos": 50},
+                         dict(axes, po4_sms=(("time", "depth", "ypos"), "f8", {}, uptake + remin)), "test")
+    return fnames
+
+
+@pytest.mark.parametrize("case", ["o2_like", "po4_pf"])
+def test_newton_forced_run_script_cases(tmp_path, case):
+    """the two file-driven configurations the reference has run scripts for
+    (scripts/run_py_driver_2d_forced_o2_like.sh: constant restoring, file source scaled by -1/3 with a sink
+    threshold; run_py_driver_2d_forced_preformed_po4.sh: file restoring, no source), spun up by the Newton
+    driver on a 26 x 30 grid from forcing files on another grid; the converged iterate is checked with the
+    oracle's forward year"""
+    from nk_ooc_amd import ncio, nk_driver
+    from nk_ooc_amd.forcing import load_forcing
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import make_config, setup
+
+    nz, ny = 26, 30
+    files = _reference_like_forcing_files(tmp_path)
+    if case == "o2_like":
+        info = {"forced_surf_restore_opt": "const", "forced_surf_restore_const": "1.0",
+                "forced_surf_restore_rate_10m": "1.0 / 3600.0", "forced_sms_opt": "file",
+                "forced_sms_fname": files["sms"], "forced_sms_varname": "po4_sms",
+                "forced_sms_scalef": "-1.0 / 3.0", "forced_sink_thres": "0.05"}
+    else:
+        info = {"forced_surf_restore_opt": "file", "forced_surf_restore_fname": files["surf"],
+                "forced_surf_restore_varname": "po4", "forced_surf_restore_rate_10m": "1.0 / 3600.0",
+                "forced_sms_opt": "none"}
+    workdir = str(tmp_path / "work")
+    cfg = make_config(workdir, nz, ny, tracer_module_names=f"forced_{{suff}}:{case}", extra_modelinfo=info,
+                      extra_solverinfo={"newton_max_iter": "10"})
+    ModelState.write_files = True
+    try:
+        setup(cfg, fp_cnt=1)
+        solver = nk_driver.run(cfg)
+        assert solver.converged().all() and 1 <= solver.get_iteration() <= 10
+        eng = solver.iterate.tracer_modules[0].eng
+        assert eng.module_kind == 2 and eng.state_dependent_precond == (case == "o2_like")
+        x = solver.iterate.tracer_modules[0].get_tracer_vals_all().reshape(-1)
+    finally:
+        ModelState.reset_class()
+    # oracle forward year from the converged iterate: a fixed point of the annual map to the solver's tolerance
+    depth, ypos = default_axes(nz, ny)
+    kw = {}
+    if case == "o2_like":
+        kw = dict(surf_restore_opt="const", surf_restore_const=1.0, sms_opt="file", sink_thres=0.05,
+                  sms_series=load_forcing(files["sms"], "po4_sms", [depth.mid, ypos.mid], scalef=-1.0 / 3.0))
+    else:
+        kw = dict(surf_restore_opt="file", sms_opt="none",
+                  surf_restore_series=load_forcing(files["surf"], "po4", [ypos.mid]))
+    tm = Forced(Py2dModel(depth, ypos), surf_restore_rate_10m=1.0 / 3600.0, **kw)
+    fx = radau.comp_fcn(tm, x)
+    rel_tol = float(cfg["solverinfo"]["newton_rel_tol"])
+    weight = np.outer(depth.delta, ypos.delta).reshape(-1)
+    norm = lambda a: np.sqrt(np.sum(weight * a * a) / np.sum(weight))   # noqa: E731
+    assert norm(fx) <= 3.0 * rel_tol * norm(x), (norm(fx), norm(x))
+    assert np.all(np.isfinite(x)) and x.min() > -1e-6      # bounds: lob 0.0 (tracer_module_defs.yaml)

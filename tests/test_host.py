@@ -118,7 +118,9 @@ def test_cfg_yaml_and_grid_vars(tmp_path):
     cfg2 = make_config(str(tmp_path), 8, 8, tracer_module_names="iage,forced_{suff}:a:b")
     gen_grid_vars_file(cfg2["modelinfo"])
     mc2 = ModelConfig(cfg2["modelinfo"])
-    assert cfg2["modelinfo"]["tracer_module_names"] == "iage,forced_a,forced_b"
+    assert mc2.modelinfo["tracer_module_names"] == "iage,forced_a,forced_b"
+    # the caller's dictionary keeps the unexpanded names: it configures the driver after the set-up
+    assert cfg2["modelinfo"]["tracer_module_names"] == "iage,forced_{suff}:a:b"
     assert list(mc2.tracer_module_defs["forced_b"]["tracers"]) == ["b"]
     assert mc2.region_cnt == 1
 
