@@ -345,3 +345,32 @@ def test_newton_forced_run_script_cases(tmp_path, case):
     norm = lambda a: np.sqrt(np.sum(weight * a * a) / np.sum(weight))   # noqa: E731
     assert norm(fx) <= 3.0 * rel_tol * norm(x), (norm(fx), norm(x))
     assert np.all(np.isfinite(x)) and x.min() > -1e-6      # bounds: lob 0.0 (tracer_module_defs.yaml)
+
+
+def test_forced_iage_configuration_is_the_iage_tracer():
+    """scripts/run_py_driver_2d_forced_iage.sh: restoring to 0 at 1/3600 s^-1 per 10 m and a constant source
+    of 1 yr/yr make forced_{suff}:iage the first tracer of the iage module -- same tendencies bit for bit,
+    same forward year under the same schedule"""
+    from nk_ooc_amd.engine import forced_engine, iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    nz, ny = 26, 26
+    grid = Grid2d.default(nz, ny)
+    frc = forced_engine(grid, {"forced_surf_restore_opt": "const", "forced_surf_restore_const": "0.0",
+                               "forced_surf_restore_rate_10m": "1.0 / 3600.0", "forced_sms_opt": "const",
+                               "forced_sms_const": "1.0 / (365.0 * 86400.0)"})
+    age = iage_engine(grid)
+    assert frc.module_kind == 0
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal((1, nz, ny))
+    for t in (0.0, 0.4 * YEAR):
+        got = frc.download(frc.tend(t, frc.upload(y)))[0]
+        want = age.download(age.tend(t, age.upload(np.concatenate([y, y]))))[0]
+        assert np.array_equal(got, want)
+    col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    y0 = np.broadcast_to(col[:, None], (1, nz, ny)).copy()
+    fa, _, sched = age.comp_fcn(age.upload(np.concatenate([y0, y0])), record=True)
+    ff, _, _ = frc.comp_fcn(frc.upload(y0), replay=sched)
+    ref = age.download(age.comp_fcn(age.upload(np.concatenate([y0, y0])), replay=sched)[0])[0]
+    assert rel_err(frc.download(ff)[0], ref) < 1e-11
+    assert rel_err(frc.download(ff)[0], age.download(fa)[0]) < 1e-8
