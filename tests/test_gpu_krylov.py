@@ -108,7 +108,6 @@ def test_krylov_column_regions_vs_reference_baselines(tmp_path):
     """the ci_py_driver_2d_iage_column_regions case end to end on the GPU, compared with the
     reference's committed files at the tolerances of its CI script"""
     import json
-    import shutil
 
     from nk_ooc_amd.krylov_solver import KrylovSolver
 

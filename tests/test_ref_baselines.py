@@ -3,7 +3,6 @@
 import os
 
 import numpy as np
-import pytest
 
 from helpers import oracle_iage
 from nk_ooc_amd import ncio

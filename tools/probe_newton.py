@@ -5,7 +5,6 @@ import sys
 import tempfile
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nk_ooc_amd import nk_driver  # noqa: E402
