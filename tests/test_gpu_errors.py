@@ -115,3 +115,50 @@ def test_non_finite_state_terminates_with_an_error():
     vals[0, 3, 4] = np.nan
     with pytest.raises(Nk2dError, match="step size"):
         eng.comp_fcn(eng.upload(vals))
+
+
+def test_forcing_record_descriptors_are_checked(tmp_path):
+    """module kind 2 (forced module with forcing files): malformed record sets are refused at creation,
+    the state dependent Jacobian / preconditioner entry points insist on their linearisation states, and the
+    host reader refuses what utils.gen_forcing_fcn would"""
+    from nk_ooc_amd.engine import ModuleEngine, Nk2dError, forced_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    nz, ny = 22, 9
+    grid = Grid2d.default(nz, ny)
+    times = np.array([0.0, 0.5, 1.0]) * YEAR
+    sms = np.zeros((3, nz, ny)) - 1.0e-8
+    with pytest.raises(Nk2dError, match="without forcing records"):
+        ModuleEngine(grid, tc=1, module_kind=2)
+    with pytest.raises(Nk2dError, match="at least 2 records"):
+        ModuleEngine(grid, tc=1, module_kind=2, sms_series=(times[:1], sms[:1]))
+    with pytest.raises(Nk2dError, match="not increasing"):
+        ModuleEngine(grid, tc=1, module_kind=2, sms_series=(times[::-1].copy(), sms))
+    with pytest.raises(Nk2dError, match="1 tracer"):
+        ModuleEngine(grid, tc=2, module_kind=2, sms_series=(times, sms))
+    with pytest.raises(Nk2dError, match="sink_thres"):
+        ModuleEngine(grid, tc=1, module_kind=2, sms_series=(times, sms), sink_thres=-1.0)
+    eng = ModuleEngine(grid, tc=1, surf_rate=(1.0e-6,), surf_target=(1.0,), module_kind=2, sms_series=(times, sms),
+                       sink_thres=0.5)
+    v = _state(eng)
+    with pytest.raises(Nk2dError, match="linearisation state"):
+        eng.jacobian_apply(0.0, v)
+    with pytest.raises(Nk2dError, match="nk2d_precond_setup_states"):
+        eng.precond_setup()
+    assert eng._lib.nk2d_precond_setup_states(eng._ctx, None) < 0
+    eng.set_lin_state(v)
+    assert np.all(np.isfinite(eng.download(eng.jacobian_apply(0.0, v))))
+    # an engine without forcing files has no use for the three states
+    plain = ModuleEngine(grid, tc=1, decay_rate=(1.0e-8,))
+    with pytest.raises(Nk2dError, match="forcing files only"):
+        plain.precond_setup_states([_state(plain)] * 3)
+    # host side: option names and combinations as forced.py:64-68,92-94,32-38 checks them
+    with pytest.raises(ValueError, match="forced_surf_restore_opt"):
+        forced_engine(grid, {"forced_surf_restore_opt": "files", "forced_sms_opt": "none"})
+    with pytest.raises(ValueError, match="forced_sms_opt"):
+        forced_engine(grid, {"forced_surf_restore_opt": "const", "forced_surf_restore_const": "1.0", "forced_sms_opt": "x"})
+    with pytest.raises(ValueError, match="must be decay"):
+        forced_engine(grid, {"forced_surf_restore_opt": "none", "forced_sms_opt": "none"})
+    with pytest.raises((OSError, KeyError, FileNotFoundError)):
+        forced_engine(grid, {"forced_surf_restore_opt": "file", "forced_surf_restore_fname": str(tmp_path / "missing.nc"),
+                             "forced_surf_restore_varname": "po4", "forced_sms_opt": "none"})
