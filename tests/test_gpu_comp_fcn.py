@@ -110,3 +110,27 @@ def test_factor_storage_precision_does_not_move_the_result(golden_dir):
         got[flag] = eng.download(fx).reshape(-1)
         assert rel_err(got[flag], want) < 1e-10
     assert rel_err(got[1.0], got[0.0]) < 1e-11
+
+
+@pytest.mark.parametrize("vv,kh", [(3.0, 3.0e6), (0.0, 1.0e7)])
+def test_comp_fcn_strong_lateral_coupling(vv, kh):
+    """lateral advection / mixing far above the defaults (per grid spacing: several times the coupling of the
+    416 x 416 case, on 20 columns): the line relaxation then needs
+    many sweeps per solve (contraction bound close to 1) -- replayed year to 1e-10, free-running year at the
+    reference CI tolerance, counters within 10 % of the oracle's (SciPy's) own"""
+    from oracle import radau
+
+    nz, ny = 24, 20
+    _, tm = oracle_iage(nz, ny, vv, kh)
+    col = np.interp(tm.model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    y0 = (np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2)
+          * (1.0 + 0.1 * np.random.default_rng(4).standard_normal((2, nz, ny)))).reshape(-1)
+    want, solver = radau.comp_fcn(tm, y0, return_solver=True)
+    eng = make_engine(nz, ny, vv, kh)
+    fx, stats, _ = eng.comp_fcn(eng.upload(y0), replay=np.array(solver.schedule, dtype=np.float64))
+    assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
+    assert stats["nsweeps"] > 3 * stats["nnewton"]          # beyond the two-sweep minimum
+    fx, stats, _ = eng.comp_fcn(eng.upload(y0))
+    assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
+    for key, ref in (("nfev", solver.stats.nfev), ("njev", solver.stats.njev), ("nlu", solver.stats.nlu)):
+        assert abs(stats[key] - ref) <= 0.1 * ref + 5, (key, stats[key], ref)
