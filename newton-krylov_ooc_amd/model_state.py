@@ -25,6 +25,7 @@ import numpy as np
 from . import hist as hist_mod
 from . import ncio
 from .engine import PHOSPHORUS_PARAM_NAMES, forced_engine, iage_engine, phosphorus_engine
+from .limiter import scalef_for_bound
 from .grid import Grid2d, SpatialAxis
 
 YEAR = 365.0 * 86400.0
@@ -666,19 +667,8 @@ class ModelState:
                         lob = src["bounds"].get("lob", lob)
                         upb = src["bounds"].get("upb", upb)
                 mask = self.model_config_obj.grid_vars[metadata["region_mask_varname"]]["region_mask"]
-                for bound, sign in ((lob, -1.0), (upb, 1.0)):
-                    if bound is None:
-                        continue
-                    viol = sign * (ref[tr] + inc[tr] - bound) > 0.0
-                    if not viol.any():
-                        continue
-                    if (sign * (ref[tr] - bound) > 0.0).any():
-                        raise ValueError("base < lob" if sign < 0 else "base > upb")
-                    ratio = np.ones(ref[tr].shape)
-                    np.divide(bound - ref[tr], inc[tr], out=ratio, where=viol)
-                    for reg in range(nreg):
-                        cand = np.amin(ratio, initial=np.inf, where=mask == reg + 1)
-                        scalef[ind, reg] = min(scalef[ind, reg], cand)
+                for bound, upper in ((lob, False), (upb, True)):
+                    np.minimum(scalef[ind], scalef_for_bound(nreg, mask, ref[tr], inc[tr], bound, upper), out=scalef[ind])
             if (scalef[ind] < 1.0).any():
                 tms.log_vals("applying scalef", scalef[ind])
                 tms *= scalef[ind]

@@ -208,3 +208,38 @@ def test_eval_expr(expr, expected):
     from nk_ooc_amd.engine import _eval_number
 
     assert _eval_number(expr) == expected
+
+
+def test_limiter_known_answers():
+    """the Newton increment limiter against the cases the reference pins for utils.min_by_region /
+    comp_scalef_lob / comp_scalef_upb (tests/test_utils.py:78-221)"""
+    from nk_ooc_amd.limiter import region_min, scalef_for_bound
+
+    vals = np.arange(24.0).reshape(4, 6)
+    rows, cols = np.indices(vals.shape)
+    for mask, expected in ((np.ones(vals.shape, dtype=np.int32), [0.0]),
+                           (1 + rows, vals[:, 0]), (1 + rows // 2, vals[::2, 0]),
+                           (1 + cols, vals[0, :]), (1 + cols // 2, vals[0, ::2])):
+        mask = mask.astype(np.int32)
+        assert np.array_equal(region_min(int(mask.max()), mask, vals), np.asarray(expected))
+    assert region_min(2, np.ones((2, 2), dtype=np.int32), np.ones((2, 2)))[1] == np.inf   # empty region
+
+    # seven regions (columns), three cells each; lower bound 0
+    nreg = 7
+    mask = np.tile(np.arange(1, nreg + 1, dtype=np.int32), (3, 1))
+    base = np.ones((3, nreg))
+    inc = np.ones((3, nreg))
+    inc[0, 1] = -0.5                                   # stays above the bound
+    inc[0:2, 2] = [-0.5, -1.0]                         # reaches the bound exactly
+    inc[:, 3] = [-0.5, -1.0, -2.0]                     # crosses it: half the increment fits
+    base[:, 4:] = 0.0                                  # base on the bound ...
+    inc[0, 5] = 0.0                                    # ... zero increments are harmless
+    inc[0:2, 6] = [0.0, -1.0]                          # ... a negative one cannot be taken at all
+    expected = np.array([1.0, 1.0, 1.0, 0.5, 1.0, 1.0, 0.0])
+    assert np.array_equal(scalef_for_bound(nreg, mask, base, inc, 0.0, upper=False), expected)
+    assert np.array_equal(scalef_for_bound(nreg, mask, -base, -inc, -0.0, upper=True), expected)
+    assert np.array_equal(scalef_for_bound(nreg, mask, base, inc, None, upper=False), np.ones(nreg))
+    with pytest.raises(ValueError, match="base < lob"):
+        scalef_for_bound(nreg, mask, base - 2.0, inc, 0.0, upper=False)
+    with pytest.raises(ValueError, match="base > upb"):
+        scalef_for_bound(nreg, mask, base + 2.0, inc + 1.0, 1.5, upper=True)
