@@ -22,6 +22,8 @@ import sys
 import numpy as np
 from scipy.io import netcdf_file
 
+from .hist import units_conversion_factor
+
 LOG = logging.getLogger(__name__)
 
 
@@ -112,13 +114,19 @@ def isclose_all_vars(fname1, fname2, rtol, atol):
             if var1.data.dtype.kind in "SU" or var2.data.dtype.kind in "SU":
                 continue
             units1, units2 = _decode(getattr(var1, "units", None)), _decode(getattr(var2, "units", None))
+            vals1 = np.array(var1.data)
             if units1 is not None and units2 is not None and units1 != units2:
                 if "since" in units1 or "since" in units2:
                     raise ValueError(f"time-like units disagree '{units1}'!='{units2}'")
-                LOG.info("    %s units differ ('%s', '%s'); conversion is not available", name, units1, units2)
-                same = False
-                continue
-            if not _close_values(name, np.array(var1.data), getattr(var1, "_FillValue", None),
+                # values of the first file are expressed in the units of the second (utils.py:304-310)
+                factor = units_conversion_factor(units1, units2)
+                if factor is None:
+                    LOG.info("    %s units differ ('%s', '%s') and cannot be converted", name, units1, units2)
+                    same = False
+                    continue
+                if factor != 1.0:
+                    vals1 = vals1 * factor
+            if not _close_values(name, vals1, getattr(var1, "_FillValue", None),
                                  np.array(var2.data), getattr(var2, "_FillValue", None), rtol, atol):
                 same = False
     return same

@@ -92,6 +92,41 @@ def _units_product(*units):
     return units_str_format(" ".join(f"({unit})" for unit in units))
 
 
+# SI value and dimension of the units that appear in the files of this code base (tracer_module_defs.yaml,
+# history and stats files); prefixes are spelled out, nothing is guessed
+_UNIT_TABLE = {
+    "m": (1.0, "L"), "meter": (1.0, "L"), "meters": (1.0, "L"), "cm": (1.0e-2, "L"), "mm": (1.0e-3, "L"),
+    "km": (1.0e3, "L"),
+    "s": (1.0, "T"), "sec": (1.0, "T"), "second": (1.0, "T"), "seconds": (1.0, "T"), "h": (3600.0, "T"),
+    "hr": (3600.0, "T"), "hour": (3600.0, "T"), "hours": (3600.0, "T"),
+    "d": (86400.0, "T"), "day": (86400.0, "T"), "days": (86400.0, "T"),
+    "a": (365.25 * 86400.0, "T"), "yr": (365.25 * 86400.0, "T"), "year": (365.25 * 86400.0, "T"),
+    "years": (365.25 * 86400.0, "T"),
+    "mol": (1.0, "N"), "mmol": (1.0e-3, "N"), "umol": (1.0e-6, "N"), "nmol": (1.0e-9, "N"),
+    "g": (1.0e-3, "M"), "kg": (1.0, "M"), "mg": (1.0e-6, "M"),
+}
+
+
+def units_conversion_factor(units_from, units_to):
+    """number to multiply values in `units_from` with to express them in `units_to` (the role of
+    pint's Quantity.to in utils.isclose_all_vars, nk_ooc/utils.py:304-310); None when a unit is not in
+    the table or the dimensions differ"""
+    def reduce(expr):
+        scale, dims = 1.0, {}
+        for name, power in _parse_units(expr).items():
+            if name not in _UNIT_TABLE:
+                return None
+            value, dim = _UNIT_TABLE[name]
+            scale *= value ** power
+            dims[dim] = dims.get(dim, 0) + power
+        return scale, {dim: power for dim, power in dims.items() if power}
+
+    src, dst = reduce(units_from), reduce(units_to)
+    if src is None or dst is None or src[1] != dst[1]:
+        return None
+    return src[0] / dst[0]
+
+
 def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):
     """module_hists: list of (tracer metadata dict name -> attrs, hist [ntime, tc, nz, ny]);
     vmix_coeff_fcn(t) -> (nz-1, ny) mixing coefficient / dz_mid"""

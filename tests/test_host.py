@@ -243,3 +243,24 @@ def test_limiter_known_answers():
         scalef_for_bound(nreg, mask, base - 2.0, inc, 0.0, upper=False)
     with pytest.raises(ValueError, match="base > upb"):
         scalef_for_bound(nreg, mask, base + 2.0, inc + 1.0, 1.5, upper=True)
+
+
+def test_isclose_all_vars_reference_files(golden_dir):
+    """baseline_cmp.isclose_all_vars on the three data files the reference's own test holds
+    (input/tests/isclose_{base,same,diff}.nc, tests/test_utils.py:53-76): `same` stores var2 in cm instead
+    of m, `diff` also perturbs var1 by 1e-7"""
+    from nk_ooc_amd.baseline_cmp import isclose_all_vars
+    from nk_ooc_amd.hist import units_conversion_factor
+
+    base, same, diff = (os.path.join(golden_dir, "ref_tests_input", f"isclose_{tag}.nc") for tag in ("base", "same", "diff"))
+    for rtol, atol in ((0.0, 0.0), (1.0e-5, 1.0e-5)):
+        assert isclose_all_vars(base, base, rtol=rtol, atol=atol)
+        assert isclose_all_vars(base, same, rtol=rtol, atol=atol)        # equal once the units are accounted for
+    assert not isclose_all_vars(base, diff, rtol=0.0, atol=0.0)
+    assert not isclose_all_vars(base, diff, rtol=1.0e-8, atol=1.0e-8)
+    assert isclose_all_vars(base, diff, rtol=1.0e-5, atol=1.0e-5)
+    assert units_conversion_factor("m", "cm") == 100.0
+    assert units_conversion_factor("mmol / m^3", "mol / m^3") == 1.0e-3
+    assert units_conversion_factor("m / d", "m / s") == 1.0 / 86400.0
+    assert units_conversion_factor("(mmol / m^3) (m)", "mmol / m^2") == 1.0
+    assert units_conversion_factor("m", "s") is None and units_conversion_factor("furlong", "m") is None
