@@ -16,3 +16,17 @@ def rel_err(a, b):
     b = np.asarray(b)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def free_years(eng, x, **kw):
+    """one free-running forward year with SciPy's Jacobian reuse (radau.py:509-517, the mode whose counters
+    are comparable with solve_ivp's) and one in the engine's default mode (Jacobian re-evaluated at every
+    step start): ((fx, stats, sched), (fx, stats, sched))"""
+    from nk_ooc_amd.engine import DEFAULT_JAC_FRESH
+
+    eng.set_option("jac_fresh", 0)
+    try:
+        faithful = eng.comp_fcn(x, **kw)
+    finally:
+        eng.set_option("jac_fresh", DEFAULT_JAC_FRESH)
+    return faithful, eng.comp_fcn(x, **kw)

@@ -12,7 +12,7 @@ Two modes ("parity reality check"):
 import numpy as np
 import pytest
 
-from helpers import oracle_iage, rel_err
+from helpers import free_years, oracle_iage, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -48,14 +48,17 @@ def test_comp_fcn_replay(golden_dir, tag, nz, ny, vv, kh):
 def test_comp_fcn_free(golden_dir, tag, nz, ny, vv, kh):
     g = np.load(f"{golden_dir}/comp_fcn_{tag}.npz")
     eng = make_engine(nz, ny, vv, kh)
-    fx, stats, sched = eng.comp_fcn(eng.upload(g["y0"]), record=True)
+    (fx, stats, sched), (fx_def, stats_def, _) = free_years(eng, eng.upload(g["y0"]), record=True)
     got = eng.download(fx).reshape(-1)
-    # reference CI tolerance for fcn files
+    # reference CI tolerance for fcn files, in both controller modes
     assert np.allclose(got, g["fcn"], rtol=1.0e-3, atol=1.0e-6), np.max(np.abs(got - g["fcn"]))
+    assert np.allclose(eng.download(fx_def).reshape(-1), g["fcn"], rtol=1.0e-3, atol=1.0e-6)
     assert len(sched) == stats["nsteps"]
-    # the controller takes the same kind of path as SciPy's: counters within 10 %
+    # with SciPy's Jacobian reuse the controller takes the same kind of path as SciPy's: counters within 10 %;
+    # the default mode needs no more tendency evaluations than that
     for key in ("nfev", "njev", "nlu"):
         assert abs(stats[key] - int(g[key])) <= 0.1 * int(g[key]) + 5, (key, stats[key], int(g[key]))
+    assert stats_def["nfev"] <= 1.05 * stats["nfev"] and stats_def["njev"] >= stats_def["nsteps"]
     # the recorded schedule replays to the same answer (smooth map)
     # (the replay solves the stage systems to 1e-3 or better, the free run to the engine's default inner
     # tolerance: both are converged to SciPy's Newton tolerance, 1e-3 of the error tolerance 1e-6)
@@ -74,6 +77,7 @@ def test_controller_variants_take_identical_decisions():
     col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2) + 0.01 * rng.standard_normal((2, 26, 26)))
     results = []
+    eng.set_option("jac_fresh", 0)
     for mode in (0, 1, 2):
         eng.set_option("device_ctl", mode)
         fx, stats, sched = eng.comp_fcn(x, record=True)
@@ -84,10 +88,9 @@ def test_controller_variants_take_identical_decisions():
         assert np.array_equal(sched, results[0][2])
         for key in ("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton"):
             assert stats[key] == results[0][1][key], key
-    # jac_fresh leaves SciPy's decision sequence but solves the same ODE to the same tolerance
+    # jac_fresh (the engine's default) leaves SciPy's decision sequence but solves the same ODE to the same tolerance
     eng.set_option("jac_fresh", 1)
     fx, stats, _ = eng.comp_fcn(x)
-    eng.set_option("jac_fresh", 0)
     assert np.allclose(eng.download(fx), results[0][0], rtol=1e-3, atol=1e-6)
     assert stats["njev"] == stats["nsteps"] + 1 or stats["njev"] >= stats["nsteps"]
 
@@ -130,7 +133,8 @@ def test_comp_fcn_strong_lateral_coupling(vv, kh):
     fx, stats, _ = eng.comp_fcn(eng.upload(y0), replay=np.array(solver.schedule, dtype=np.float64))
     assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
     assert stats["nsweeps"] > 3 * stats["nnewton"]          # beyond the two-sweep minimum
-    fx, stats, _ = eng.comp_fcn(eng.upload(y0))
+    (fx, stats, _), (fx_def, _, _) = free_years(eng, eng.upload(y0))
     assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
+    assert np.allclose(eng.download(fx_def).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
     for key, ref in (("nfev", solver.stats.nfev), ("njev", solver.stats.njev), ("nlu", solver.stats.nlu)):
         assert abs(stats[key] - ref) <= 0.1 * ref + 5, (key, stats[key], ref)

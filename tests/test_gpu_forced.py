@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import free_years, rel_err
 from oracle import krylov, radau
 from oracle.grid import default_axes
 from oracle.model import Forced, Iage, Py2dModel, apply_precond_stable
@@ -50,14 +50,19 @@ def test_forced_kernels(golden_dir, tag):
         want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
         fx, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=np.array(solver.schedule))
         assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
-        fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]))
+        (fx, stats, _), (fx_def, _, _) = free_years(eng, eng.upload(g["y0"]))
         assert np.allclose(eng.download(fx).reshape(-1), g["fcn"], rtol=1e-3, atol=1e-6)
+        assert np.allclose(eng.download(fx_def).reshape(-1), g["fcn"], rtol=1e-3, atol=1e-6)
         assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
 
 
-def test_two_module_krylov(tmp_path):
+def test_two_module_krylov(tmp_path, monkeypatch):
     """tracer_module_names = iage,forced_{suff}:dye with the decay options: two engines
     (two HIP streams), Hessenberg / beta of shape [2, ...]; compared with the oracle"""
+    # The forced module starts from an exactly uniform state, where the reference's own map amplifies
+    # roundoff to 1e-3 (stale-Jacobian Newton iterations, DESIGN.md section 5): its Hessenberg entries are
+    # comparable with the oracle's only when the engines reuse the Jacobian as SciPy does.
+    monkeypatch.setenv("NK2D_JAC_FRESH", "0")
     from nk_ooc_amd.krylov_solver import KrylovSolver
     from nk_ooc_amd.model_config import ModelConfig
     from nk_ooc_amd.model_state import ModelState
@@ -177,12 +182,13 @@ def test_forced_file_kernels(golden_dir, tmp_path, tag):
         want, solver = radau.comp_fcn(tm, g["y0"], return_solver=True)
         fx, _, _ = eng.comp_fcn(eng.upload(g["y0"]), replay=np.array(solver.schedule))
         assert rel_err(eng.download(fx).reshape(-1), want) < 1e-10
-        fx, stats, _ = eng.comp_fcn(eng.upload(g["y0"]))
+        (fx, stats, _), (fx_def, _, _) = free_years(eng, eng.upload(g["y0"]))
         # free-running controller: differences of the order of the integrator's tolerance (1e-6 per step);
         # the kink of the sink threshold makes the map less smooth than the linear modules'
         atol = 5e-5 if eng.state_dependent_precond else 1e-6
-        err = np.abs(eng.download(fx).reshape(-1) - g["fcn"])
-        assert np.all(err <= atol + 1e-3 * np.abs(g["fcn"])), err.max()
+        for res in (fx, fx_def):
+            err = np.abs(eng.download(res).reshape(-1) - g["fcn"])
+            assert np.all(err <= atol + 1e-3 * np.abs(g["fcn"])), err.max()
         assert abs(stats["nfev"] - int(g["nfev"])) <= 0.1 * int(g["nfev"]) + 20
 
 
