@@ -219,7 +219,10 @@ int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* 
    "device_ctl" (1: take the Newton convergence decisions on the device and read back once
    per step attempt instead of once per Newton iteration), "jac_fresh" (1: re-evaluate the
    Jacobian at every step start instead of SciPy's reuse heuristic; same ODE, same error
-   control, different -- shorter -- sequence of Newton iterations), "sweep_wpb" */
+   control, different -- shorter -- sequence of Newton iterations), "growth_cap" (> 0: largest
+   growth factor of the step size after a step whose Newton iteration failed and was repeated with
+   half the step; 1.0 is the rule of Hairer & Wanner's RADAU5, 0 = SciPy, which has none),
+   "sweep_wpb" */
 int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);
 
 /* block until every operation queued on the context's stream has finished */

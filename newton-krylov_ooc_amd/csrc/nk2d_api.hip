@@ -123,6 +123,11 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
+    if (key == "growth_cap") {
+        if (!(value >= 0.0)) return nk2d_fail(c, "nk2d_set_option: growth_cap must be >= 0");
+        c->growth_cap = value;
+        return 0;
+    }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "factor_fp32") {
         // the single precision copy is written by the next factorisation: drop the cached one
@@ -311,6 +316,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->cur_guard = nullptr;
     c->device_ctl = 0;
     c->jac_fresh = 0;
+    c->growth_cap = 0.0;
     c->hist_n = 0;
     c->hist_next = 0;
     c->hist_t = nullptr;

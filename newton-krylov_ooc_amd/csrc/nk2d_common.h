@@ -90,6 +90,8 @@ struct nk2d_ctx {
     const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
     int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
     int jac_fresh;          // 1: re-evaluate the Jacobian at every step start (see nk2d_set_option)
+    double growth_cap;      // > 0: largest step growth factor after a step whose Newton iteration failed at first
+                            // (nk2d_set_option "growth_cap"; 0 = SciPy: no memory of the failure)
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials

@@ -402,7 +402,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             s.current_jac = true;
             s.have_lu = false;
         }
-        bool rejected = false, accepted = false;
+        bool rejected = false, accepted = false, newton_failed = false;
         double h = 0, t_new = 0, err = 0, safety = 0, rate = 0;
         bool have_rate = false;
         int n_iter = 0;
@@ -450,6 +450,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             if (!converged) {
                 h_abs *= 0.5;
                 s.have_lu = false;
+                newton_failed = true;
                 continue;
             }
             // error estimate (radau.py:477-487); with device control its first pass was queued
@@ -493,6 +494,10 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         const bool recompute_jac = n_iter > 2 && have_rate && rate > 1e-3;
         double factor = predict_factor(h_abs, has_h_old, h_abs_old, err, has_err_old, err_old);
         factor = std::min(MAX_FACTOR, safety * factor);
+        // option "growth_cap" (RADAU5's rule with 1.0: after a step whose simplified Newton iteration failed and
+        // had to be repeated with half the step size, the next step is not allowed to grow -- Hairer & Wanner's
+        // radau5.f, `IF (REJECT) HNEW = MIN(HNEW, H)`; SciPy's Radau has no such memory and tries up to 10 h again)
+        if (newton_failed && c->growth_cap > 0.0) factor = std::min(factor, c->growth_cap);
         const double h_lu_used = s.h_lu;
         if (!recompute_jac && factor < 1.2) factor = 1;
         else s.have_lu = false;

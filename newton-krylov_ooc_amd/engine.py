@@ -22,6 +22,12 @@ DEFAULT_LIN_TOL = 3.0e-2
 # SuperLU factorisations): same ODE, same error control, ~15 % fewer simplified-Newton iterations
 # (DESIGN.md section 3).  0 (or NK2D_JAC_FRESH=0 in the environment) follows SciPy decision for decision.
 DEFAULT_JAC_FRESH = 1
+# largest growth factor of the step size after a step whose simplified Newton iteration failed at first and was
+# repeated with half the step size (nk2d_set_option "growth_cap"): 1.0 is the rule of Hairer & Wanner's RADAU5
+# (no growth), which SciPy's Radau dropped -- it tries up to 10 h again and fails on a third of its attempts here.
+# The rule saves 9-13 % of a forward year but changes the step sizes, and with them the history samples by up
+# to 1.8 times the tolerance of the reference's CI comparison (tools/probe_hist_modes.py): off by default.
+DEFAULT_GROWTH_CAP = 0.0
 
 
 class Nk2dError(RuntimeError):
@@ -132,6 +138,7 @@ class ModuleEngine:
         self._ctx = ctx
         self._precond_ready = False
         self.set_option("jac_fresh", float(os.environ.get("NK2D_JAC_FRESH", DEFAULT_JAC_FRESH)))
+        self.set_option("growth_cap", float(os.environ.get("NK2D_GROWTH_CAP", DEFAULT_GROWTH_CAP)))
 
     def close(self):
         if self._ctx is not None:

@@ -78,6 +78,7 @@ def test_controller_variants_take_identical_decisions():
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2) + 0.01 * rng.standard_normal((2, 26, 26)))
     results = []
     eng.set_option("jac_fresh", 0)
+    eng.set_option("growth_cap", 0)
     for mode in (0, 1, 2):
         eng.set_option("device_ctl", mode)
         fx, stats, sched = eng.comp_fcn(x, record=True)
@@ -93,6 +94,15 @@ def test_controller_variants_take_identical_decisions():
     fx, stats, _ = eng.comp_fcn(x)
     assert np.allclose(eng.download(fx), results[0][0], rtol=1e-3, atol=1e-6)
     assert stats["njev"] == stats["nsteps"] + 1 or stats["njev"] >= stats["nsteps"]
+    # growth_cap 1.0 (RADAU5's rule: no step growth after a Newton failure) changes the step sequence, not the ODE
+    # or its tolerances: fewer Newton iterations, the same year to the integrator's accuracy
+    eng.set_option("growth_cap", 1.0)
+    fx_cap, stats_cap, _ = eng.comp_fcn(x)
+    eng.set_option("growth_cap", 0.0)
+    assert np.allclose(eng.download(fx_cap), results[0][0], rtol=1e-3, atol=1e-5)
+    assert stats_cap["nnewton"] < stats["nnewton"]
+    with pytest.raises(Exception, match="growth_cap"):
+        eng.set_option("growth_cap", -1.0)
 
 
 def test_factor_storage_precision_does_not_move_the_result(golden_dir):

@@ -63,6 +63,7 @@ def test_two_module_krylov(tmp_path, monkeypatch):
     # roundoff to 1e-3 (stale-Jacobian Newton iterations): its Hessenberg entries are
     # comparable with the oracle's only when the engines reuse the Jacobian as SciPy does.
     monkeypatch.setenv("NK2D_JAC_FRESH", "0")
+    monkeypatch.setenv("NK2D_GROWTH_CAP", "0")
     from nk_ooc_amd.krylov_solver import KrylovSolver
     from nk_ooc_amd.model_config import ModelConfig
     from nk_ooc_amd.model_state import ModelState

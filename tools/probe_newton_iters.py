@@ -25,10 +25,15 @@ else:
     y0 = np.stack([np.broadcast_to(p[:, None], (n, n)) for p in prof]).copy()
     make = phosphorus_engine
 ref = None
-for lin_tol in (1e-8, 1e-3, 1e-2, 3e-2, 1e-1, 3e-1):
-    for fresh in (0, 1):
+# NK2D_GROWTH_CAPS=0,1.0,1.5: scan of the growth cap after a Newton failure at the default inner tolerance
+caps = [float(v) for v in os.environ.get("NK2D_GROWTH_CAPS", "").split(",") if v]
+for lin_tol in ((3e-2,) if caps else (1e-8, 1e-3, 1e-2, 3e-2, 1e-1, 3e-1)):
+    for fresh in (range(1, len(caps) + 1) if caps else (0, 1)):
         eng = make(grid, lin_tol=lin_tol)
-        eng.set_option("jac_fresh", fresh)
+        eng.set_option("jac_fresh", 1 if fresh else 0)
+        eng.set_option("growth_cap", caps[fresh - 1] if caps else 0.0)
+        if caps:
+            print("growth_cap", caps[fresh - 1], end=": ")
         x = eng.upload(y0)
         x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])      # the state after one fixed-point year, as in bench.py
         t0 = time.time()
