@@ -160,3 +160,28 @@ def test_newton_resume_after_interruption(tmp_path, stop_at):
     norm = lambda log, cfg: [s.replace(cfg["solverinfo"]["workdir"], "WORK") for s in log]
     assert norm(log_a, cfg_a) == norm(log_b, cfg_b)
     ModelState.reset_class()
+
+
+def test_ci_py_driver_2d_iage_setup(tmp_path):
+    """scripts/ci_py_driver_2d_iage.sh on the GPU: the 30 x 30 set-up with one fixed-point year, compared file by
+    file with the reference's committed baselines by the comparer with the reference's CLI semantics
+    (grid_vars.nc at the default tolerances; fcn_0000 / init_iterate / init_iterate_0000 at atol 1e-6,
+    rtol 1e-3; the committed fixture leaves out hist_0000.nc for its size)"""
+    from nk_ooc_amd import baseline_cmp
+    from nk_ooc_amd.model_state import ModelState
+    from nk_ooc_amd.setup_solver import make_config, setup
+
+    base = os.path.join(os.path.dirname(__file__), "golden", "ref_baselines", "ci_py_driver_2d_iage")
+    workdir = str(tmp_path)
+    cfg = make_config(workdir, 30, 30)
+    ModelState.write_files = True
+    try:
+        setup(cfg, fp_cnt=1)
+    finally:
+        ModelState.reset_class()
+    assert baseline_cmp.compare("grid_vars.nc", workdir, base)
+    gen = os.path.join(workdir, "gen_init_iterate")
+    for fname in ("fcn_0000.nc", "init_iterate_0000.nc"):
+        assert baseline_cmp.compare(fname, gen, base, rtol=1.0e-3, atol=1.0e-6), fname
+    assert baseline_cmp.compare("init_iterate.nc", os.path.dirname(cfg["solverinfo"]["init_iterate_fname"]), base,
+                                rtol=1.0e-3, atol=1.0e-6)
