@@ -10,9 +10,19 @@ the checkpoint trail (NetCDF3 vector files, Krylov_state.json), exactly the body
 `KrylovSolver.solve`'s loop (reference nk_ooc/krylov_solver.py:112-163).  Inputs are
 resident in HBM before the timed region (iterate, F(iterate), preconditioner factors).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, every rank
-owns one iage tracer module on its own GPU; the only collective is the per-iteration
-all-reduce of the convergence flag (RCCL).  value = (N * K) / max-over-ranks time.
+N > 1: one process per GPU over RCCL (torch.distributed, backend nccl).  Called as
+`python bench.py --gpus N` without a launcher around it, this process starts the N ranks
+itself (`python -m torch.distributed.run`, before anything here touches the GPU) and relays
+rank 0's JSON line.  Weak scaling: every rank owns one iage tracer module on its own GPU;
+the only collective of that layout is the per-iteration all-reduce of the convergence
+flag.  value = (N * K) / max-over-ranks time.  With N >= 2 the line also carries `shard_e2`:
+ONE iage module with its two tracers sharded over ranks 0 and 1 (SURVEY.md section 8(e) level
+2, every Radau norm and every Krylov inner product an all-reduce) timed against the same
+module on one GPU.
+
+At N = 1 the line also carries `ladder` (the metric's 26 x 26 ... 416 x 416 grid ladder: JVPs/s
+and roofline fraction per size, the CPU oracle's forward year beside it), `roofline_precond` (the
+one genuinely HBM-streaming kernel) and `cpu_baseline`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,6 +31,8 @@ import argparse
 import json
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -31,12 +43,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LADDER_SIZES = (26, 52, 104, 208)
+YEAR = 365.0 * 86400.0
 
 
-def cpu_baseline(grid_n, gpu_attempts_per_year, budget_s):
-    """time the oracle (CPU restatement of the reference path: NumPy stencil + SciPy
-    SuperLU + restated Radau controller, single thread) on a bounded sample: the first
-    Radau step attempts of the same forward year, until `budget_s` of wall time."""
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child
+    processes (nothing in this process has touched the GPU) and relay what rank 0 prints"""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.startswith("{"):
+            print(line, end="", flush=True)
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+def cpu_oracle_year(grid_n, budget_s, attempts_hint=None):
+    """the oracle (CPU restatement of the reference path: NumPy stencil + SciPy SuperLU + restated Radau
+    controller) on one host thread, from the gen_init_iterate profile: a full forward year when it
+    finishes within `budget_s`, otherwise its first step attempts scaled to `attempts_hint` attempts"""
+    from threadpoolctl import threadpool_limits
+
     from oracle import radau
     from oracle.grid import default_axes
     from oracle.model import Iage, Py2dModel, gen_init_iterate
@@ -45,30 +81,240 @@ def cpu_baseline(grid_n, gpu_attempts_per_year, budget_s):
     model = Py2dModel(depth, ypos)
     tm = Iage(model)
     y0 = gen_init_iterate(model).reshape(-1)
-    year = 365.0 * 86400.0
-    t0 = time.perf_counter()
-    solver = radau.RadauOracle(tm.comp_tend, tm.comp_jacobian, 0.0, y0, year, max_step=0.01 * year)
-    steps = 0
-    while time.perf_counter() - t0 < budget_s and solver.t < year:
-        solver.step()
-        steps += 1
-    wall = time.perf_counter() - t0
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        solver = radau.RadauOracle(tm.comp_tend, tm.comp_jacobian, 0.0, y0, YEAR, max_step=0.01 * YEAR)
+        steps = 0
+        while time.perf_counter() - t0 < budget_s and solver.t < YEAR:
+            solver.step()
+            steps += 1
+        wall = time.perf_counter() - t0
     attempts = steps + solver.stats.nrejected
-    sec_per_attempt = wall / max(attempts, 1)
-    finished = solver.t >= year
-    sec_per_jvp = wall if finished else sec_per_attempt * gpu_attempts_per_year
+    finished = solver.t >= YEAR
+    res = {"grid": grid_n, "full_year": finished, "wall_s": wall, "attempts": attempts,
+           "nfev": solver.stats.nfev, "nlu": solver.stats.nlu}
+    if finished:
+        res["seconds_per_year"] = wall
+    elif attempts_hint:
+        res["seconds_per_year"] = wall / max(attempts, 1) * attempts_hint
+        res["extrapolated_from_attempts"] = attempts
+    return res
+
+
+def cpu_baseline(grid_n, gpu_attempts_per_year, budget_s):
+    res = cpu_oracle_year(grid_n, budget_s, gpu_attempts_per_year)
+    sec = res["seconds_per_year"]
+    how = (f"one full forward year in {res['wall_s']:.1f} s" if res["full_year"] else
+           f"first {res['attempts']} Radau step attempts in {res['wall_s']:.1f} s "
+           f"({res['wall_s'] / max(res['attempts'], 1):.2f} s each), scaled to the {gpu_attempts_per_year} "
+           f"attempts the GPU run needed per forward year")
     return {
-        "value": 1.0 / sec_per_jvp,
+        "value": 1.0 / sec,
         "unit": "JVPs/s",
         "cores": 1,
         "kind": "port",
-        "sample": (f"oracle (NumPy+SciPy SuperLU Radau restatement) on iage {grid_n}x{grid_n}: "
-                   + (f"one full forward year in {wall:.1f} s" if finished else
-                      f"first {attempts} Radau step attempts in {wall:.1f} s "
-                      f"({sec_per_attempt:.2f} s each), scaled to the {gpu_attempts_per_year} "
-                      f"attempts the GPU run needed per forward year"))
-        + "; one JVP = one forward year; preconditioner and Arnoldi cost ignored",
+        "sample": f"oracle (NumPy+SciPy SuperLU Radau restatement) on iage {grid_n}x{grid_n}: {how}; "
+                  "one JVP = one forward year; preconditioner and Arnoldi cost ignored",
     }
+
+
+class Workload:
+    """iage on an n x n grid set up as the reference CI does: gen_init_iterate + one fixed-point year,
+    F(iterate), preconditioner factors -- all resident before any timing"""
+
+    def __init__(self, n, device_ordinal, tag, write_files=True):
+        from nk_ooc_amd.model_config import ModelConfig
+        from nk_ooc_amd.model_state import ModelState
+        from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+
+        self.n = n
+        self.workdir = tempfile.mkdtemp(prefix=f"nk2d_bench_{tag}_")
+        self.cfg = make_config(self.workdir, n, n, extra_solverinfo={"krylov_rel_tol": "0.0"})
+        gen_grid_vars_file(self.cfg["modelinfo"])
+        ModelState.reset_class()
+        ModelState.device_map = {"iage": device_ordinal}
+        ModelState.write_files = write_files
+        ModelState.model_config_obj = ModelConfig(self.cfg["modelinfo"])
+        t0 = time.perf_counter()
+        self.iterate = ModelState("gen_init_iterate")
+        self.iterate += self.iterate.comp_fcn(os.path.join(self.workdir, "fcn_init.nc"), None)
+        self.fcn = self.iterate.comp_fcn(os.path.join(self.workdir, "fcn_00.nc"), None)
+        self.fwd_stats = ModelState.last_stats[0]
+        self.eng = self.iterate.tracer_modules[0].eng
+        t1 = time.perf_counter()
+        self.eng.precond_setup()
+        self.eng.sync()
+        self.precond_setup_s = time.perf_counter() - t1
+        self.setup_s = time.perf_counter() - t0
+
+    def krylov(self, k_iters, tag, device):
+        from nk_ooc_amd import dist as nkdist
+
+        solverinfo = dict(self.cfg["solverinfo"])
+        solverinfo["krylov_workdir"] = os.path.join(self.workdir, tag)
+        solverinfo["krylov_max_iter"] = str(k_iters)
+        solver = nkdist.DistributedKrylovSolver(self.iterate, solverinfo, resume=False, rewind=False,
+                                                hist_fname=None, device=device)
+        solver.solve(os.path.join(self.workdir, f"increment_{tag}.nc"), self.fcn)
+        return solver
+
+    def close(self):
+        from nk_ooc_amd.model_state import ModelState
+
+        ModelState.reset_class()
+        shutil.rmtree(self.workdir, ignore_errors=True)
+
+
+def roofline_of(eng, n):
+    """dominant kernel of the forward year, from the library's HIP-event windows on the context's own
+    stream (nk2d_profile_reset / nk2d_profile_read).  `achieved` uses the RAW window time per launch --
+    the event pair's own cost is NOT subtracted, so this is a lower bound of what the kernel does; the
+    value net of an empty pair's reading and the static rocprofv3 figure of the same command are printed
+    beside it, labelled."""
+    prof = eng.profile_read()
+    samples = max(prof["samples"], 1)
+    bytes_per_launch = prof["bytes"] / samples
+    net_us = max(prof["avg_us"], 1e-3)
+    raw_us = net_us + prof["event_overhead_us"] * prof["windows"] / samples
+    achieved = bytes_per_launch / (raw_us * 1e-6) / 1e9
+    out = {
+        "bound": "hbm",
+        "kernel": f"k_newton_fused<{(eng.nz + 63) // 64}, 0, 0, 1>",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "avg_launch_us": raw_us,
+        "timing": "HIP event pairs on the context's stream around back-to-back launches, event cost included",
+        "avg_launch_us_net_of_empty_event_pair": net_us,
+        "frac_net_of_empty_event_pair": bytes_per_launch / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "event_pair_empty_us": prof["event_overhead_us"],
+        "event_windows": prof["windows"],
+        "event_samples": prof["samples"],
+        "launches": prof["launches"],
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+    }
+    pmc_fname = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{n}.json")
+    if not os.path.exists(pmc_fname):
+        pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")
+    if os.path.exists(pmc_fname):
+        pmc = json.load(open(pmc_fname))
+        out["traffic"] = pmc["traffic_bytes_per_launch_upper"]
+        out["traffic_source"] = ("static profile file " + os.path.relpath(pmc_fname, ROOT) +
+                                 " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not collected in this run)")
+    stats_fname = os.path.join(ROOT, "profiles", f"r02_rocprof_bench{n}", "kernel_stats.csv")
+    if os.path.exists(stats_fname):
+        for line in open(stats_fname):
+            if line.startswith('"void ' + out["kernel"]):
+                avg_ns = float(line.rsplit('",', 1)[1].split(",")[2])
+                out["rocprofv3"] = {"avg_launch_us": avg_ns / 1000.0,
+                                    "frac": bytes_per_launch / (avg_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                    "source": "static profile file " + os.path.relpath(stats_fname, ROOT)}
+                break
+    return out
+
+
+def precond_roofline(eng, reps=5):
+    """the preconditioner apply: 2 ny dense mat-vecs per tracer streamed from HBM (k_pc_gemv), timed with a
+    HIP event pair on the context's stream around whole applies"""
+    v = eng.upload(__import__("numpy").ones(eng.shape))
+    out = eng.precond_apply(v)
+    eng.sync()
+    eng.timer_begin()
+    for _ in range(reps):
+        eng.precond_apply(v, out=out)
+    ms = eng.timer_end() / reps
+    m = 3 * eng.nz
+    nbytes = 2.0 * eng.ny * eng.tc * m * m * 8.0
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_pc_gemv (nk2d_precond_apply: forward + backward block substitution)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "ms_per_apply": ms, "launches_per_apply": 2 * eng.ny + 2,
+            "algorithmic_bytes_per_apply": nbytes,
+            "timing": "HIP event pair on the context's stream around whole applies (launch gaps included)"}
+
+
+def run_ladder(device_ordinal, device, args):
+    """the metric's grid ladder below the headline size: JVPs/s of the same Krylov loop, the dominant
+    kernel's roofline fraction, and the CPU oracle's forward year at the sizes it finishes"""
+    rows = []
+    cpu_full = {26: 60.0, 52: 240.0}       # budget for a full CPU year; beyond: bounded sample
+    for n in LADDER_SIZES:
+        wl = Workload(n, device_ordinal, f"ladder{n}")
+        try:
+            wl.krylov(1, "warm", device)
+            wl.eng.profile_reset(1)
+            wl.eng.sync()
+            t0 = time.perf_counter()
+            wl.krylov(args.ladder_steps, "timed", device)
+            wl.eng.sync()
+            elapsed = time.perf_counter() - t0
+            roof = roofline_of(wl.eng, n)
+            from nk_ooc_amd.model_state import ModelState
+
+            st = ModelState.last_stats[0]
+            row = {"grid": n, "jvps_per_s": args.ladder_steps / elapsed,
+                   "ms_per_jvp": 1000.0 * elapsed / args.ladder_steps,
+                   "forward_year_s": st["seconds"], "nsteps": st["nsteps"], "nlaunch": st["nlaunch"],
+                   "roofline_frac": roof["frac"], "avg_launch_us": roof["avg_launch_us"],
+                   "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]}
+            if args.cpu_baseline_seconds > 0:
+                attempts = st["nsteps"] + st["nrejected"]
+                cpu = cpu_oracle_year(n, cpu_full.get(n, 12.0), attempts)
+                if "seconds_per_year" in cpu:
+                    row["cpu_oracle"] = {"seconds_per_year": cpu["seconds_per_year"], "full_year": cpu["full_year"],
+                                         "cores": 1, "attempts_timed": cpu["attempts"]}
+                    row["gpu_over_cpu"] = cpu["seconds_per_year"] / (elapsed / args.ladder_steps)
+            rows.append(row)
+        finally:
+            wl.close()
+    return rows
+
+
+def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms):
+    """SURVEY.md section 8(e) level 2, measured: ONE iage module, its two tracers on ranks 0 and 1"""
+    import numpy as np
+    import torch
+    import torch.distributed as tdist
+
+    from nk_ooc_amd import dist as nkdist
+    from nk_ooc_amd.grid import Grid2d
+
+    group = tdist.new_group([0, 1])
+    result = None
+    if rank < 2:
+        n = args.grid
+        grid = Grid2d.default(n, n)
+        comm = nkdist.ShardComm(device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu", group=group)
+        eng = nkdist.iage_shard_engine(grid, rank, comm, device_id=local_rank)
+        eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(grid.depth.delta, grid.ypos.delta))
+        col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+        x = eng.upload(np.broadcast_to(col[:, None], (1, n, n)).copy())
+        fx0, _, _ = eng.comp_fcn(x)
+        x = eng.axpby(1.0, x, 1.0, fx0)
+        fx, _, _ = eng.comp_fcn(x)
+        eng.precond_setup()
+        eng.sync()
+        k = max(1, min(args.steps, 2))
+        nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 1)     # warm-up
+        calls0 = comm.calls
+        tdist.barrier(group=group)
+        t0 = time.perf_counter()
+        _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, k)
+        eng.sync()
+        tdist.barrier(group=group)
+        elapsed = time.perf_counter() - t0
+        result = {"layout": "ONE iage module, tracer per rank on ranks 0 and 1 (block-diagonal Jacobian); every "
+                            "Radau norm and every Krylov inner product is an all-reduce(SUM) of 1 .. (j+1) nreg doubles",
+                  "backend": backend, "grid": [n, n], "krylov_iterations": k,
+                  "ms_per_jvp": 1000.0 * elapsed / k, "jvps_per_s": k / elapsed,
+                  "allreduces_per_jvp": (info["allreduces"] - calls0) / k,
+                  "one_gpu_ms_per_jvp": one_gpu_ms,
+                  "speedup_over_one_gpu": (one_gpu_ms / (1000.0 * elapsed / k)) if one_gpu_ms else None}
+        eng.close()
+    tdist.barrier()
+    return result
 
 
 def main():
@@ -79,66 +325,58 @@ def main():
     ap.add_argument("--grid", type=int, default=416, help="depth and ypos levels")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-files", action="store_true", help="skip the NetCDF trail (not the default)")
+    ap.add_argument("--no-ladder", action="store_true", help="skip the 26..208 grid ladder")
+    ap.add_argument("--ladder-steps", type=int, default=3)
+    ap.add_argument("--no-shard", action="store_true", help="skip the sharded-module leg of N >= 2 runs")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, all-reduce their ranks over gloo and print the world size "
+                         "(CPU check of the self-launch path, tests/test_dist.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's invocation: no launcher around us.  Nothing above has touched the GPU.
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
 
     from nk_ooc_amd import dist as nkdist
-    from nk_ooc_amd.model_config import ModelConfig
-    from nk_ooc_amd.model_state import ModelState
-    from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+
+    if args.launch_check:
+        rank, _, world = nkdist.init_process_group_from_env("gloo")
+        total = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            torch.distributed.all_reduce(total)
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": world, "rank_sum": int(total.item())}), flush=True)
+        return
 
     # NK2D_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks
-    # share the visible GPUs and the (4-byte) collectives run on CPU tensors; never used by the driver
+    # share the visible GPUs and the (tiny) collectives run on CPU tensors; never used by the driver
     backend = os.environ.get("NK2D_BENCH_BACKEND", "nccl")
-    rank, local_rank, world = nkdist.init_process_group_from_env(backend)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    if backend == "nccl" and world_env > 1:
+        torch.cuda.set_device(local_rank)       # before the process group: RCCL binds to the current device
+    rank, _, world = nkdist.init_process_group_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     n = args.grid
-    workdir = tempfile.mkdtemp(prefix=f"nk2d_bench_r{rank}_")
+    wl = None
     try:
-        cfg = make_config(workdir, n, n, extra_solverinfo={"krylov_rel_tol": "0.0"})
-        gen_grid_vars_file(cfg["modelinfo"])
-        ModelState.reset_class()
-        ModelState.device_map = {"iage": local_rank}
-        ModelState.write_files = not args.no_files
-        ModelState.model_config_obj = ModelConfig(cfg["modelinfo"])
-
-        # inputs: gen_init_iterate profile + one fixed-point year (as the reference CI sets
-        # up), F(iterate), and the preconditioner factors -- all resident before timing
-        t_setup = time.perf_counter()
-        iterate = ModelState("gen_init_iterate")
-        iterate += iterate.comp_fcn(os.path.join(workdir, "fcn_init.nc"), None)
-        fcn = iterate.comp_fcn(os.path.join(workdir, "fcn_00.nc"), None)
-        fwd_stats = ModelState.last_stats[0]
-        eng = iterate.tracer_modules[0].eng
-        t_pc = time.perf_counter()
-        eng.precond_setup()
-        eng.sync()
-        precond_setup_s = time.perf_counter() - t_pc
-        setup_s = time.perf_counter() - t_setup
-
-        def run(k_iters, tag):
-            solverinfo = dict(cfg["solverinfo"])
-            solverinfo["krylov_workdir"] = os.path.join(workdir, tag)
-            solverinfo["krylov_max_iter"] = str(k_iters)
-            solver = nkdist.DistributedKrylovSolver(iterate, solverinfo, resume=False, rewind=False,
-                                                    hist_fname=None, device=device)
-            solver.solve(os.path.join(workdir, f"increment_{tag}.nc"), fcn)
-            return solver
-
+        wl = Workload(n, local_rank, f"r{rank}", write_files=not args.no_files)
+        eng = wl.eng
         if args.warmup > 0:
-            run(args.warmup, "krylov_warm")
+            wl.krylov(args.warmup, "krylov_warm", device)
         eng.profile_reset(1)
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         t0 = time.perf_counter()
-        solver = run(args.steps, "krylov_timed")
+        wl.krylov(args.steps, "krylov_timed", device)
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -148,23 +386,14 @@ def main():
         if world > 1:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(el.item())
-        prof = eng.profile_read()
-        jvp_stats = ModelState.last_stats[0]
+        from nk_ooc_amd.model_state import ModelState
 
+        jvp_stats = ModelState.last_stats[0]
+        out = None
         if rank == 0:
             total_jvps = args.steps * world
-            # HIP-event windows around back-to-back launches of the kernel on the context's stream
-            # (nk2d_profile_reset/read): per-launch time net of the event machinery, and the
-            # algorithmic bytes of exactly those launches
-            bytes_per_launch = prof["bytes"] / max(prof["samples"], 1)
-            kernel_us = max(prof["avg_us"], 1e-3)
-            achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-            traffic = None
-            pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")
-            if os.path.exists(pmc_fname):
-                # HBM-side bytes per launch of the same kernel from separate rocprofv3 --pmc
-                # passes (FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE); see the file
-                traffic = json.load(open(pmc_fname))["traffic_bytes_per_launch_upper"]
+            totals = eng.profile_totals()
+            roof = roofline_of(eng, n)
             out = {
                 "metric": "GMRES JVPs/sec, py_driver_2d iage",
                 "value": total_jvps / elapsed,
@@ -186,37 +415,62 @@ def main():
                     "tracer_modules_per_gpu": 1,
                     "krylov_iterations": args.steps,
                     "parallelism": f"tracer-module-per-gpu x{world}",
+                    "collective_backend": backend if world > 1 else None,
+                    "integrator_mode": integrator_mode(),
                 },
-                "roofline": {
-                    "bound": "hbm",
-                    "kernel": f"k_newton_fused<{eng.nz // 64 + (1 if eng.nz % 64 else 0)}, 0, 0, 1>",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic,
-                    "avg_launch_us": kernel_us,
-                    "event_windows": prof["windows"],
-                    "event_pair_empty_us": prof["event_overhead_us"],
-                    "event_samples": prof["samples"],
-                    "launches": prof["launches"],
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                "roofline": roof,
+                "end_to_end": {
+                    "what": "algorithmic bytes of ALL launches of the dominant kernel in the timed region / wall "
+                            "time of the timed region (host round trips, other kernels and the file trail included "
+                            "in the time, their bytes not counted): a lower bound of the whole path's rate",
+                    "dominant_kernel_bytes_per_jvp": totals["bytes"] / args.steps,
+                    "dominant_kernel_launches_per_jvp": totals["launches"] / args.steps,
+                    "achieved_GBs_per_gpu": totals["bytes"] / elapsed / 1e9,
+                    "frac_of_hbm_peak": totals["bytes"] / elapsed / 1e9 / HBM_PEAK_GBS,
                 },
                 "forward_year": {k: jvp_stats[k] for k in
                                  ("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps",
                                   "nlaunch", "seconds")},
-                "setup_seconds": {"total": setup_s, "precond_factorisation": precond_setup_s},
+                "setup_seconds": {"total": wl.setup_s, "precond_factorisation": wl.precond_setup_s},
             }
+            if world == 1:
+                out["roofline_precond"] = precond_roofline(eng)
+        one_gpu_ms = 1000.0 * elapsed / args.steps
+        wl.close()
+        wl = None
+        if world >= 2 and not args.no_shard:
+            shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms)
+            if rank == 0:
+                out["shard_e2"] = shard
+        if rank == 0:
+            if world == 1 and not args.no_ladder:
+                out["ladder"] = run_ladder(local_rank, device, args)
+                out["ladder"].append({"grid": n, "jvps_per_s": out["value"], "ms_per_jvp": out["ms_per_step"],
+                                      "forward_year_s": jvp_stats["seconds"], "nsteps": jvp_stats["nsteps"],
+                                      "nlaunch": jvp_stats["nlaunch"], "roofline_frac": out["roofline"]["frac"],
+                                      "avg_launch_us": out["roofline"]["avg_launch_us"],
+                                      "algorithmic_bytes_per_launch": out["roofline"]["algorithmic_bytes_per_launch"]})
             if world == 1 and args.cpu_baseline_seconds > 0:
                 attempts = jvp_stats["nsteps"] + jvp_stats["nrejected"]
                 out["cpu_baseline"] = cpu_baseline(n, attempts, args.cpu_baseline_seconds)
                 out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+                if "ladder" in out:
+                    out["ladder"][-1]["cpu_oracle"] = {
+                        "seconds_per_year": 1.0 / out["cpu_baseline"]["value"], "full_year": False, "cores": 1}
             print(json.dumps(out), flush=True)
     finally:
-        ModelState.reset_class()
-        shutil.rmtree(workdir, ignore_errors=True)
+        if wl is not None:
+            wl.close()
         if world > 1:
             torch.distributed.destroy_process_group()
+
+
+def integrator_mode():
+    """the controller mode of the forward years in this run (engine defaults, overridable from the environment)"""
+    from nk_ooc_amd.engine import DEFAULT_JAC_FRESH, DEFAULT_LIN_TOL
+
+    return {"jac_fresh": int(float(os.environ.get("NK2D_JAC_FRESH", DEFAULT_JAC_FRESH))),
+            "lin_tol": float(os.environ.get("NK2D_LIN_TOL", DEFAULT_LIN_TOL)), "rtol": 1.0e-6, "atol": 1.0e-6}
 
 
 if __name__ == "__main__":

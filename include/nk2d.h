@@ -215,6 +215,59 @@ int nk2d_profile_reset(nk2d_ctx* ctx, int32_t every_n);
 int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
                       double* overhead_us, int64_t* windows);
 
+/* the same counters since the last nk2d_profile_reset over ALL launches of the dominant kernel (timed
+   or not): their number and their algorithmic bytes -- for the end-to-end rate bytes / wall time */
+int nk2d_profile_totals(nk2d_ctx* ctx, int64_t* launches, double* bytes);
+/* a HIP event pair on the context's own stream for the caller's measurements (bench.py times the
+   preconditioner apply with it): nk2d_timer_begin records the first event, nk2d_timer_end records
+   the second, waits for it and returns the elapsed milliseconds between the two */
+int nk2d_timer_begin(nk2d_ctx* ctx);
+int nk2d_timer_end(nk2d_ctx* ctx, double* elapsed_ms);
+
+/* ---- the Krylov loop itself on the device ------------------------------
+
+   nk2d_jvp: ModelStateBase.comp_jacobian_fcn_state_prod for one tracer module,
+   nk_ooc/model_state_base.py:492-527, in one call: sigma[r] = 1e-4 * norm(x)[r] (1 where that is 0),
+   w = (F(x + sigma v) - fx) * (1 / sigma), region by region.  fx = F(x) is the caller's (the Newton
+   solver has it).  perturb_fcn (optional, may be null) receives F(x + sigma v), the vector the
+   reference dumps as perturb_fcn_w_raw_NN.nc; sigma_out (optional) [nreg]; stats (optional) of the
+   perturbed forward year. */
+int nk2d_jvp(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_vec v, nk2d_vec w, nk2d_vec perturb_fcn,
+             double* sigma_out, nk2d_stats* stats);
+
+/* nk2d_gmres_solve: KrylovSolver.solve + _solve0 for ONE tracer module, nk_ooc/krylov_solver.py:85-165:
+   left-preconditioned GMRES (Saad alg. 9.4), zero initial guess, no restart, one Hessenberg per
+   region, coefficients = argmin || beta e_1 - H c ||_2 (the reference calls np.linalg.lstsq,
+   krylov_solver.py:168-181; here a Givens QR of the Hessenberg -- the same minimiser), stop when
+   iteration >= min_iter and || sum_j c_j w_j + M^-1 fx || < rel_tol * beta in every region, or at
+   max_iter.  Everything stays in HBM; nothing is written to disk (the Python mirror of KrylovSolver
+   keeps the reference's file trail).  The preconditioner is nk2d_precond_apply: call
+   nk2d_precond_setup (or _setup_states) first; the phosphorus module, whose preconditioner is
+   assembled above this boundary, is refused.
+   Outputs (caller-owned host buffers, zero padded): beta [nreg]; h_mat [max_iter+1][max_iter][nreg]
+   (the reference's h_mat[module] with the iteration axes first); resid_norm [max_iter][nreg];
+   coeff [max_iter][nreg] of the last iteration; *iters = iterations done; increment = the device
+   vector the reference dumps as increment_NN.nc.  Any of beta / h_mat / resid_norm / coeff may be null. */
+int nk2d_gmres_solve(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, double rel_tol, int32_t min_iter,
+                     int32_t max_iter, nk2d_vec increment, double* beta, double* h_mat,
+                     double* resid_norm, double* coeff, int32_t* iters);
+
+/* all n region-weighted dot products <w, basis[i]> in one launch and one read-back (the fused
+   multi-dot of SURVEY.md section 8(e)); out [n][nreg] */
+int nk2d_multi_dot(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* out);
+/* w -= sum_i bcast(h[i]) basis[i] in one launch; h [n][nreg] (classical Gram-Schmidt update) */
+int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, const double* h);
+
+/* Tracers of one module sharded over several contexts / GPUs (level 2): the
+   tracers' Jacobian blocks are independent, but SciPy's Radau takes its decisions from norms over the
+   whole module (radau.py:118,481; common.py:63-65).  With a hook installed, every sum of squares the
+   controller reads is passed through `fn` (the caller makes it an all-reduce over the shards: RCCL on
+   GPUs, gloo in the CPU tests) and the RMS norms divide by global_n = the module's tc * nz * ny, so
+   that all shards take identical decisions.  fn == NULL removes the hook.  Host-side decisions only
+   (option "device_ctl" 0). */
+typedef double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares);
+int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double global_n);
+
 /* run-time options: "lin_tol" (relative accuracy of the inner line-relaxation solves),
    "device_ctl" (1: take the Newton convergence decisions on the device and read back once
    per step attempt instead of once per Newton iteration), "jac_fresh" (1: re-evaluate the

@@ -123,10 +123,22 @@ SIGNATURES = {
     "nk2d_apply_region_mask": (_ci, [_vp, _vp]),
     "nk2d_profile_reset": (_ci, [_vp, _i32]),
     "nk2d_profile_read": (_ci, [_vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p, c_int64_p]),
+    "nk2d_profile_totals": (_ci, [_vp, c_int64_p, c_double_p]),
+    "nk2d_timer_begin": (_ci, [_vp]),
+    "nk2d_timer_end": (_ci, [_vp, c_double_p]),
+    "nk2d_jvp": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, c_double_p, ctypes.POINTER(Stats)]),
+    "nk2d_gmres_solve": (_ci, [_vp, _vp, _vp, _d, _i32, _i32, _vp, c_double_p, c_double_p, c_double_p,
+                               c_double_p, c_int32_p]),
+    "nk2d_multi_dot": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
+    "nk2d_multi_axpy": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
+    "nk2d_set_norm_hook": (_ci, [_vp, _vp, _vp, _d]),
     "nk2d_set_option": (_ci, [_vp, ctypes.c_char_p, _d]),
     "nk2d_sync": (_ci, [_vp]),
     "nk2d_stream": (_vp, [_vp]),
 }
+
+# double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares)
+NORM_HOOK = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double)
 
 _lib = None
 

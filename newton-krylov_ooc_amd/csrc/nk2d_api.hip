@@ -194,6 +194,44 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     c->win_seq = 0;
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
+    c->fused_bytes_all = 0.0;
+    return 0;
+}
+
+extern "C" int nk2d_profile_totals(nk2d_ctx* c, int64_t* launches, double* bytes) {
+    if (launches) *launches = c->sweep_launches;
+    if (bytes) *bytes = c->fused_bytes_all;
+    return 0;
+}
+
+extern "C" int nk2d_timer_begin(nk2d_ctx* c) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (!c->timer_ready) {
+        NK2D_CHECK(c, hipEventCreate(&c->timer_ev[0]));
+        NK2D_CHECK(c, hipEventCreate(&c->timer_ev[1]));
+        c->timer_ready = 1;
+    }
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[0], c->stream));
+    return 0;
+}
+
+extern "C" int nk2d_timer_end(nk2d_ctx* c, double* elapsed_ms) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (!c->timer_ready) return nk2d_fail(c, "nk2d_timer_end: nk2d_timer_begin was not called");
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[1], c->stream));
+    NK2D_CHECK(c, hipEventSynchronize(c->timer_ev[1]));
+    float ms = 0.f;
+    NK2D_CHECK(c, hipEventElapsedTime(&ms, c->timer_ev[0], c->timer_ev[1]));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return 0;
+}
+
+extern "C" int nk2d_set_norm_hook(nk2d_ctx* c, nk2d_norm_hook_fn fn, void* user, double global_n) {
+    if (fn && !(global_n >= (double)c->tc * c->nz * c->ny))
+        return nk2d_fail(c, "nk2d_set_norm_hook: global_n must be at least this context's tc * nz * ny");
+    c->norm_hook = fn;
+    c->norm_hook_user = fn ? user : nullptr;
+    c->global_n = fn ? global_n : 0.0;
     return 0;
 }
 
@@ -417,6 +455,11 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->win_seq = 0;
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
+    c->fused_bytes_all = 0.0;
+    c->norm_hook = nullptr;
+    c->norm_hook_user = nullptr;
+    c->global_n = 0.0;
+    c->timer_ready = 0;
     *out = c;  // returned even on failure so that nk2d_last_error can be read
     return create_impl(c, desc);
 }
@@ -441,6 +484,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     for (float* b : fbufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->timer_ready) { (void)hipEventDestroy(c->timer_ev[0]); (void)hipEventDestroy(c->timer_ev[1]); }
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hPART) (void)hipHostFree(c->hPART);

@@ -131,6 +131,16 @@ struct nk2d_ctx {
     // counters of the running comp_fcn
     nk2d_stats st;
 
+    // coupling of the integrator's scalar norms across contexts that share one tracer module (tracers
+    // sharded over GPUs, nk2d_set_norm_hook): every sum of squares the controller reads goes through
+    // norm_hook (an all-reduce supplied by the caller) and n_total is the module's size, not the shard's
+    nk2d_norm_hook_fn norm_hook;
+    void* norm_hook_user;
+    double global_n;
+    // generic event pair on the context's stream (nk2d_timer_begin / nk2d_timer_end)
+    hipEvent_t timer_ev[2];
+    int timer_ready;
+
     // sampled HIP-event timing of the line-relaxation sweep kernel (nk2d_profile_*)
     int prof_every;
     std::vector<hipEvent_t> prof_ev;  // start/stop pairs
@@ -139,6 +149,7 @@ struct nk2d_ctx {
     double prof_overhead_ms;          // elapsed time of an EMPTY event pair (calibration)
     int64_t prof_cnt;
     int64_t sweep_launches;           // launches of the dominant kernel since the last nk2d_profile_reset
+    double fused_bytes_all;           // algorithmic bytes of ALL those launches (timed or not)
     double sweep_bytes;               // algorithmic bytes of the launches inside timed windows
     int64_t prof_windows;             // timed windows folded into prof_ms_sum (prof_cnt: their launches)
     std::vector<int> prof_win_launches;

@@ -1819,6 +1819,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         if (!do_update) words += 3.0 * N;
         if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;
         c->sweep_launches++;
+        c->fused_bytes_all += 8.0 * words;
         if (c->win_open) {
             c->win_launches++;
             c->win_bytes += 8.0 * words;

@@ -492,6 +492,12 @@ int precond_eliminate(nk2d_ctx* c) {
                                          pc->BUF + ((size_t)src * nsys + sys) * mm, sizeof(double) * mm,
                                          hipMemcpyDeviceToDevice, c->stream));
         NK2D_CHECK(c, hipGetLastError());
+        // bounded queue depth: a column is ~80 launches, and the whole elimination used to be queued (33 000
+        // launches at 416 x 416) before the first synchronisation.  Under `rocprofv3 --pmc` that crashed the
+        // profiler's dispatch interceptor (SIGSEGV in librocprofiler-sdk.so reached from this loop's
+        // hipLaunchKernel, with or without torch in the process: gpurun_out/r02_pc_fetch.log resolved against
+        // the probe's /proc/self/maps).  The GPU is never idle for it: a column is 1.3 ms of work.
+        if ((j & 3) == 3) NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     }
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     return 0;

@@ -48,6 +48,12 @@ struct Ctl {
 
 double rms_from_sum(double s, double count) { return std::sqrt(s) / std::sqrt(count); }
 
+// a sum of squares over this context's tracers -> over the whole tracer module (nk2d_set_norm_hook:
+// the caller's all-reduce when the module's tracers are sharded over contexts; identity otherwise)
+inline void couple(const nk2d_ctx* c, double* sum) {
+    if (c->norm_hook) *sum = c->norm_hook(c->norm_hook_user, *sum);
+}
+
 int eval_kv(nk2d_ctx* c, double t, int slot) {
     double* out[1] = {c->KV[slot]};
     return nk2d_k_vmix(c, 1, &t, out);
@@ -229,6 +235,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
         } else {
             NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
         }
+        couple(c, &sum);
         const double dW_norm = rms_from_sum(sum, 3.0 * s.n_total);
         if (!(dW_norm == dW_norm)) break;  // NaN: treat as divergence
         if (has_old) { rate = dW_norm / dW_norm_old; has_rate = true; }
@@ -348,8 +355,10 @@ int initial_step(Ctl& s, double* h_out) {
     double s0 = 0, s1 = 0, s2 = 0;
     NK2D_TRY(nk2d_r_wnorm(c, c->Y, nullptr, 1.0, 0.0, c->Y));
     NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &s0));
+    couple(c, &s0);
     NK2D_TRY(nk2d_r_wnorm(c, c->F, nullptr, 1.0, 0.0, c->Y));
     NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &s1));
+    couple(c, &s1);
     const double d0 = rms_from_sum(s0, s.n_total), d1 = rms_from_sum(s1, s.n_total);
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     h0 = std::min(h0, interval);
@@ -359,6 +368,7 @@ int initial_step(Ctl& s, double* h_out) {
     c->st.nfev++;
     NK2D_TRY(nk2d_r_wnorm(c, c->TMP2, c->F, 1.0, -1.0, c->Y));
     NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &s2));
+    couple(c, &s2);
     const double d2 = rms_from_sum(s2, s.n_total) / h0;
     double h1;
     if (d1 <= 1e-15 && d2 <= 1e-15) h1 = std::max(1e-6, h0 * 1e-3);
@@ -470,6 +480,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 }
                 NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
             }
+            couple(c, &sum);
             err = rms_from_sum(sum, s.n_total);
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             if (rejected && err > 1) {
@@ -479,6 +490,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 NK2D_TRY(solve_systems(s, true, false, &buf));
                 NK2D_TRY(nk2d_r_err_norm(c, c->XR[buf]));
                 NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
+                couple(c, &sum);
                 err = rms_from_sum(sum, s.n_total);
             }
             if (err > 1) {
@@ -563,7 +575,9 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.t = c->d.t0;
     s.t1 = c->d.t1;
     s.max_step = (c->d.t1 - c->d.t0) * c->d.max_step_frac;
-    s.n_total = (double)c->tc * c->nz * c->ny;
+    s.n_total = (c->norm_hook && c->global_n > 0.0) ? c->global_n : (double)c->tc * c->nz * c->ny;
+    if (c->norm_hook && c->device_ctl != 0 && !replay)
+        return nk2d_fail(c, "nk2d_comp_fcn: a norm hook (sharded tracer module) needs host-side decisions (device_ctl 0)");
     s.newton_tol = std::max(10 * std::numeric_limits<double>::epsilon() / c->d.rtol, std::min(0.03, std::sqrt(c->d.rtol)));
     s.has_old_h = s.has_old_err = false;
     s.h_abs_old = s.err_old = 0;

@@ -265,6 +265,78 @@ class ModuleEngine:
         return {"avg_us": avg.value, "samples": samples.value, "launches": launches.value,
                 "bytes": nbytes.value, "event_overhead_us": ovh.value, "windows": windows.value}
 
+    def profile_totals(self):
+        """launches of the dominant kernel since profile_reset (timed or not) and their algorithmic bytes"""
+        launches, nbytes = ctypes.c_int64(), ctypes.c_double()
+        self._chk(self._lib.nk2d_profile_totals(self._ctx, ctypes.byref(launches), ctypes.byref(nbytes)))
+        return {"launches": launches.value, "bytes": nbytes.value}
+
+    def timer_begin(self):
+        """first event of a HIP event pair on the context's own stream"""
+        self._chk(self._lib.nk2d_timer_begin(self._ctx))
+
+    def timer_end(self):
+        """second event of the pair; waits for it and returns the elapsed milliseconds"""
+        ms = ctypes.c_double()
+        self._chk(self._lib.nk2d_timer_end(self._ctx, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- the Krylov loop on the device (C entry points of SURVEY.md section 8(b)) -----------------
+    def jvp(self, x, fx, v, out=None, perturb_fcn=None):
+        """finite-difference Jacobian-vector product in one call (model_state_base.py:492-527):
+        returns (w, sigma [nreg], stats of the perturbed year)"""
+        out = self.new_vec() if out is None else out
+        sigma = np.empty(self.nreg)
+        stats = _lib.Stats()
+        self._chk(self._lib.nk2d_jvp(self._ctx, x.ptr, fx.ptr, v.ptr, out.ptr,
+                                     perturb_fcn.ptr if perturb_fcn is not None else None,
+                                     _dp(sigma), ctypes.byref(stats)))
+        return out, sigma, stats.as_dict()
+
+    def gmres_solve(self, x, fx, rel_tol, min_iter, max_iter, out=None):
+        """KrylovSolver.solve for this one module, all on the device (krylov_solver.py:85-165).  Returns
+        (increment, dict(beta [nreg], h_mat [iters+1, iters, nreg], resid_norm [iters, nreg],
+        coeff [iters, nreg], iters))"""
+        out = self.new_vec() if out is None else out
+        beta = np.zeros(self.nreg)
+        h_mat = np.zeros((max_iter + 1, max_iter, self.nreg))
+        resid = np.zeros((max_iter, self.nreg))
+        coeff = np.zeros((max_iter, self.nreg))
+        iters = ctypes.c_int32()
+        if not self._precond_ready and self.module_kind != 1:
+            self.precond_setup()
+        self._chk(self._lib.nk2d_gmres_solve(self._ctx, x.ptr, fx.ptr, float(rel_tol), int(min_iter),
+                                             int(max_iter), out.ptr, _dp(beta), _dp(h_mat), _dp(resid),
+                                             _dp(coeff), ctypes.byref(iters)))
+        k = iters.value
+        return out, {"beta": beta, "h_mat": h_mat[: k + 1, :k].copy(), "resid_norm": resid[:k].copy(),
+                     "coeff": coeff[:k].copy(), "iters": k}
+
+    def multi_dot(self, w, basis):
+        """all region-weighted dots <w, basis[i]> in one launch: (n, nreg)"""
+        out = np.empty((len(basis), self.nreg))
+        ptrs = (ctypes.c_void_p * len(basis))(*[v.ptr for v in basis])
+        self._chk(self._lib.nk2d_multi_dot(self._ctx, w.ptr, len(basis), ptrs, _dp(out)))
+        return out
+
+    def multi_axpy(self, w, basis, h):
+        """w -= sum_i bcast(h[i]) basis[i], in place, one launch"""
+        h = np.ascontiguousarray(h, dtype=np.float64).reshape(len(basis), self.nreg)
+        ptrs = (ctypes.c_void_p * len(basis))(*[v.ptr for v in basis])
+        self._chk(self._lib.nk2d_multi_axpy(self._ctx, w.ptr, len(basis), ptrs, _dp(h)))
+        return w
+
+    def set_norm_hook(self, fcn, global_n):
+        """couple the integrator's scalar norms with other contexts holding tracers of the same module
+        (dist.TracerShardedModule): `fcn(local_sum_of_squares) -> global sum`; None removes the hook"""
+        if fcn is None:
+            self._norm_hook = None
+            self._chk(self._lib.nk2d_set_norm_hook(self._ctx, None, None, 0.0))
+            return
+        self._norm_hook = _lib.NORM_HOOK(lambda user, val: float(fcn(val)))   # keep the thunk alive
+        self._chk(self._lib.nk2d_set_norm_hook(
+            self._ctx, ctypes.cast(self._norm_hook, ctypes.c_void_p), None, float(global_n)))
+
     def comp_fcn_hist(self, x, t_eval, out=None):
         """forward year with dense output: returns (fx, stats, hist [len(t_eval), tc, nz, ny])"""
         out = self.new_vec() if out is None else out

@@ -193,7 +193,8 @@ class ModelState:
     _engines = None
     _grid = None
     _resident = {}
-    RESIDENT_MAX = 256      # device snapshots kept by name (only trimmed when the files are on disk)
+    RESIDENT_MAX = 256      # device snapshots kept by name; the oldest are dropped beyond this, with or
+                            # without the files on disk (write_files=False: a dropped name cannot be re-opened)
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
     _precond_state = {}     # precond file -> {module name: linearisation field}
     last_stats = None       # stats of the most recent comp_fcn, per module
@@ -278,6 +279,10 @@ class ModelState:
                                    src["init_iterate_vals"])
                 vals.append(np.broadcast_to(column[:, np.newaxis], shape))
             return np.stack(vals)
+        if not self.write_files and not os.path.exists(fname):
+            raise FileNotFoundError(
+                f"{fname}: not on disk (ModelState.write_files is False) and its device snapshot was "
+                f"dropped from the resident cache (RESIDENT_MAX={self.RESIDENT_MAX})")
         data, _ = ncio.read_file(fname, list(tracers))
         for tracer_name in tracers:
             if data[tracer_name].shape != shape:
@@ -299,11 +304,12 @@ class ModelState:
         if caller is None:
             raise ValueError("caller unknown")
         # device snapshot under the file's name: a later ModelState(fname) of this process skips the
-        # file read.  Oldest snapshots are dropped beyond RESIDENT_MAX (the files remain on disk).
+        # file read.  Oldest snapshots are dropped beyond RESIDENT_MAX whether or not the files are
+        # written: the cache is bounded (a Krylov solve re-opens only names of its own iteration range).
         cache = self._resident
         cache.pop(os.path.abspath(fname), None)
         cache[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
-        while len(cache) > self.RESIDENT_MAX and self.write_files:
+        while len(cache) > self.RESIDENT_MAX:
             cache.pop(next(iter(cache)))
         if self.write_files:
             tracer_vals = {}

@@ -104,8 +104,71 @@ class FakeEngine:
     def apply_region_mask(self, v):
         return v
 
+    def multi_dot(self, w, basis):
+        return np.stack([self.dot(w, v) for v in basis])
+
+    def multi_axpy(self, w, basis, h):
+        for coef, v in zip(np.asarray(h), basis):
+            w.arr -= coef[0] * v.arr
+        return w
+
+
+def shard_main(outdir):
+    """tracers of one module on two ranks: all-reduced inner products, CGS-2 and the sharded GMRES loop"""
+    import torch.distributed as dist
+
+    from nk_ooc_amd import dist as nkdist
+
+    rank, _, world = nkdist.init_process_group_from_env("gloo")
+    assert world == 2
+    nz, ny = 6, 5
+    eng = FakeEngine(nz, ny, 1, seed=10 + rank)
+    weight = np.outer(np.linspace(1.0, 2.0, nz), np.linspace(3.0, 1.0, ny))
+    eng.set_region(np.ones((nz, ny), dtype=np.int32), weight)
+    wn = eng.wn.reshape(nz, ny)
+    rng = np.random.default_rng(123)                       # the same full vectors on both ranks
+    full = rng.standard_normal((5, 2, nz, ny))
+
+    def wdot(a, b):
+        return float((wn[np.newaxis] * a * b).sum())
+
+    comm = nkdist.ShardComm("cpu")
+    vs = nkdist.ShardedVectorSpace(eng, comm)
+    local = [eng.upload(v[rank:rank + 1]) for v in full]
+    dot_err = abs(vs.dot(local[0], local[1])[0] - wdot(full[0], full[1])) / abs(wdot(full[0], full[1]))
+    # orthonormal basis of three full vectors (redundantly on both ranks), then project a fourth
+    basis_full = []
+    for v in full[:3]:
+        v = v.copy()
+        for b in basis_full:
+            v -= wdot(v, b) * b
+        basis_full.append(v / np.sqrt(wdot(v, v)))
+    w_full = full[3].copy()
+    h_want = []
+    for b in basis_full:
+        h_want.append(wdot(w_full, b))
+        w_full -= h_want[-1] * b
+    basis = [eng.upload(b[rank:rank + 1]) for b in basis_full]
+    w = eng.upload(full[3][rank:rank + 1])
+    h_got = vs.cgs2(w, basis)
+    h_err = float(np.max(np.abs(h_got[:, 0] - np.array(h_want))))
+    ortho = float(np.max(np.abs(comm.allreduce(eng.multi_dot(w, basis)))))
+    calls = comm.calls
+    x, fx = local[4], eng.comp_fcn(local[4])[0]
+    before = comm.calls
+    _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 3)
+    res = {"dot_err": dot_err, "h_err": h_err, "ortho": ortho, "allreduces": calls,
+           "gmres_resid_drop": float(info["resid_norm"][-1][0] / info["beta"][0]),
+           "gmres_allreduces_per_iter": (comm.calls - before - 1) / info["iters"]}
+    with open(os.path.join(outdir, f"shard{rank}.json"), "w") as fptr:
+        json.dump(res, fptr)
+    dist.barrier()
+    dist.destroy_process_group()
+
 
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "shard":
+        return shard_main(sys.argv[1])
     import torch.distributed as dist
 
     from nk_ooc_amd import dist as nkdist

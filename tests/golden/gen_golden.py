@@ -378,9 +378,65 @@ def gen_forced_file_all():
     gen_forced_file("file_restore_decay_70x5", 70, 5, "file", "decay", None, 13)
 
 
+def gen_comp_fcn_large(n, leg):
+    """forward year on an n x n grid (n = 52, 104: the production-mode parity cases).  Two legs that
+    may run as separate processes (each takes ~15 min at 104 x 104):
+      leg "ref":   solve_ivp driven with the genuine reference functions, exactly as
+                   py_driver_2d/model_state.py:102-114 does -> y0, fcn, nfev/njev/nlu;
+      leg "sched": the oracle's Radau restatement on the same y0 -> accepted-step schedule
+                   (t, t_new, h, n_newton, t_jac, h_lu) for step-replay mode, and its result.
+    `merge` joins them into comp_fcn_{n}x{n}.npz after checking that the two results are bit-identical
+    (the oracle reproduces solve_ivp)."""
+    tag = f"{n}x{n}"
+    part = os.path.join(HERE, f"_part_{leg}_{tag}.npz")
+    if leg == "ref":
+        from scipy import integrate
+
+        depth, ypos, processes, tm = ref_setup(n, n, 0.1, 1000.0)
+        col = np.interp(depth.mid, [55.0, 200.0], [0.0, 2.0])
+        y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).reshape(-1).copy()
+        time_range = (0.0, 365.0 * 86400.0)
+        sol = integrate.solve_ivp(
+            tm.comp_tend, time_range, y0, "Radau", np.array(time_range),
+            max_step=(time_range[1] - time_range[0]) * 0.01, atol=1.0e-6, rtol=1.0e-6,
+            args=(processes,), jac=tm.comp_jacobian,
+            jac_sparsity=tm.comp_jacobian_sparsity(time_range[0], y0, processes))
+        np.savez_compressed(part, y0=y0, fcn=sol.y[:, -1] - y0, nfev=sol.nfev, njev=sol.njev, nlu=sol.nlu)
+        print("ref leg", tag, sol.nfev, sol.njev, sol.nlu)
+    elif leg == "sched":
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        from oracle import radau
+        from oracle.grid import default_axes
+        from oracle.model import Iage, Py2dModel, gen_init_iterate
+
+        model = Py2dModel(*default_axes(n, n), 0.1, 1000.0)
+        tm = Iage(model)
+        y0 = gen_init_iterate(model).reshape(-1)
+        res, solver = radau.comp_fcn(tm, y0, return_solver=True)
+        st = solver.stats
+        np.savez_compressed(part, y0=y0, fcn=res, schedule=np.array(solver.schedule, dtype=np.float64),
+                            nfev=st.nfev, njev=st.njev, nlu=st.nlu, nrejected=st.nrejected, nnewton=st.nnewton)
+        print("sched leg", tag, st.nfev, st.njev, st.nlu, len(solver.schedule))
+    else:
+        ref = np.load(os.path.join(HERE, f"_part_ref_{tag}.npz"))
+        sch = np.load(os.path.join(HERE, f"_part_sched_{tag}.npz"))
+        assert np.array_equal(ref["y0"], sch["y0"]) and np.array_equal(ref["fcn"], sch["fcn"]), \
+            "oracle and solve_ivp(reference functions) differ"
+        for key in ("nfev", "njev", "nlu"):
+            assert int(ref[key]) == int(sch[key]), key
+        np.savez_compressed(os.path.join(HERE, f"comp_fcn_{tag}.npz"), nz=n, ny=n, max_abs_vvel=0.1,
+                            horiz_mix_coeff=1000.0, y0=ref["y0"], fcn=ref["fcn"], nfev=ref["nfev"],
+                            njev=ref["njev"], nlu=ref["nlu"], schedule=sch["schedule"],
+                            nrejected=sch["nrejected"], nnewton=sch["nnewton"])
+        print("wrote comp_fcn", tag, "(solve_ivp with reference functions == oracle, bit for bit)")
+
+
 def main():
     _install_placeholders()
     sys.path.insert(0, REF)
+    if len(sys.argv) == 4 and sys.argv[1] == "large":     # large <n> <ref|sched|merge>
+        gen_comp_fcn_large(int(sys.argv[2]), sys.argv[3])
+        return
     if sys.argv[1:] == ["forced_file"]:      # only the fixtures of the file-driven forced options
         gen_forced_file_all()
         return

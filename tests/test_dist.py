@@ -32,3 +32,32 @@ def test_world_size_2_gloo(tmp_path):
     assert out[0]["iters"] == 3 and out[1]["iters"] == 3
     for o in out:
         assert o["resid"] < 0.2 * o["fcn_norm"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver calls it (no launcher, no WORLD_SIZE): the parent starts
+    the ranks itself and relays rank 0's JSON line (here the CPU-only launch check over gloo)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch_check": 2, "rank_sum": 3}
+
+
+def test_sharded_module_reductions_gloo(tmp_path):
+    """SURVEY.md section 8(e) level 2 on the CPU: a module's tracers on two ranks, inner products and
+    CGS-2 all-reduced over gloo (NumPy stand-in engines), against the unsharded numbers"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29534",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "shard"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = [json.load(open(tmp_path / f"shard{r}.json")) for r in range(2)]
+    assert out[0] == out[1]                       # every rank holds the same reduced numbers
+    assert out[0]["dot_err"] < 1e-14 and out[0]["h_err"] < 1e-12 and out[0]["ortho"] < 1e-14
+    assert out[0]["allreduces"] == 1 + 2 + 1     # dot, CGS-2 (two passes), final check
+    assert out[0]["gmres_resid_drop"] < 0.5 and out[0]["gmres_allreduces_per_iter"] <= 6.0

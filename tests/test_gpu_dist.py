@@ -38,13 +38,48 @@ def test_module_per_rank_matches_single_process(tmp_path):
         assert np.allclose(got["inc_norm"], want["inc_norm"], rtol=1e-9)
 
 
+def _check_two_rank_line(stdout, backend):
+    line = [ln for ln in stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0.0
+    assert out["config"]["parallelism"].endswith("x2") and out["config"]["collective_backend"] == backend
+    for key in ("roofline", "metric", "unit", "ms_per_step", "dtype", "end_to_end"):
+        assert key in out
+    assert "cpu_baseline" not in out and "ladder" not in out   # rank 0 of single-GPU runs only
+    # SURVEY.md section 8(e) level 2, measured in the same run: ONE module, tracer per rank
+    shard = out["shard_e2"]
+    assert shard["backend"] == backend and shard["ms_per_jvp"] > 0.0
+    assert shard["allreduces_per_jvp"] > 100            # every Radau norm is a collective
+    return out
+
+
 def test_bench_two_ranks():
     res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "26",
                    "--cpu-baseline-seconds", "0"], 29542)
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0.0
-    assert out["config"]["parallelism"].endswith("x2")
-    for key in ("roofline", "metric", "unit", "ms_per_step", "dtype"):
-        assert key in out
-    assert "cpu_baseline" not in out        # timed on rank 0 of single-GPU runs only
+    _check_two_rank_line(res.stdout, "gloo")
+
+
+def test_bench_starts_its_own_ranks_on_the_gpu_box():
+    """the driver's invocation: `python bench.py --gpus 2`, no launcher, no WORLD_SIZE"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="1", NK2D_BENCH_BACKEND="gloo")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup",
+                          "0", "--grid", "26", "--cpu-baseline-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    _check_two_rank_line(res.stdout, "gloo")
+
+
+def test_bench_two_ranks_rccl():
+    """the same over RCCL (backend nccl), one rank per GPU: needs two GPUs, skipped on the one-GPU box"""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL refuses two ranks on one GPU; this leg runs on multi-GPU nodes")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NK2D_BENCH_BACKEND")}
+    env.update(OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup",
+                          "0", "--grid", "52", "--cpu-baseline-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    _check_two_rank_line(res.stdout, "nccl")
