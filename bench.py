@@ -90,7 +90,7 @@ def cpu_oracle_year(grid_n, budget_s, attempts_hint=None):
             steps += 1
         wall = time.perf_counter() - t0
     attempts = steps + solver.stats.nrejected
-    finished = solver.t >= YEAR
+    finished = bool(solver.t >= YEAR)
     res = {"grid": grid_n, "full_year": finished, "wall_s": wall, "attempts": attempts,
            "nfev": solver.stats.nfev, "nlu": solver.stats.nlu}
     if finished:

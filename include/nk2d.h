@@ -255,8 +255,10 @@ int nk2d_gmres_solve(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, double rel_tol, int
 /* all n region-weighted dot products <w, basis[i]> in one launch and one read-back (the fused
    multi-dot of SURVEY.md section 8(e)); out [n][nreg] */
 int nk2d_multi_dot(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, double* out);
-/* w -= sum_i bcast(h[i]) basis[i] in one launch; h [n][nreg] (classical Gram-Schmidt update) */
-int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, const double* h);
+/* w -= sum_i bcast(h[i]) basis[i] in one launch; h [n][nreg] (classical Gram-Schmidt update).  fill: the
+   broadcast value where region_mask <= 0 -- 1.0 is the reference's (every modified Gram-Schmidt projection
+   subtracts basis[i] itself there); a re-orthogonalisation pass uses 0.0 so as not to subtract it twice */
+int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis, const double* h, double fill);
 
 /* Tracers of one module sharded over several contexts / GPUs (level 2): the
    tracers' Jacobian blocks are independent, but SciPy's Radau takes its decisions from norms over the

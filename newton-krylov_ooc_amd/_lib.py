@@ -130,7 +130,7 @@ SIGNATURES = {
     "nk2d_gmres_solve": (_ci, [_vp, _vp, _vp, _d, _i32, _i32, _vp, c_double_p, c_double_p, c_double_p,
                                c_double_p, c_int32_p]),
     "nk2d_multi_dot": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
-    "nk2d_multi_axpy": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
+    "nk2d_multi_axpy": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p, _d]),
     "nk2d_set_norm_hook": (_ci, [_vp, _vp, _vp, _d]),
     "nk2d_set_option": (_ci, [_vp, ctypes.c_char_p, _d]),
     "nk2d_sync": (_ci, [_vp]),

@@ -21,7 +21,9 @@
 
 namespace {
 
-__device__ __forceinline__ double bcast_r(const double* __restrict__ coef, int m) { return (m > 0) ? coef[m - 1] : 1.0; }
+__device__ __forceinline__ double bcast_r(const double* __restrict__ coef, int m, double fill) {
+    return (m > 0) ? coef[m - 1] : fill;
+}
 
 // part[(task * n + i) * nreg + r] = sum over the column's cells of region r+1 of wn * (w * v_i)
 template <int E>
@@ -55,11 +57,13 @@ __global__ void k_multi_dot(int ncol, int ny, int nreg, int n, const double* __r
     }
 }
 
-// w <- w - bcast(h_0) v_0 - bcast(h_1) v_1 - ...  (subtractions in index order)
+// w <- w - bcast(h_0) v_0 - bcast(h_1) v_1 - ...  (subtractions in index order); fill: value of the
+// broadcast coefficients where region_mask <= 0 (the reference's broadcast_region_vals fills 1.0,
+// tracer_module_state_base.py:502-515)
 template <int E>
 __global__ void k_multi_axpy(int ncol, int ny, int nreg, int n, double* __restrict__ w,
                              const double* const* __restrict__ vecs, const double* __restrict__ h,
-                             const int32_t* __restrict__ mask) {
+                             const int32_t* __restrict__ mask, double fill) {
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * NK2D_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (task >= ncol) return;
@@ -72,7 +76,7 @@ __global__ void k_multi_axpy(int ncol, int ny, int nreg, int n, double* __restri
     for (int i = 0; i < n; ++i) {
         load_col<E>(vecs[i], task, lane, vv);
 #pragma unroll
-        for (int e = 0; e < E; ++e) ww[e] = ww[e] - bcast_r(h + (size_t)i * nreg, mm[e]) * vv[e];
+        for (int e = 0; e < E; ++e) ww[e] = ww[e] - bcast_r(h + (size_t)i * nreg, mm[e], fill) * vv[e];
     }
     store_col<E>(w, task, lane, ww);
 }
@@ -194,7 +198,7 @@ extern "C" int nk2d_multi_dot(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec
     return 0;
 }
 
-extern "C" int nk2d_multi_axpy(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec* basis, const double* h) {
+extern "C" int nk2d_multi_axpy(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec* basis, const double* h, double fill) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     if (n < 1 || n > 512) return nk2d_fail(c, "nk2d_multi_axpy: n out of range");
     Scratch s;
@@ -203,7 +207,7 @@ extern "C" int nk2d_multi_axpy(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_ve
     const size_t nco = (size_t)n * c->nreg;
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_multi_axpy<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                               c->ncol, c->ny, c->nreg, n, (double*)w,
-                                              (const double* const*)(s.coef + nco), s.coef, c->MASK));
+                                              (const double* const*)(s.coef + nco), s.coef, c->MASK, fill));
     NK2D_CHECK(c, hipGetLastError());
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     return 0;

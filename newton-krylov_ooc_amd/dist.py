@@ -148,9 +148,11 @@ class ShardedVectorSpace:
         """orthogonalise w against the (orthonormal) basis in place: classical Gram-Schmidt, twice.
         Returns the projection coefficients (n, nreg) -- what modified Gram-Schmidt returns, to rounding."""
         h_tot = np.zeros((len(basis), self.eng.nreg))
-        for _ in range(2):
+        for sweep in range(2):
             h_val = self.comm.allreduce(self.eng.multi_dot(w, basis))
-            self.eng.multi_axpy(w, basis, h_val)
+            # cells outside every region: the reference's projections subtract each basis vector once there
+            # (region broadcast fills 1.0, tracer_module_state_base.py:502-515) -- the first pass does that
+            self.eng.multi_axpy(w, basis, h_val, fill=1.0 if sweep == 0 else 0.0)
             h_tot += h_val
         return h_tot
 

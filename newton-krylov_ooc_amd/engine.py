@@ -319,11 +319,12 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_multi_dot(self._ctx, w.ptr, len(basis), ptrs, _dp(out)))
         return out
 
-    def multi_axpy(self, w, basis, h):
-        """w -= sum_i bcast(h[i]) basis[i], in place, one launch"""
+    def multi_axpy(self, w, basis, h, fill=1.0):
+        """w -= sum_i bcast(h[i]) basis[i], in place, one launch; `fill` = broadcast value where the
+        region mask is <= 0 (1.0: the reference's, 0.0: leave those cells alone)"""
         h = np.ascontiguousarray(h, dtype=np.float64).reshape(len(basis), self.nreg)
         ptrs = (ctypes.c_void_p * len(basis))(*[v.ptr for v in basis])
-        self._chk(self._lib.nk2d_multi_axpy(self._ctx, w.ptr, len(basis), ptrs, _dp(h)))
+        self._chk(self._lib.nk2d_multi_axpy(self._ctx, w.ptr, len(basis), ptrs, _dp(h), float(fill)))
         return w
 
     def set_norm_hook(self, fcn, global_n):

@@ -34,16 +34,23 @@ class Regions:
         self.nreg = int(mask.max())
         flat_m = mask.reshape(-1)
         flat_w = weight.reshape(-1)
-        self.rows = []  # (indices, normalised weights) per region
+        # one CSR row per region: w / sum_region(w), column indices ascending (model_config.py:292-315)
+        import scipy.sparse
+
+        indices, indptr, data = [], [0], []
         for r in range(self.nreg):
             idx = np.nonzero(flat_m == r + 1)[0]
             raw = flat_w[idx]
             sum_r = 1.0 / sum(raw)
-            self.rows.append((idx, np.array([sum_r * val for val in raw])))
+            indices.extend(idx)
+            indptr.append(len(indices))
+            data.extend([sum_r * val for val in raw])
+        self.mean_matrix = scipy.sparse.csr_array((data, indices, indptr), shape=(self.nreg, flat_w.size))
 
     def mean_of(self, plane_flat):
-        """region_comp_mean_matrix.dot(plane): CSR row sums in index order"""
-        return np.array([np.dot(w, plane_flat[idx]) for idx, w in self.rows])
+        """region_comp_mean_matrix.dot(plane): the CSR mat-vec sums every row in index order, one term
+        after the other -- the association the reference's inner products have"""
+        return self.mean_matrix.dot(plane_flat)
 
     def bcast(self, vals, fill=1.0):
         res = np.full(self.mask.shape, fill)

@@ -107,7 +107,7 @@ class FakeEngine:
     def multi_dot(self, w, basis):
         return np.stack([self.dot(w, v) for v in basis])
 
-    def multi_axpy(self, w, basis, h):
+    def multi_axpy(self, w, basis, h, fill=1.0):
         for coef, v in zip(np.asarray(h), basis):
             w.arr -= coef[0] * v.arr
         return w

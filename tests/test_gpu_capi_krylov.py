@@ -197,3 +197,46 @@ def test_norm_hook_couples_two_single_tracer_engines():
     fx_id, stats_id, _ = whole.comp_fcn(whole.upload(y0))
     assert np.array_equal(whole.download(fx_id), whole.download(fx_free))
     whole.set_norm_hook(None, 0.0)
+
+
+def test_plugin_backend_on_the_device():
+    """the HIP side of the variant-B plugin (tests/ref_plugin/py_driver_2d_hip/_backend.py) without the reference
+    around it: what it hands the reference's comp_fcn in place of solve_ivp's result, and the preconditioner.
+    (The reference side of the same plugin runs under the real nk_driver in tests/test_ref_dropin.py.)"""
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_plugin"))
+    from py_driver_2d_hip import _backend
+
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    nz, ny = 26, 26
+    grid = Grid2d.default(nz, ny)
+    weight = np.outer(grid.depth.delta, grid.ypos.delta)
+    mask = np.ones((nz, ny), dtype=np.int32)
+    modelinfo = {"depth_axisname": "depth", "ypos_axisname": "ypos", "depth_units": "m", "ypos_units": "m",
+                 "max_abs_vvel": "0.1", "horiz_mix_coeff": "1000.0"}
+    ms_cls = types.SimpleNamespace(model_config_obj=types.SimpleNamespace(modelinfo=modelinfo),
+                                   depth=grid.depth, ypos=grid.ypos)
+    tm = types.SimpleNamespace(name="iage", _tracer_module_def={"tracers": {"iage": {}, "iage_slow_rest": {}}},
+                               get_grid_vars=lambda name: {"region_mask": mask, "grid_weight": weight})
+    backend = _backend.HipBackend(ms_cls)
+    col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    y0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2).copy()
+    year = 365.0 * 86400.0
+    eng = iage_engine(grid)
+    fx, _, _ = eng.comp_fcn(eng.upload(y0))
+    want = eng.download(fx)
+    t, y = backend.forward_year(tm, y0.reshape(-1), np.array([0.0, year]))
+    assert y.shape == (y0.size, 2) and np.array_equal(y[:, 0], y0.reshape(-1))
+    assert np.array_equal(y[:, 1], y0.reshape(-1) + want.reshape(-1))         # what `sol.y[:, -1]` is read from
+    t_eval = np.linspace(0.0, year, 61)
+    t, y = backend.forward_year(tm, y0.reshape(-1), t_eval)
+    assert y.shape == (y0.size, 61) and np.array_equal(t, t_eval)
+    assert np.allclose(y[:, -1] - y0.reshape(-1), want.reshape(-1), rtol=1e-12, atol=1e-15)
+    v = np.random.default_rng(1).standard_normal(y0.shape)
+    assert np.array_equal(backend.precond_apply(tm, v), eng.download(eng.precond_apply(eng.upload(v))))
+    with pytest.raises(NotImplementedError):
+        backend.engine(types.SimpleNamespace(name="phosphorus"))
