@@ -118,7 +118,8 @@ extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     const std::string key(name ? name : "");
     if (key == "device_ctl") {
-        if (value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: device_ctl must be 0, 1 or 2");
+        if (value != 0.0 && value != 1.0 && value != 2.0 && value != 3.0)
+            return nk2d_fail(c, "nk2d_set_option: device_ctl must be 0, 1, 2 or 3");
         c->device_ctl = (int)value;
         return 0;
     }
@@ -129,6 +130,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
+    if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "factor_fp32") {
         // the single precision copy is written by the next factorisation: drop the cached one
         c->factor_fp32 = value != 0.0;
@@ -442,6 +444,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->hSTAGE = nullptr;
     c->stage_elems = 0;
     c->precond = nullptr;
+    c->pc_valu = 0;
     c->st = nk2d_stats();
     c->prof_every = 0;
     c->hSNAP = nullptr;
@@ -460,6 +463,9 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->norm_hook_user = nullptr;
     c->global_n = 0.0;
     c->timer_ready = 0;
+    c->YR_PART = c->YR_OUT = c->hYR_OUT = c->YR_REC = nullptr;
+    c->YR_SYNC = nullptr;
+    c->YR_MTAB = nullptr;
     *out = c;  // returned even on failure so that nk2d_last_error can be read
     return create_impl(c, desc);
 }
@@ -485,6 +491,12 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->timer_ready) { (void)hipEventDestroy(c->timer_ev[0]); (void)hipEventDestroy(c->timer_ev[1]); }
+    if (c->YR_OUT) {
+        (void)hipFree(c->YR_PART); (void)hipFree(c->YR_OUT); (void)hipFree(c->YR_SYNC); (void)hipFree(c->YR_MTAB);
+        if (c->YR_REC) (void)hipFree(c->YR_REC);
+        (void)hipHostFree(c->hYR_OUT);
+        (void)hipEventDestroy(c->yr_ev[0]); (void)hipEventDestroy(c->yr_ev[1]);
+    }
     if (c->MASK) (void)hipFree(c->MASK);
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hPART) (void)hipHostFree(c->hPART);

@@ -122,6 +122,7 @@ struct nk2d_ctx {
     double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
+    int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
 
     // optional dense-output sampling of the running comp_fcn (history files)
     int hist_n, hist_next;
@@ -137,6 +138,14 @@ struct nk2d_ctx {
     nk2d_norm_hook_fn norm_hook;
     void* norm_hook_user;
     double global_n;
+    // persistent whole-year kernel (device_ctl 3, nk2d_kernels.hip): norm partials [2][ncol], result block,
+    // barrier counter + abort flag, sweeps-per-shift table, schedule record, timing events
+    double *YR_PART, *YR_OUT, *hYR_OUT, *YR_REC;
+    void* YR_SYNC;
+    int* YR_MTAB;
+    double yr_lin_tol;
+    int64_t yr_rec_cap;
+    hipEvent_t yr_ev[2];
     // generic event pair on the context's stream (nk2d_timer_begin / nk2d_timer_end)
     hipEvent_t timer_ev[2];
     int timer_ready;
@@ -295,17 +304,42 @@ __device__ __forceinline__ void shift_next(const double (&a)[E], double (&o)[E],
     for (int e = 0; e < E - 1; ++e) o[e] = a[e + 1];
 }
 
-template <int E>
+// Memory policy MP of the column accessors.  0: plain loads and stores -- one kernel launch per phase, the
+// launch boundary orders everything.  1: agent-coherent accesses (relaxed agent-scope atomics = `sc1` loads and
+// stores on gfx950: the load bypasses the CU's L1, the store is written through) for data that OTHER workgroups
+// of a persistent launch read or write between two grid barriers (k_year_persistent): an array accessed with
+// MP = 1 anywhere in such a launch must be accessed with MP = 1 everywhere in it.
+template <int MP>
+__device__ __forceinline__ double ld_mp(const double* p) {
+    if constexpr (MP == 1) {
+        const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        return __longlong_as_double((long long)bits);
+    } else {
+        return *p;
+    }
+}
+template <int MP>
+__device__ __forceinline__ void st_mp(double* p, double v) {
+    if constexpr (MP == 1) {
+        __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
+}
+
+template <int E, int MP = 0>
 __device__ __forceinline__ void load_col(const double* __restrict__ base, size_t col, int lane, double (&o)[E]) {
     const double* p = base + col * (size_t)(E * 64) + lane;
 #pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = p[e * 64];
+    for (int e = 0; e < E; ++e) o[e] = ld_mp<MP>(p + e * 64);
 }
-template <int E>
+template <int E, int MP = 0>
 __device__ __forceinline__ void store_col(double* __restrict__ base, size_t col, int lane, const double (&v)[E]) {
     double* p = base + col * (size_t)(E * 64) + lane;
 #pragma unroll
-    for (int e = 0; e < E; ++e) p[e * 64] = v[e];
+    for (int e = 0; e < E; ++e) st_mp<MP>(p + e * 64, v[e]);
 }
 
 // Tridiagonal solve of one column held by one wave (E consecutive rows per lane):
@@ -474,6 +508,8 @@ int nk2d_r_reduce_err(nk2d_ctx* c);
 int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8);
 int nk2d_r_ctl_snapshot(nk2d_ctx* c, int slot);
 int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8);
+int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double max_step, double n_total,
+                         double* record, int64_t record_cap, int64_t* record_n);
 // nk2d_radau.hip
 int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first);
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,

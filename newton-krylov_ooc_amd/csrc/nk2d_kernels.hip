@@ -7,6 +7,7 @@
 // horiz_mix.py:50-71, vert_mix.py:24-87, iage.py:22-41); fused multiply-adds are
 // written out explicitly only inside the tridiagonal solves.
 #include "nk2d_common.h"
+#include "nk2d_hostmath.h"
 
 #include <cmath>
 #include <cstring>
@@ -155,14 +156,7 @@ int nk2d_k_unpack_state(nk2d_ctx* c, const double* src, double* dst_dev) {
 // np.interp restated for the host (numpy/core/src/multiarray/compiled_base.c semantics)
 // ---------------------------------------------------------------------------------
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out) {
-    if (x > xp[n - 1]) { *out = fp[n - 1]; return 0; }
-    if (x < xp[0]) { *out = fp[0]; return 0; }
-    int j = 0;
-    while (j + 1 < n && xp[j + 1] <= x) ++j;  // xp[j] <= x < xp[j+1]
-    if (j == n - 1 || xp[j] == x) { *out = fp[j]; return 0; }
-    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-    *out = slope * (x - xp[j]) + fp[j];
-    return 0;
+    return nk2d_hm_interp(n, xp, fp, x, out);
 }
 
 // ---------------------------------------------------------------------------------
@@ -180,13 +174,7 @@ struct VmixArgs {
 // host: bracketing interval of x in the increasing knots xs[0..n) as scipy's interp1d picks it
 // (searchsorted, clipped to [1, n-1]: the end intervals extrapolate)
 static void forcing_bracket(int n, const double* xs, double x, int* lo, double* dx, double* den) {
-    int hi = 0;
-    while (hi < n && xs[hi] < x) ++hi;   // searchsorted(xs, x), side = "left"
-    if (hi < 1) hi = 1;
-    if (hi > n - 1) hi = n - 1;
-    *lo = hi - 1;
-    *dx = x - xs[hi - 1];
-    *den = xs[hi] - xs[hi - 1];
+    nk2d_hm_bracket(n, xs, x, lo, dx, den);
 }
 static void vmix_forcing_args(const nk2d_ctx* c, int nt, const double* times, VmixArgs& A) {
     for (int i = 0; i < 4; ++i) { A.srec[i] = A.rrec[i] = 0; A.sdx[i] = A.rdx[i] = 0.0; A.sden[i] = A.rden[i] = 1.0; }
@@ -206,13 +194,13 @@ __device__ __forceinline__ double ramp2(double x, double x0, double x1, double y
     return slope * (x - x0) + y0;
 }
 
-template <int E>
-__device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int task, int lane) {
-    const int ti = task / P.ny, j = task - ti * P.ny;
-    const double frac = A.frac[ti];
-    const double bld = A.bldmin + (P.BLDMAX[j] - A.bldmin) * frac;
-    const double x0 = bld - A.hw, x1 = bld + A.hw;
-    const double y0 = A.y0, y1 = A.y1;
+// vertical mixing coefficient of ypos column j at the time whose seasonal fraction is `frac`
+template <int E, int MP = 0>
+__device__ __forceinline__ void vmix_col(const DevP& P, double bldmin, double vy0, double vy1, double hw, double frac,
+                                         double* __restrict__ out, int j, int lane) {
+    const double bld = bldmin + (P.BLDMAX[j] - bldmin) * frac;
+    const double x0 = bld - hw, x1 = bld + hw;
+    const double y0 = vy0, y1 = vy1;
     const double slope = (y1 - y0) / (x1 - x0);
     double zm0[E], zm1[E], dm[E], dmr[E], wb[E], kv[E];
     load_col<E>(P.ZM0, 0, lane, zm0);
@@ -252,7 +240,13 @@ __device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int 
         }
         kv[e] = val;
     }
-    store_col<E>(A.out[ti], j, lane, kv);
+    store_col<E, MP>(out, j, lane, kv);
+}
+
+template <int E, int MP = 0>
+__device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int task, int lane) {
+    const int ti = task / P.ny, j = task - ti * P.ny;
+    vmix_col<E, MP>(P, A.bldmin, A.y0, A.y1, A.hw, A.frac[ti], A.out[ti], j, lane);
     // forcing fields of the same time (kind 2), linear in time between two records:
     // slope = (y_hi - y_lo) / (x_hi - x_lo), y = slope (x - x_lo) + y_lo  (scipy interp1d, utils.py:529-531)
     if (P.f_sms > 0) {
@@ -480,16 +474,16 @@ int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f) {
 // Jacobian planes (advection.py:111-173, horiz_mix.py:100-142, vert_mix.py:140-182)
 // up = d tend[k]/d c[k-1], dn = .../d c[k+1], south = .../d c[j-1], north = .../d c[j+1]
 // ---------------------------------------------------------------------------------
-template <int E>
-__global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict__ JL, double* __restrict__ JU,
-                      double* __restrict__ JS, double* __restrict__ JN, double* __restrict__ JC,
-                      const double* __restrict__ ylin, double* __restrict__ UPR) {
-    TASK_PROLOGUE(P.ny)
+template <int E, int MP = 0>
+__device__ __forceinline__ void jac_body(const DevP& P, const double* __restrict__ kvp, double* __restrict__ JL,
+                                         double* __restrict__ JU, double* __restrict__ JS, double* __restrict__ JN,
+                                         double* __restrict__ JC, const double* __restrict__ ylin,
+                                         double* __restrict__ UPR, int task, int lane) {
     const int j = task;
     ColCoef<E> cf;
     load_coef<E>(P, j, lane, cf);
     double kv[E], kvprev[E], up[E], dn[E], so[E], no[E], ce[E];
-    load_col<E>(kvp, j, lane, kv);
+    load_col<E, MP>(kvp, j, lane, kv);
     shift_prev<E>(kv, kvprev, lane, 0.0);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -512,11 +506,11 @@ __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict
         no[e] = a_n + h_n;
         ce[e] = (a_c + h_c) + v_c;
     }
-    store_col<E>(JL, j, lane, up);
-    store_col<E>(JU, j, lane, dn);
-    store_col<E>(JS, j, lane, so);
-    store_col<E>(JN, j, lane, no);
-    store_col<E>(JC, j, lane, ce);
+    store_col<E, MP>(JL, j, lane, up);
+    store_col<E, MP>(JU, j, lane, dn);
+    store_col<E, MP>(JS, j, lane, so);
+    store_col<E, MP>(JN, j, lane, no);
+    store_col<E, MP>(JC, j, lane, ce);
     if (ylin != nullptr && P.f_sms > 0) {
         // forced module, file source with a sink threshold: UPR = -d sms / d tracer at the linearisation state
         // and the time of the bundle (forced.py:188-202); zero without a threshold
@@ -543,6 +537,14 @@ __global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict
         }
         store_col<E>(UPR, j, lane, upr);
     }
+}
+
+template <int E>
+__global__ void k_jac(DevP P, const double* __restrict__ kvp, double* __restrict__ JL, double* __restrict__ JU,
+                      double* __restrict__ JS, double* __restrict__ JN, double* __restrict__ JC,
+                      const double* __restrict__ ylin, double* __restrict__ UPR) {
+    TASK_PROLOGUE(P.ny)
+    jac_body<E, 0>(P, kvp, JL, JU, JS, JN, JC, ylin, UPR, task, lane);
 }
 
 // ylin: linearisation state (used by the phosphorus module only)
@@ -631,11 +633,11 @@ __device__ __forceinline__ void line_offdiag(const DevP& P, int tr, int lane, co
 
 // real part of the diagonal of the column tridiagonal: shift - JC + module terms; identity rows
 // past the column end
-template <int E, int KIND>
+template <int E, int KIND, int MP = 0>
 __device__ __forceinline__ void line_diag(const DevP& P, const double* __restrict__ JC, int tr, int j, int lane,
                                           double shift_re, double (&dre)[E]) {
     double jc[E], upr[E], dzr[E];
-    load_col<E>(JC, j, lane, jc);
+    load_col<E, MP>(JC, j, lane, jc);
     if constexpr (KIND == 1) {
         load_col<E>(P.UPR, j, lane, upr);
         load_col<E>(P.DZR, 0, lane, dzr);
@@ -769,23 +771,21 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
     }
 }
 
-template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(A.ntasks)
+template <int E, int KIND, int MP = 0>
+__device__ __forceinline__ void sweep_body(const DevP& P, const SweepArgs& A, int task, int lane) {
     const int nvar = A.ntasks / P.ny, j = task / nvar, var = task - j * nvar;
     const bool is_c = var >= A.nreal / P.ny;
     const int tr = is_c ? var - A.nreal / P.ny : var;
     const int col = tr * P.ny + j;
     double jl[E], ju[E], a[E], cc[E];
-    load_col<E>(A.JL, j, lane, jl);
-    load_col<E>(A.JU, j, lane, ju);
+    load_col<E, MP>(A.JL, j, lane, jl);
+    load_col<E, MP>(A.JU, j, lane, ju);
     line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     const int cs_col = (j > 0) ? col - 1 : col, cn_col = (j < P.ny - 1) ? col + 1 : col;
     double js[E], jn[E], upr[E];
     if (!A.first) {
-        load_col<E>(A.JS, j, lane, js);
-        load_col<E>(A.JN, j, lane, jn);
+        load_col<E, MP>(A.JS, j, lane, js);
+        load_col<E, MP>(A.JN, j, lane, jn);
         if constexpr (KIND == 1) load_col<E>(P.UPR, j, lane, upr);
     }
     if (!is_c) {
@@ -795,8 +795,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
         load_tab<E>(A.fr_tab, col, lane, tab);
         if (!A.first) {
             double xs[E], xn[E];
-            load_col<E>(A.xr_old, cs_col, lane, xs);
-            load_col<E>(A.xr_old, cn_col, lane, xn);
+            load_col<E, MP>(A.xr_old, cs_col, lane, xs);
+            load_col<E, MP>(A.xr_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], r[e]));
             if constexpr (KIND == 1) phos_couple<E>(P, tr, j, lane, A.xr_old, upr, r);
@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
 #pragma unroll
         for (int e = 0; e < E; ++e) r[e] = ((lane * E + e) < P.nz) ? r[e] : 0.0;
         tridiag_apply<E, double>(a, cc, inv, tab, r, lane);
-        store_col<E>(A.xr_new, col, lane, r);
+        store_col<E, MP>(A.xr_new, col, lane, r);
     } else {
         cplx r[E], inv[E], tab[NK2D_TAB];
         double rr[E], ri[E], t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
@@ -820,12 +820,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
         for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
         if (!A.first) {
             double xs[E], xn[E];
-            load_col<E>(A.xcr_old, cs_col, lane, xs);
-            load_col<E>(A.xcr_old, cn_col, lane, xn);
+            load_col<E, MP>(A.xcr_old, cs_col, lane, xs);
+            load_col<E, MP>(A.xcr_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) rr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], rr[e]));
-            load_col<E>(A.xci_old, cs_col, lane, xs);
-            load_col<E>(A.xci_old, cn_col, lane, xn);
+            load_col<E, MP>(A.xci_old, cs_col, lane, xs);
+            load_col<E, MP>(A.xci_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) ri[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], ri[e]));
             if constexpr (KIND == 1) {
@@ -841,9 +841,16 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
         tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
 #pragma unroll
         for (int e = 0; e < E; ++e) { rr[e] = r[e].re; ri[e] = r[e].im; }
-        store_col<E>(A.xcr_new, col, lane, rr);
-        store_col<E>(A.xci_new, col, lane, ri);
+        store_col<E, MP>(A.xcr_new, col, lane, rr);
+        store_col<E, MP>(A.xci_new, col, lane, ri);
     }
+}
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(A.ntasks)
+    sweep_body<E, KIND, 0>(P, A, task, lane);
 }
 
 static void fill_factor_args(const nk2d_ctx* c, SweepArgs& A) {
@@ -968,15 +975,7 @@ __global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, 
 // binary tree), so that the host- and the device-controlled integrators see bit-identical norms.
 int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part) {
     if (part == nullptr) part = c->hPART;
-    double sh[NK2D_BLOCK];
-    for (int t = 0; t < NK2D_BLOCK; ++t) {
-        double acc = 0.0;
-        for (int i = t; i < ntasks; i += NK2D_BLOCK) acc += part[i];
-        sh[t] = acc;
-    }
-    for (int o = NK2D_BLOCK / 2; o > 0; o >>= 1)
-        for (int t = 0; t < o; ++t) sh[t] += sh[t + o];
-    *out = sh[0];
+    *out = nk2d_hm_part_sum(part, ntasks, NK2D_BLOCK);
     return 0;
 }
 
@@ -1115,7 +1114,7 @@ struct PredictArgs {
     double x0, x1, x2;
 };
 
-template <int E>
+template <int E, int MP = 0>
 __device__ __forceinline__ void predict_body(const PredictArgs& A, int task, int lane) {
     const double* __restrict__ y = A.y;
     const double* __restrict__ yold = A.yold;
@@ -1125,11 +1124,11 @@ __device__ __forceinline__ void predict_body(const PredictArgs& A, int task, int
     const size_t nv = A.nv;
     const double x0 = A.x0, x1 = A.x1, x2 = A.x2;
     double yy[E], yo[E], z0[E], z1[E], z2[E];
-    load_col<E>(y, task, lane, yy);
-    load_col<E>(yold, task, lane, yo);
-    load_col<E>(zp, task, lane, z0);
-    load_col<E>(zp + nv, task, lane, z1);
-    load_col<E>(zp + 2 * nv, task, lane, z2);
+    load_col<E, MP>(y, task, lane, yy);
+    load_col<E, MP>(yold, task, lane, yo);
+    load_col<E, MP>(zp, task, lane, z0);
+    load_col<E, MP>(zp + nv, task, lane, z1);
+    load_col<E, MP>(zp + 2 * nv, task, lane, z2);
     const double xs[3] = {x0, x1, x2};
     double o[3][E];
 #pragma unroll
@@ -1147,7 +1146,7 @@ __device__ __forceinline__ void predict_body(const PredictArgs& A, int task, int
     }
     double wv[E];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) store_col<E>(z + i * nv, task, lane, o[i]);
+    for (int i = 0; i < 3; ++i) store_col<E, MP>(z + i * nv, task, lane, o[i]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -1212,10 +1211,8 @@ struct FusedArgs {
 // STAGE = 0: instantiation for launches without the stage part.  For the phosphorus module the
 // full kernel needs more registers than two waves per SIMD leave while its 3 ny columns are more
 // waves than the chip has SIMDs; the stage-less instantiation fits and runs in one round.
-template <int E, int KIND, int FACTOR, int STAGE>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(P.ncol)
+template <int E, int KIND, int FACTOR, int STAGE, int MP = 0>
+__device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
@@ -1223,18 +1220,18 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         ColCoef<E> cf;
         load_coef<E>(P, j, lane, cf);
         double y0[E], ys[E], yn[E];
-        load_col<E>(A.st.y, task, lane, y0);
-        load_col<E>(A.st.y, cs_col, lane, ys);
-        load_col<E>(A.st.y, cn_col, lane, yn);
+        load_col<E, MP>(A.st.y, task, lane, y0);
+        load_col<E, MP>(A.st.y, cs_col, lane, ys);
+        load_col<E, MP>(A.st.y, cn_col, lane, yn);
 #pragma unroll
         for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             double c[E], cs[E], cn[E], kv[E], f[E];
-            load_col<E>(A.st.z + i * A.st.nv, task, lane, c);
-            load_col<E>(A.st.z + i * A.st.nv, cs_col, lane, cs);
-            load_col<E>(A.st.z + i * A.st.nv, cn_col, lane, cn);
-            load_col<E>(A.st.kv[i], j, lane, kv);
+            load_col<E, MP>(A.st.z + i * A.st.nv, task, lane, c);
+            load_col<E, MP>(A.st.z + i * A.st.nv, cs_col, lane, cs);
+            load_col<E, MP>(A.st.z + i * A.st.nv, cn_col, lane, cn);
+            load_col<E, MP>(A.st.kv[i], j, lane, kv);
 #pragma unroll
             for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
             tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
@@ -1279,24 +1276,24 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     double a[E], cc[E];
     {
         double jl[E], ju[E];
-        load_col<E>(A.sw.JL, j, lane, jl);
-        load_col<E>(A.sw.JU, j, lane, ju);
+        load_col<E, MP>(A.sw.JL, j, lane, jl);
+        load_col<E, MP>(A.sw.JU, j, lane, ju);
         line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     }
     if (!A.sw.first) {
         double js[E], jn[E], xs[E], xn[E];
-        load_col<E>(A.sw.JS, j, lane, js);
-        load_col<E>(A.sw.JN, j, lane, jn);
-        load_col<E>(A.sw.xr_old, cs_col, lane, xs);
-        load_col<E>(A.sw.xr_old, cn_col, lane, xn);
+        load_col<E, MP>(A.sw.JS, j, lane, js);
+        load_col<E, MP>(A.sw.JN, j, lane, jn);
+        load_col<E, MP>(A.sw.xr_old, cs_col, lane, xs);
+        load_col<E, MP>(A.sw.xr_old, cn_col, lane, xn);
 #pragma unroll
         for (int e = 0; e < E; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e]));
-        load_col<E>(A.sw.xcr_old, cs_col, lane, xs);
-        load_col<E>(A.sw.xcr_old, cn_col, lane, xn);
+        load_col<E, MP>(A.sw.xcr_old, cs_col, lane, xs);
+        load_col<E, MP>(A.sw.xcr_old, cn_col, lane, xn);
 #pragma unroll
         for (int e = 0; e < E; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e]));
-        load_col<E>(A.sw.xci_old, cs_col, lane, xs);
-        load_col<E>(A.sw.xci_old, cn_col, lane, xn);
+        load_col<E, MP>(A.sw.xci_old, cs_col, lane, xs);
+        load_col<E, MP>(A.sw.xci_old, cn_col, lane, xn);
 #pragma unroll
         for (int e = 0; e < E; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
         if constexpr (KIND == 1) {
@@ -1313,7 +1310,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         double inv[E], tab[NK2D_TAB];
         if constexpr (FACTOR) {
             double dre[E];
-            line_diag<E, KIND>(P, A.sw.JC, tr, j, lane, A.sw.cre, dre);
+            line_diag<E, KIND, MP>(P, A.sw.JC, tr, j, lane, A.sw.cre, dre);
             tridiag_factor<E, double>(a, cc, dre, inv, tab, lane);
             store_col<E>(A.sw.fr_inv, task, lane, inv);
             double* p = A.sw.fr_tab + (size_t)task * (NK2D_TAB * 64) + lane;
@@ -1340,7 +1337,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         if constexpr (FACTOR) {
             double dre[E];
             cplx d[E];
-            line_diag<E, KIND>(P, A.sw.JC, tr, j, lane, A.sw.ccr, dre);
+            line_diag<E, KIND, MP>(P, A.sw.JC, tr, j, lane, A.sw.ccr, dre);
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = c_make(dre[e], ((lane * E + e) < P.nz) ? A.sw.cci : 0.0);
             tridiag_factor<E, cplx>(a, cc, d, inv, tab, lane);
@@ -1389,25 +1386,25 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     }
     if (!A.do_stage && A.delta) {  // correction of the first sweep's solution
         double x1[E];
-        load_col<E>(A.sw.xr_old, task, lane, x1);
+        load_col<E, MP>(A.sw.xr_old, task, lane, x1);
 #pragma unroll
         for (int e = 0; e < E; ++e) fr[e] = x1[e] + fr[e];
-        load_col<E>(A.sw.xcr_old, task, lane, x1);
+        load_col<E, MP>(A.sw.xcr_old, task, lane, x1);
 #pragma unroll
         for (int e = 0; e < E; ++e) fcr[e] = x1[e] + fcr[e];
-        load_col<E>(A.sw.xci_old, task, lane, x1);
+        load_col<E, MP>(A.sw.xci_old, task, lane, x1);
 #pragma unroll
         for (int e = 0; e < E; ++e) fci[e] = x1[e] + fci[e];
     }
     if (!A.do_update) {
-        store_col<E>(A.sw.xr_new, task, lane, fr);
-        store_col<E>(A.sw.xcr_new, task, lane, fcr);
-        store_col<E>(A.sw.xci_new, task, lane, fci);
+        store_col<E, MP>(A.sw.xr_new, task, lane, fr);
+        store_col<E, MP>(A.sw.xcr_new, task, lane, fcr);
+        store_col<E, MP>(A.sw.xci_new, task, lane, fci);
         return;
     }
     // dW = (fr, fcr, fci): norm partial, W += dW, Z = T W
     double yy[E], w0[E], w1[E], w2[E];
-    load_col<E>(A.st.y, task, lane, yy);
+    load_col<E, MP>(A.st.y, task, lane, yy);
     load_col<E>(A.st.w, task, lane, w0);
     load_col<E>(A.st.w + A.st.nv, task, lane, w1);
     load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
@@ -1422,7 +1419,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
         w2[e] = w2[e] + fci[e];
     }
     acc = wave_sum(acc);
-    if (lane == 0) A.part[task] = acc;
+    if (lane == 0) st_mp<MP>(A.part + task, acc);
     double* wout = const_cast<double*>(A.st.w);
     double* zout = const_cast<double*>(A.st.z);
     store_col<E>(wout, task, lane, w0);
@@ -1433,27 +1430,40 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int e = 0; e < E; ++e) zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
-        store_col<E>(zout + r * A.st.nv, task, lane, zz);
+        store_col<E, MP>(zout + r * A.st.nv, task, lane, zz);
     }
 }
 
+template <int E, int KIND, int FACTOR, int STAGE>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(P.ncol)
+    newton_fused_body<E, KIND, FACTOR, STAGE, 0>(P, A, task, lane);
+}
+
 // error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
-template <int E>
-__global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
-                          double* __restrict__ out, const int* __restrict__ guard) {
-    GUARD_RETURN(guard)
-    TASK_PROLOGUE(ncol)
+template <int E, int MP = 0>
+__device__ __forceinline__ void err_rhs_body(const double* __restrict__ f, const double* __restrict__ z, size_t nv,
+                                             double h, double* __restrict__ out, int task, int lane) {
     double ff[E], z0[E], z1[E], z2[E];
     load_col<E>(f, task, lane, ff);
-    load_col<E>(z, task, lane, z0);
-    load_col<E>(z + nv, task, lane, z1);
-    load_col<E>(z + 2 * nv, task, lane, z2);
+    load_col<E, MP>(z, task, lane, z0);
+    load_col<E, MP>(z + nv, task, lane, z1);
+    load_col<E, MP>(z + 2 * nv, task, lane, z2);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / h;
         ff[e] = ff[e] + ze;
     }
     store_col<E>(out, task, lane, ff);
+}
+
+template <int E>
+__global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
+                          double* __restrict__ out, const int* __restrict__ guard) {
+    GUARD_RETURN(guard)
+    TASK_PROLOGUE(ncol)
+    err_rhs_body<E, 0>(f, z, nv, h, out, task, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1474,24 +1484,22 @@ struct ErrArgs {
     int last;              // this launch ends the solve
 };
 
-template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(P.ncol)
+template <int E, int KIND, int MP = 0>
+__device__ __forceinline__ void err_fused_body(const DevP& P, const ErrArgs& A, int task, int lane) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     double r[E], x1[E], a[E], cc[E];
     {
         double jl[E], ju[E];
-        load_col<E>(A.sw.JL, j, lane, jl);
-        load_col<E>(A.sw.JU, j, lane, ju);
+        load_col<E, MP>(A.sw.JL, j, lane, jl);
+        load_col<E, MP>(A.sw.JU, j, lane, ju);
         line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     }
     if (A.stage == 0) {
         double z0[E], z1[E], z2[E];
         load_col<E>(A.f, task, lane, r);
-        load_col<E>(A.z, task, lane, z0);
-        load_col<E>(A.z + A.nv, task, lane, z1);
-        load_col<E>(A.z + 2 * A.nv, task, lane, z2);
+        load_col<E, MP>(A.z, task, lane, z0);
+        load_col<E, MP>(A.z + A.nv, task, lane, z1);
+        load_col<E, MP>(A.z + 2 * A.nv, task, lane, z2);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / A.h;
@@ -1500,11 +1508,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
     } else {
         const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
         double js[E], jn[E], xs[E], xn[E];
-        load_col<E>(A.sw.JS, j, lane, js);
-        load_col<E>(A.sw.JN, j, lane, jn);
-        load_col<E>(A.sw.xr_old, cs_col, lane, xs);
-        load_col<E>(A.sw.xr_old, cn_col, lane, xn);
-        load_col<E>(A.sw.xr_old, task, lane, x1);
+        load_col<E, MP>(A.sw.JS, j, lane, js);
+        load_col<E, MP>(A.sw.JN, j, lane, jn);
+        load_col<E, MP>(A.sw.xr_old, cs_col, lane, xs);
+        load_col<E, MP>(A.sw.xr_old, cn_col, lane, xn);
+        load_col<E, MP>(A.sw.xr_old, task, lane, x1);
 #pragma unroll
         for (int e = 0; e < E; ++e) r[e] = __builtin_fma(jn[e], xn[e], js[e] * xs[e]);
         if constexpr (KIND == 1) {
@@ -1525,11 +1533,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
 #pragma unroll
         for (int e = 0; e < E; ++e) r[e] = x1[e] + r[e];
     }
-    store_col<E>(A.sw.xr_new, task, lane, r);
+    store_col<E, MP>(A.sw.xr_new, task, lane, r);
     if (!A.last) return;
     double yy[E], z2[E];
-    load_col<E>(A.y, task, lane, yy);
-    load_col<E>(A.z + 2 * A.nv, task, lane, z2);
+    load_col<E, MP>(A.y, task, lane, yy);
+    load_col<E, MP>(A.z + 2 * A.nv, task, lane, z2);
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1539,33 +1547,39 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
         acc += q * q;
     }
     acc = wave_sum(acc);
-    if (lane == 0) A.part[task] = acc;
+    if (lane == 0) st_mp<MP>(A.part + task, acc);
+}
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(P.ncol)
+    err_fused_body<E, KIND, 0>(P, A, task, lane);
 }
 
 // filtered error estimate right-hand side  fun(t, y + error) + Z^T E / h  (radau.py:485-487)
-template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK)
-    k_err_rhs2(DevP P, const double* __restrict__ y, const double* __restrict__ err, const double* __restrict__ kvp,
-               const double* __restrict__ z, size_t nv, double h, double* __restrict__ out) {
-    TASK_PROLOGUE(P.ncol)
+template <int E, int KIND, int MP = 0>
+__device__ __forceinline__ void err_rhs2_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ err,
+                                              const double* __restrict__ kvp, const double* __restrict__ z, size_t nv,
+                                              double h, double* __restrict__ out, int task, int lane) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     ColCoef<E> cf;
     load_coef<E>(P, j, lane, cf);
     double c[E], cs[E], cn[E], t0[E], kv[E], ff[E];
-    load_col<E>(y, task, lane, c);
-    load_col<E>(err, task, lane, t0);
+    load_col<E, MP>(y, task, lane, c);
+    load_col<E, MP>(err, task, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
-    load_col<E>(y, cs_col, lane, cs);
-    load_col<E>(err, cs_col, lane, t0);
+    load_col<E, MP>(y, cs_col, lane, cs);
+    load_col<E, MP>(err, cs_col, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) cs[e] = cs[e] + t0[e];
-    load_col<E>(y, cn_col, lane, cn);
-    load_col<E>(err, cn_col, lane, t0);
+    load_col<E, MP>(y, cn_col, lane, cn);
+    load_col<E, MP>(err, cn_col, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
-    load_col<E>(kvp, j, lane, kv);
+    load_col<E, MP>(kvp, j, lane, kv);
     tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, ff);
     if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, ff);
     if constexpr (KIND == 1) {
@@ -1576,9 +1590,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
         phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, ff);
     }
     double z0[E], z1[E], z2[E];
-    load_col<E>(z, task, lane, z0);
-    load_col<E>(z + nv, task, lane, z1);
-    load_col<E>(z + 2 * nv, task, lane, z2);
+    load_col<E, MP>(z, task, lane, z0);
+    load_col<E, MP>(z + nv, task, lane, z1);
+    load_col<E, MP>(z + 2 * nv, task, lane, z2);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double ze = ((z0[e] * cE[0] + z1[e] * cE[1]) + z2[e] * cE[2]) / h;
@@ -1587,32 +1601,39 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     store_col<E>(out, task, lane, ff);
 }
 
-// accepted step: y_new = y + Z2 and f_new = fun(t_new, y_new) in one pass (radau.py:509-521); the
-// lateral neighbours' y_new are formed on the fly, each wave stores its own column
 template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK)
-    k_commit_tend(DevP P, const double* __restrict__ y, const double* __restrict__ z2, const double* __restrict__ kvp,
-                  double* __restrict__ ynew, double* __restrict__ f) {
+    k_err_rhs2(DevP P, const double* __restrict__ y, const double* __restrict__ err, const double* __restrict__ kvp,
+               const double* __restrict__ z, size_t nv, double h, double* __restrict__ out) {
     TASK_PROLOGUE(P.ncol)
+    err_rhs2_body<E, KIND, 0>(P, y, err, kvp, z, nv, h, out, task, lane);
+}
+
+// accepted step: y_new = y + Z2 and f_new = fun(t_new, y_new) in one pass (radau.py:509-521); the
+// lateral neighbours' y_new are formed on the fly, each wave stores its own column
+template <int E, int KIND, int MP = 0>
+__device__ __forceinline__ void commit_tend_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ z2,
+                                                 const double* __restrict__ kvp, double* __restrict__ ynew,
+                                                 double* __restrict__ f, int task, int lane) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     ColCoef<E> cf;
     load_coef<E>(P, j, lane, cf);
     double c[E], cs[E], cn[E], t0[E], kv[E], ff[E];
-    load_col<E>(y, task, lane, c);
-    load_col<E>(z2, task, lane, t0);
+    load_col<E, MP>(y, task, lane, c);
+    load_col<E, MP>(z2, task, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
-    store_col<E>(ynew, task, lane, c);
-    load_col<E>(y, cs_col, lane, cs);
-    load_col<E>(z2, cs_col, lane, t0);
+    store_col<E, MP>(ynew, task, lane, c);
+    load_col<E, MP>(y, cs_col, lane, cs);
+    load_col<E, MP>(z2, cs_col, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) cs[e] = cs[e] + t0[e];
-    load_col<E>(y, cn_col, lane, cn);
-    load_col<E>(z2, cn_col, lane, t0);
+    load_col<E, MP>(y, cn_col, lane, cn);
+    load_col<E, MP>(z2, cn_col, lane, t0);
 #pragma unroll
     for (int e = 0; e < E; ++e) cn[e] = cn[e] + t0[e];
-    load_col<E>(kvp, j, lane, kv);
+    load_col<E, MP>(kvp, j, lane, kv);
     tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, ff);
     if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, ff);
     if constexpr (KIND == 1) {
@@ -1625,16 +1646,22 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     store_col<E>(f, task, lane, ff);
 }
 
-// sum((err / (atol + max(|y|, |y + Z2|) rtol))^2)  (radau.py:480-481)
-template <int E>
-__global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
-                           const double* __restrict__ err, double* __restrict__ part) {
-    GUARD_RETURN(P.guard)
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK)
+    k_commit_tend(DevP P, const double* __restrict__ y, const double* __restrict__ z2, const double* __restrict__ kvp,
+                  double* __restrict__ ynew, double* __restrict__ f) {
     TASK_PROLOGUE(P.ncol)
+    commit_tend_body<E, KIND, 0>(P, y, z2, kvp, ynew, f, task, lane);
+}
+
+// sum((err / (atol + max(|y|, |y + Z2|) rtol))^2)  (radau.py:480-481)
+template <int E, int MP = 0>
+__device__ __forceinline__ void err_norm_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ z2p,
+                                              const double* __restrict__ err, double* __restrict__ part, int task, int lane) {
     double yy[E], z2[E], er[E];
-    load_col<E>(y, task, lane, yy);
-    load_col<E>(z2p, task, lane, z2);
-    load_col<E>(err, task, lane, er);
+    load_col<E, MP>(y, task, lane, yy);
+    load_col<E, MP>(z2p, task, lane, z2);
+    load_col<E, MP>(err, task, lane, er);
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1644,7 +1671,15 @@ __global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* _
         acc += a * a;
     }
     acc = wave_sum(acc);
-    if (lane == 0) part[task] = acc;
+    if (lane == 0) st_mp<MP>(part + task, acc);
+}
+
+template <int E>
+__global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
+                           const double* __restrict__ err, double* __restrict__ part) {
+    GUARD_RETURN(P.guard)
+    TASK_PROLOGUE(P.ncol)
+    err_norm_body<E, 0>(P, y, z2p, err, part, task, lane);
 }
 
 // sum(((ca a + cb b) / (atol + |ys| rtol))^2), used by the initial-step heuristic
@@ -1946,5 +1981,567 @@ int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out) {
                                                c->ncol, c->ny, c->YOLD, c->ZP, c->nv, y0, c->MASK, out));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
+    return 0;
+}
+
+// =================================================================================================
+// The whole forward year in ONE launch (nk2d_set_option "device_ctl" 3).
+//
+// The host-controlled integrator (nk2d_radau.hip) reads one scalar per simplified-Newton iteration and
+// launches 60 000 small kernels per 416 x 416 year; at 26 x 26 ... 208 x 208 the year is nothing but
+// launch gaps and host round trips.  Here every wave owns its (tracer, ypos) column for the WHOLE year:
+// the phases of the Radau step (the same device functions the per-phase kernels call, in the same order)
+// are separated by grid-wide barriers, and SciPy's controller (radau.py:399-539) runs redundantly in every
+// wave -- all waves read the same norm partials, reduce them in the association of nk2d_part_sum and
+// take identical decisions, so no decision is ever broadcast and the host is not involved until y(T).
+//
+// Visibility between workgroups follows the hand-off the guides validate for gfx950 (MI355X_MICROARCH.md,
+// inter-workgroup visibility, table row 1): every array another workgroup may read is stored write-through
+// and loaded L1-bypassing (MP = 1 accessors: relaxed agent-scope atomics = sc1); before a barrier every
+// wave drains its stores (s_waitcnt vmcnt(0)), the workgroup joins, ONE lane adds to the arrival counter
+// (agent scope) and polls it; the others wait at the workgroup barrier behind that lane.  Arrays only ever
+// touched by their owning wave (W, right-hand sides, the line factorisation, F) stay plain.  Every spin is
+// bounded; a timeout raises a grid-wide abort flag that every wave sees at its next barrier.
+// The grid is launched cooperatively, so it is rejected -- not deadlocked -- when it is not fully resident.
+// =================================================================================================
+#define NK2D_SPIN_LIMIT 4000000
+
+struct YearArgs {
+    double *Y, *YOLD, *F, *Z, *ZP, *W;
+    double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP;
+    double* KV[4];
+    SweepArgs fac;             // Jacobian planes + factor pointers (the other members are set per phase)
+    double* PART;              // [2][ncol]: norm partials, the two halves alternate from one reduction to the next
+    double t0, t1, h_abs0, max_step, newton_tol, n_total, growth_cap;
+    int jac_fresh, f32;
+    double bld_t[4], bld_f[4], bldmin, vy0, vy1, hw;
+    const int* m_tab;          // sweeps for the shift bucket k (host: nk2d_sweeps_for), n_tab entries
+    int n_tab;
+    double rho_c0, rho_dlog;
+    unsigned* arrive;          // grid barrier arrival counter (zeroed by the host)
+    int* abort_flag;
+    double* out;               // [32]: status, t, counters, swap parities, bytes
+    double* record;            // accepted steps [cap][NK2D_SCHED_WIDTH] or null
+    long long record_cap;
+};
+
+struct GridBarrier {
+    unsigned* arrive;
+    int* abort_flag;
+    unsigned nwg, epoch;
+    int* lds_ok;
+    __device__ __forceinline__ bool sync() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned target = (epoch + 1u) * nwg;
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int good = 1;
+            long long spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > NK2D_SPIN_LIMIT ||
+                    __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *lds_ok = good;
+        }
+        __syncthreads();
+        ++epoch;
+        return *lds_ok != 0;
+    }
+};
+
+// sum of the ncol per-column partials in the association of nk2d_part_sum / k_reduce (256 strided
+// accumulators, then a binary tree), identical in every wave
+__device__ __forceinline__ double year_part_sum(const double* part, int n, int lane) {
+    double acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc[q] = 0.0;
+        for (int i = lane + 64 * q; i < n; i += NK2D_BLOCK) acc[q] += ld_mp<1>(part + i);
+    }
+    acc[0] += acc[2];   // sh[t] += sh[t + 128]
+    acc[1] += acc[3];
+    double v = acc[0] + acc[1];   // sh[t] += sh[t + 64]
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+__device__ __forceinline__ double year_interp4(const double* xp, const double* fp, double x) {
+    if (x > xp[3]) return fp[3];
+    if (x < xp[0]) return fp[0];
+    int j = 0;
+    while (j + 1 < 4 && xp[j + 1] <= x) ++j;
+    if (j == 3 || xp[j] == x) return fp[j];
+    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    return slope * (x - xp[j]) + fp[j];
+}
+
+__device__ __forceinline__ int year_sweeps_for(const YearArgs& A, double c_real) {
+    if (A.n_tab <= 0) return 1;
+    const double pos = log10(c_real / A.rho_c0) / A.rho_dlog;
+    int k = (int)floor(pos);
+    if (k < 0) return 400;
+    if (k >= A.n_tab) k = A.n_tab - 1;
+    return A.m_tab[k];
+}
+
+__device__ __forceinline__ double year_predict_factor(double h_abs, bool has_h_old, double h_abs_old, double err,
+                                                      bool has_err_old, double err_old) {
+    double mult = 1.0;
+    if (has_err_old && has_h_old && err != 0.0) mult = h_abs / h_abs_old * pow(err_old / err, 0.25);
+    return fmin(1.0, mult) * pow(err, -0.25);
+}
+
+// values every lane of every wave holds identically: tell the compiler (scalar registers, uniform branches)
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni_b(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ double uni_d(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs A) {
+    __shared__ int lds_ok;
+    const int lane = threadIdx.x & 63;
+    const int wave = uni_i((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    const bool col_wave = wave < P.ncol;             // this wave owns column `wave` for the whole year
+    GridBarrier bar{A.arrive, A.abort_flag, gridDim.x, 0u, &lds_ok};
+    const double RC0 = 0.15505102572168222, RC1 = 0.6449489742783178, RC2 = 1.0;
+    const double MU_REAL = 3.637834252744496, MU_CR = 2.6810828736277523, MU_CI = -3.050430199247411;
+    const int NEWTON_MAXITER = 6;
+    const size_t nv = (size_t)P.ncol * (E * 64);
+
+    // buffers that swap roles: parities, the pointers are selected where they are used
+    int swapY = 0, swapZ = 0, swapKV = 0;
+#define YR_Y (swapY ? A.YOLD : A.Y)
+#define YR_YOLD (swapY ? A.Y : A.YOLD)
+#define YR_Z (swapZ ? A.ZP : A.Z)
+#define YR_ZP (swapZ ? A.Z : A.ZP)
+#define YR_KV2 (swapKV ? A.KV[3] : A.KV[2])
+#define YR_KV3 (swapKV ? A.KV[2] : A.KV[3])
+    // controller state (identical in every wave)
+    double t = A.t0, h_abs_s = A.h_abs0, h_abs_old_s = 0.0, err_old_s = 0.0;
+    bool has_old_h = false, has_old_err = false, current_jac = true, have_lu = false, have_dense = false;
+    double h_lu = 0.0, t_jac = A.t0, dense_t_old = 0.0, dense_h = 0.0;
+    int m_real = 1, m_cplx = 1;
+    bool factor_pending = false;
+    double lu_cre = 0.0, lu_ccr = 0.0, lu_cci = 0.0;
+    int nfev = 0, njev = 0, nlu = 0, nsteps = 0, nrejected = 0, nnewton = 0, nsolve = 0, nsweeps = 0, nrec = 0;
+    double words = 0.0;
+    int status = 0;     // 0 ok, 1 barrier timeout, 2 non-finite step, 3 step too small
+    // Norm partials alternate between two buffers: the waves still summing reduction n must not see the
+    // partials of reduction n + 1, which a faster wave may already write (a single phase can lie between them)
+    unsigned pev = 0;
+#define YEAR_PART() (A.PART + (size_t)(pev & 1u) * P.ncol)
+#define YEAR_SYNC() \
+    if (!bar.sync()) { status = 1; goto finish; }
+    const double Pc = (double)P.nz * P.ny, Ntot = Pc * P.tc;
+
+    // Jacobian planes from the vertical mixing plane kv (tasks spread over all waves)
+#define YEAR_JAC(kvp)                                                                                                   \
+    for (int task = wave; task < P.ny; task += nwaves)                                                                  \
+        jac_body<E, 1>(P, kvp, const_cast<double*>(A.fac.JL), const_cast<double*>(A.fac.JU), const_cast<double*>(A.fac.JS), \
+                       const_cast<double*>(A.fac.JN), const_cast<double*>(A.fac.JC), nullptr, nullptr, task, lane);
+
+    while (t < A.t1) {
+        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        double h_abs, h_abs_old = 0.0, err_old = 0.0;
+        bool has_h_old, has_err_old;
+        if (h_abs_s > A.max_step) { h_abs = A.max_step; has_h_old = has_err_old = false; }
+        else if (h_abs_s < min_step) { h_abs = min_step; has_h_old = has_err_old = false; }
+        else { h_abs = h_abs_s; h_abs_old = h_abs_old_s; err_old = err_old_s; has_h_old = has_old_h; has_err_old = has_old_err; }
+        if (A.jac_fresh && !current_jac) {
+            YEAR_JAC(YR_KV3)     // KV3 holds the plane at the current t
+            YEAR_SYNC()
+            t_jac = t; ++njev; current_jac = true; have_lu = false;
+        }
+        bool rejected = false, accepted = false, newton_failed = false;
+        double h = 0.0, t_new = 0.0, err = 0.0, safety = 0.0, rate = 0.0;
+        bool have_rate = false;
+        int n_iter = 0;
+        while (!accepted) {
+            if (uni_b(!isfinite(h_abs))) { status = 2; goto finish; }
+            if (uni_b(h_abs < min_step)) { status = 3; goto finish; }
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - A.t1 > 0) t_new = A.t1;
+            h = uni_d(t_new - t);
+            t_new = uni_d(t_new);
+            h_abs = fabs(h);
+            // stage planes at the three collocation times + predicted stage values (radau.py:445-448)
+            {
+                const double f0 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC0)));
+                const double f1 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC1)));
+                const double f2 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC2)));
+                for (int task = wave; task < 3 * P.ny; task += nwaves) {
+                    const int ti = task / P.ny, j = task - ti * P.ny;
+                    vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2),
+                                   (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV2), j, lane);
+                }
+                if (col_wave) {
+                    if (have_dense) {
+                        PredictArgs PA;
+                        PA.y = YR_Y; PA.yold = YR_YOLD; PA.zp = YR_ZP; PA.z = YR_Z; PA.w = A.W; PA.nv = nv;
+                        PA.x0 = ((t + h * RC0) - dense_t_old) / dense_h;
+                        PA.x1 = ((t + h * RC1) - dense_t_old) / dense_h;
+                        PA.x2 = ((t + h * RC2) - dense_t_old) / dense_h;
+                        predict_body<E, 1>(PA, wave, lane);
+                    } else {
+                        double zero[E];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) zero[e] = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            store_col<E, 1>(YR_Z + i * nv, wave, lane, zero);
+                            store_col<E>(A.W + i * nv, wave, lane, zero);
+                        }
+                    }
+                }
+                YEAR_SYNC()
+            }
+            bool converged = false;
+            while (!converged) {
+                if (!have_lu) {
+                    h_lu = h; have_lu = true;
+                    m_real = uni_i(year_sweeps_for(A, MU_REAL / h));
+                    m_cplx = uni_i(year_sweeps_for(A, MU_CR / h));
+                    nlu += 2;
+                    lu_cre = MU_REAL / h; lu_ccr = MU_CR / h; lu_cci = MU_CI / h;
+                    factor_pending = true;
+                }
+                // simplified Newton iterations (radau.py:48-136)
+                const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+                const int m = (m_real > m_cplx) ? m_real : m_cplx;
+                double dW_norm_old = 0.0;
+                bool has_old = false;
+                have_rate = false; rate = 0.0;
+                converged = false;
+                int k = 0;
+                for (k = 0; k < NEWTON_MAXITER; ++k) {
+                    int src = 0;
+                    for (int it = 0; it < m; ++it) {
+                        const bool do_stage = it == 0, first = it == 0, do_update = it == m - 1, delta = m == 2;
+                        const bool do_factor = factor_pending && it == 0;
+                        FusedArgs FA = {};
+                        FA.st.y = YR_Y; FA.st.z = YR_Z; FA.st.w = A.W;
+                        FA.st.kv[0] = A.KV[0]; FA.st.kv[1] = A.KV[1]; FA.st.kv[2] = YR_KV2;
+                        FA.st.br = A.BR; FA.st.bcr = A.BCR; FA.st.bci = A.BCI;
+                        FA.st.nv = nv; FA.st.mreal = mreal; FA.st.mcr = mcr; FA.st.mci = mci;
+                        FA.sw = A.fac;
+                        FA.sw.br = A.BR; FA.sw.bcr = A.BCR; FA.sw.bci = A.BCI;
+                        FA.sw.xr_old = src ? A.XR[1] : A.XR[0]; FA.sw.xcr_old = src ? A.XCR[1] : A.XCR[0];
+                        FA.sw.xci_old = src ? A.XCI[1] : A.XCI[0];
+                        FA.sw.xr_new = src ? A.XR[0] : A.XR[1]; FA.sw.xcr_new = src ? A.XCR[0] : A.XCR[1];
+                        FA.sw.xci_new = src ? A.XCI[0] : A.XCI[1];
+                        FA.sw.first = first ? 1 : 0;
+                        FA.sw.cre = lu_cre; FA.sw.ccr = lu_ccr; FA.sw.cci = lu_cci;
+                        FA.sw.f32 = 0;
+                        FA.part = YEAR_PART();
+                        FA.do_stage = do_stage ? 1 : 0; FA.do_update = do_update ? 1 : 0; FA.delta = delta ? 1 : 0;
+                        if (col_wave) {
+                            if (do_factor) newton_fused_body<E, KIND, 1, 1, 1>(P, FA, wave, lane);
+                            else newton_fused_body<E, KIND, 0, 1, 1>(P, FA, wave, lane);
+                        }
+                        {   // algorithmic bytes, as nk2d_r_newton_fused counts them
+                            double wd = 0.0;
+                            if (do_stage) wd += 7.0 * Ntot + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * Ntot);
+                            wd += (first ? 2.0 : 4.0) * Pc + (3.0 * Ntot + 3.0 * 14.0 / E * Ntot);
+                            if (do_factor) wd += Pc;
+                            if (!do_stage && !delta) wd += 3.0 * Ntot;
+                            if (!first) wd += 3.0 * Ntot;
+                            if (!do_update) wd += 3.0 * Ntot;
+                            if (do_update) wd += (do_stage ? 0.0 : Ntot) + 9.0 * Ntot;
+                            words += wd;
+                        }
+                        ++nsweeps;
+                        if (it == 0) factor_pending = false;
+                        src = 1 - src;
+                        YEAR_SYNC()
+                    }
+                    nsolve += 2; nfev += 3; ++nnewton;
+                    const double sum = uni_d(year_part_sum(YEAR_PART(), P.ncol, lane));
+                    ++pev;
+                    const double dW_norm = sqrt(sum) / sqrt(3.0 * A.n_total);
+                    if (uni_b(!(dW_norm == dW_norm))) break;
+                    if (has_old) { rate = uni_d(dW_norm / dW_norm_old); have_rate = true; }
+                    if (have_rate && uni_b(rate >= 1.0 || pow(rate, (double)(NEWTON_MAXITER - k)) / (1.0 - rate) * dW_norm > A.newton_tol)) break;
+                    if (uni_b(dW_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dW_norm < A.newton_tol))) { converged = true; break; }
+                    dW_norm_old = dW_norm;
+                    has_old = true;
+                }
+                n_iter = (k < NEWTON_MAXITER) ? k + 1 : NEWTON_MAXITER;
+                if (!converged) {
+                    if (current_jac) break;
+                    // stale Jacobian: refresh it and repeat the iteration from the predicted stage values
+                    // (radau.py:462-470: solve_collocation_system starts from Z0 again)
+                    YEAR_JAC(YR_KV3)
+                    if (col_wave) {
+                        if (have_dense) {
+                            PredictArgs PA;
+                            PA.y = YR_Y; PA.yold = YR_YOLD; PA.zp = YR_ZP; PA.z = YR_Z; PA.w = A.W; PA.nv = nv;
+                            PA.x0 = ((t + h * RC0) - dense_t_old) / dense_h;
+                            PA.x1 = ((t + h * RC1) - dense_t_old) / dense_h;
+                            PA.x2 = ((t + h * RC2) - dense_t_old) / dense_h;
+                            predict_body<E, 1>(PA, wave, lane);
+                        } else {
+                            double zero[E];
+#pragma unroll
+                            for (int e = 0; e < E; ++e) zero[e] = 0.0;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                store_col<E, 1>(YR_Z + i * nv, wave, lane, zero);
+                                store_col<E>(A.W + i * nv, wave, lane, zero);
+                            }
+                        }
+                    }
+                    YEAR_SYNC()
+                    t_jac = t; ++njev; current_jac = true; have_lu = false;
+                }
+            }
+            if (!converged) {
+                h_abs = uni_d(h_abs * 0.5);
+                have_lu = false;
+                newton_failed = true;
+                continue;
+            }
+            // error estimate (radau.py:477-487)
+            int buf = 0;
+            {
+                if (m_real <= 2) {
+                    int src = 0;
+                    for (int it = 0; it < m_real; ++it) {
+                        ErrArgs EA = {};
+                        EA.sw = A.fac;
+                        EA.f = A.F; EA.z = YR_Z; EA.y = YR_Y; EA.nv = nv; EA.h = h; EA.part = YEAR_PART();
+                        EA.sw.xr_old = src ? A.XR[1] : A.XR[0]; EA.sw.xr_new = src ? A.XR[0] : A.XR[1];
+                        EA.stage = it; EA.last = (it == m_real - 1) ? 1 : 0;
+                        if (col_wave) err_fused_body<E, KIND, 1>(P, EA, wave, lane);
+                        src = 1 - src;
+                        ++nsweeps;
+                        YEAR_SYNC()
+                    }
+                    buf = src;
+                } else {
+                    if (col_wave) err_rhs_body<E, 1>(A.F, YR_Z, nv, h, A.BR, wave, lane);
+                    // the first sweep reads only its own column's right-hand side: no barrier before it
+                    int src = 0;
+                    const int tr = wave / P.ny, j = wave - tr * P.ny;
+                    for (int it = 0; it < m_real; ++it) {
+                        SweepArgs SA = A.fac;
+                        SA.br = A.BR; SA.nreal = P.ncol; SA.ntasks = P.ncol;
+                        SA.xr_old = src ? A.XR[1] : A.XR[0]; SA.xr_new = src ? A.XR[0] : A.XR[1]; SA.first = (it == 0) ? 1 : 0;
+                        if (col_wave) sweep_body<E, KIND, 1>(P, SA, j * P.tc + tr, lane);
+                        src = 1 - src;
+                        ++nsweeps;
+                        YEAR_SYNC()
+                    }
+                    buf = src;
+                    if (col_wave) err_norm_body<E, 1>(P, YR_Y, YR_Z + 2 * nv, buf ? A.XR[1] : A.XR[0], YEAR_PART(), wave, lane);
+                    YEAR_SYNC()
+                }
+                ++nsolve;
+            }
+            {
+                const double sum = uni_d(year_part_sum(YEAR_PART(), P.ncol, lane));
+                ++pev;
+                err = sqrt(sum) / sqrt(A.n_total);
+            }
+            safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
+            if (rejected && uni_b(err > 1)) {
+                // filtered estimate: error <- solve(fun(t, y + error) + Z^T E / h)  (radau.py:485-487)
+                if (col_wave) {
+                    double tmp[E];
+                    load_col<E, 1>(buf ? A.XR[1] : A.XR[0], wave, lane, tmp);
+                    store_col<E, 1>(A.TMP, wave, lane, tmp);
+                }
+                YEAR_SYNC()
+                if (col_wave) err_rhs2_body<E, KIND, 1>(P, YR_Y, A.TMP, YR_KV3, YR_Z, nv, h, A.BR, wave, lane);
+                ++nfev;
+                int src = 0;
+                const int tr = wave / P.ny, j = wave - tr * P.ny;
+                for (int it = 0; it < m_real; ++it) {
+                    SweepArgs SA = A.fac;
+                    SA.br = A.BR; SA.nreal = P.ncol; SA.ntasks = P.ncol;
+                    SA.xr_old = src ? A.XR[1] : A.XR[0]; SA.xr_new = src ? A.XR[0] : A.XR[1]; SA.first = (it == 0) ? 1 : 0;
+                    if (col_wave) sweep_body<E, KIND, 1>(P, SA, j * P.tc + tr, lane);
+                    src = 1 - src;
+                    ++nsweeps;
+                    YEAR_SYNC()
+                }
+                buf = src;
+                ++nsolve;
+                if (col_wave) err_norm_body<E, 1>(P, YR_Y, YR_Z + 2 * nv, buf ? A.XR[1] : A.XR[0], YEAR_PART(), wave, lane);
+                YEAR_SYNC()
+                const double sum = uni_d(year_part_sum(YEAR_PART(), P.ncol, lane));
+                ++pev;
+                err = sqrt(sum) / sqrt(A.n_total);
+            }
+            if (uni_b(err > 1)) {
+                const double factor = year_predict_factor(h_abs, has_h_old, h_abs_old, err, has_err_old, err_old);
+                h_abs = uni_d(h_abs * fmax(0.2, safety * factor));
+                have_lu = false;
+                rejected = true;
+                ++nrejected;
+            } else {
+                accepted = true;
+            }
+        }
+        const bool recompute_jac = uni_b(n_iter > 2 && have_rate && rate > 1e-3);
+        double factor = year_predict_factor(h_abs, has_h_old, h_abs_old, err, has_err_old, err_old);
+        factor = fmin(10.0, safety * factor);
+        if (newton_failed && A.growth_cap > 0.0) factor = fmin(factor, A.growth_cap);
+        factor = uni_d(factor);
+        const double h_lu_used = h_lu;
+        if (!recompute_jac && uni_b(factor < 1.2)) factor = 1;
+        else have_lu = false;
+        if (A.record && nrec < A.record_cap && wave == 0 && lane == 0) {
+            double* r = A.record + (size_t)nrec * NK2D_SCHED_WIDTH;
+            r[0] = t; r[1] = t_new; r[2] = h; r[3] = (double)n_iter; r[4] = t_jac; r[5] = h_lu_used;
+        }
+        ++nrec;
+        // y_new, f_new = fun(t_new, y_new)
+        if (uni_b(t + h == t_new)) {
+            swapKV ^= 1;        // the third stage plane is the plane at t_new
+        } else {
+            const double fr = uni_d(year_interp4(A.bld_t, A.bld_f, t_new));
+            for (int j = wave; j < P.ny; j += nwaves) vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, fr, YR_KV3, j, lane);
+            YEAR_SYNC()
+        }
+        if (col_wave) commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV3, YR_YOLD, A.F, wave, lane);
+        swapY ^= 1;
+        swapZ ^= 1;
+        have_dense = true; dense_t_old = t; dense_h = uni_d(t_new - t);
+        t = t_new;
+        ++nsteps; ++nfev;
+        YEAR_SYNC()
+        if (recompute_jac) {
+            YEAR_JAC(YR_KV3)
+            YEAR_SYNC()
+            t_jac = t; ++njev; current_jac = true;
+        } else {
+            current_jac = false;
+        }
+        h_abs_old_s = h_abs_s; has_old_h = true;
+        err_old_s = err; has_old_err = true;
+        h_abs_s = uni_d(h_abs * factor);
+    }
+finish:
+    if (wave == 0 && lane == 0) {
+        double* o = A.out;
+        o[0] = (double)status; o[1] = t; o[2] = (double)nfev; o[3] = (double)njev; o[4] = (double)nlu;
+        o[5] = (double)nsteps; o[6] = (double)nrejected; o[7] = (double)nnewton; o[8] = (double)nsolve;
+        o[9] = (double)nsweeps; o[10] = (double)nrec; o[11] = (double)swapY; o[12] = (double)swapZ;
+        o[13] = (double)swapKV; o[14] = 8.0 * words; o[15] = (double)bar.epoch; o[16] = t_jac;
+    }
+#undef YEAR_SYNC
+#undef YEAR_JAC
+#undef YR_Y
+#undef YR_YOLD
+#undef YR_Z
+#undef YR_ZP
+#undef YR_KV2
+#undef YR_KV3
+#undef YEAR_PART
+}
+
+// host side: run the stepping loop of a forward year in the persistent kernel.  The caller has done SciPy's
+// prologue (f0 in F, initial step size, Jacobian at t0 with the plane of t0 in KV[3]).  Returns 1 when the
+// launch is not possible (grid not fully resident): the caller then steps under host control.
+int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double max_step, double n_total,
+                         double* record, int64_t record_cap, int64_t* record_n) {
+    if (c->kind != 0) return 1;
+    const int nblk = nk2d_grid(c->ncol);
+    if (!c->YR_OUT) {
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_PART, sizeof(double) * 2 * c->ncol));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_OUT, sizeof(double) * 32));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 256));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_MTAB, sizeof(int) * std::max<size_t>(c->rho_tab.size(), 1)));
+        NK2D_CHECK(c, hipHostMalloc((void**)&c->hYR_OUT, sizeof(double) * 32));
+        NK2D_CHECK(c, hipEventCreate(&c->yr_ev[0]));
+        NK2D_CHECK(c, hipEventCreate(&c->yr_ev[1]));
+        c->yr_lin_tol = -1.0;
+        c->yr_rec_cap = 0;
+        c->YR_REC = nullptr;
+    }
+    if (c->yr_lin_tol != c->d.lin_tol) {
+        // sweeps per shift bucket with the host's arithmetic (nk2d_sweeps_for), looked up on the device
+        std::vector<int> mtab(c->rho_tab.size());
+        for (size_t k = 0; k < mtab.size(); ++k)
+            mtab[k] = nk2d_sweeps_for(c, c->rho_c0 * std::pow(10.0, ((double)k + 0.5) * c->rho_dlog));
+        if (!mtab.empty())
+            NK2D_CHECK(c, hipMemcpy(c->YR_MTAB, mtab.data(), sizeof(int) * mtab.size(), hipMemcpyHostToDevice));
+        c->yr_lin_tol = c->d.lin_tol;
+    }
+    if (record && record_cap > c->yr_rec_cap) {
+        if (c->YR_REC) NK2D_CHECK(c, hipFree(c->YR_REC));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * record_cap));
+        c->yr_rec_cap = record_cap;
+    }
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 256, c->stream));
+    YearArgs A = {};
+    A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.W = c->W;
+    A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
+    for (int i = 0; i < 2; ++i) { A.XR[i] = c->XR[i]; A.XCR[i] = c->XCR[i]; A.XCI[i] = c->XCI[i]; }
+    A.TMP = c->TMP;
+    for (int i = 0; i < 4; ++i) A.KV[i] = c->KV[i];
+    fill_factor_args(c, A.fac);
+    A.fac.f32 = 0;
+    A.PART = c->YR_PART;
+    A.t0 = c->d.t0; A.t1 = c->d.t1; A.h_abs0 = h_abs0; A.max_step = max_step; A.newton_tol = newton_tol;
+    A.n_total = n_total; A.growth_cap = c->growth_cap; A.jac_fresh = c->jac_fresh;
+    for (int i = 0; i < 4; ++i) { A.bld_t[i] = c->d.bld_tvals[i]; A.bld_f[i] = c->d.bld_fvals[i]; }
+    A.bldmin = c->d.bldepth_min; A.vy0 = c->d.vmix_log_shallow; A.vy1 = c->d.vmix_log_deep; A.hw = c->d.vmix_half_width;
+    A.m_tab = c->YR_MTAB; A.n_tab = (int)c->rho_tab.size(); A.rho_c0 = c->rho_c0; A.rho_dlog = c->rho_dlog;
+    A.arrive = (unsigned*)c->YR_SYNC; A.abort_flag = (int*)((char*)c->YR_SYNC + 128);
+    A.out = c->YR_OUT;
+    A.record = record ? c->YR_REC : nullptr;
+    A.record_cap = record ? record_cap : 0;
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    void* args[2] = {&P, &A};
+    hipError_t rc = hipErrorInvalidValue;
+    NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
+    NK2D_DISPATCH_E(c->E, rc = hipLaunchCooperativeKernel((const void*)k_year_persistent<EE, 0>, dim3(nblk), dim3(NK2D_BLOCK),
+                                                           args, 0, c->stream));
+    if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
+    NK2D_CHECK(c, rc);
+    NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    const double* o = c->hYR_OUT;
+    const int status = (int)o[0];
+    // the buffers swapped roles on the device an odd or even number of times
+    if ((int)o[11]) std::swap(c->Y, c->YOLD);
+    if ((int)o[12]) std::swap(c->Z, c->ZP);
+    if ((int)o[13]) std::swap(c->KV[2], c->KV[3]);
+    c->st.nfev += (int64_t)o[2]; c->st.njev += (int64_t)o[3]; c->st.nlu += (int64_t)o[4];
+    c->st.nsteps += (int64_t)o[5]; c->st.nrejected += (int64_t)o[6]; c->st.nnewton += (int64_t)o[7];
+    c->st.nsolve += (int64_t)o[8]; c->st.nsweeps += (int64_t)o[9]; c->st.nlaunch += 1;
+    float ms = 0.f;
+    NK2D_CHECK(c, hipEventElapsedTime(&ms, c->yr_ev[0], c->yr_ev[1]));
+    if (c->prof_every > 0) {
+        // profile window = the whole-year kernel: one "launch", its algorithmic bytes, its duration
+        c->prof_ms_sum += ms; c->prof_windows += 1; c->prof_cnt += 1;
+        c->sweep_launches += 1; c->sweep_bytes += o[14]; c->fused_bytes_all += o[14];
+    }
+    if (status == 1) return nk2d_fail(c, "nk2d_comp_fcn: a grid barrier of the persistent year timed out", -6);
+    if (status == 2) return nk2d_fail(c, "Radau: step size is not finite (non-finite state or tendency)", -3);
+    if (status == 3) return nk2d_fail(c, "Radau: required step size is less than spacing between numbers", -3);
+    const int64_t nrec = (int64_t)o[10];
+    if (record && nrec > 0) {
+        const int64_t ncopy = std::min<int64_t>(nrec, record_cap);
+        NK2D_CHECK(c, hipMemcpy(record, c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * ncopy, hipMemcpyDeviceToHost));
+    }
+    if (record_n) *record_n = nrec;
+    if (record && nrec > record_cap) return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
     return 0;
 }

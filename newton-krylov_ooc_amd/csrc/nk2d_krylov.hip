@@ -13,6 +13,7 @@
 // Python mirror of KrylovSolver (krylov_solver.py, which keeps the reference's file trail) and this
 // all-device loop produce the same Krylov space.
 #include "nk2d_common.h"
+#include "nk2d_hostmath.h"
 
 #include <algorithm>
 #include <cmath>
@@ -133,33 +134,9 @@ int stage_ptrs(nk2d_ctx* c, Scratch& s, int n, const nk2d_vec* vecs, const doubl
     return 0;
 }
 
-// argmin_c || beta e_1 - H c ||_2 for the (j+2) x (j+1) upper Hessenberg H (column major access via hess(i, k)):
-// Givens rotations to upper triangular form, back substitution.  A zero pivot (exact breakdown) leaves that
-// coefficient at zero -- the minimum-norm choice np.linalg.lstsq makes for a rank-deficient column.
+// least squares of the Hessenberg: nk2d_hostmath.h (built and run under AddressSanitizer on the CPU, `make asan-host`)
 void hessenberg_lstsq(int ncols, const std::vector<double>& H, int ld, double beta, double* coef) {
-    const int nrows = ncols + 1;
-    std::vector<double> R(H), g(nrows, 0.0);
-    g[0] = beta;
-    for (int k = 0; k < ncols; ++k) {
-        const double a = R[(size_t)k * ld + k], b = R[(size_t)(k + 1) * ld + k];
-        const double r = std::hypot(a, b);
-        if (r == 0.0) continue;
-        const double cs = a / r, sn = b / r;
-        for (int col = k; col < ncols; ++col) {
-            const double u = R[(size_t)k * ld + col], v = R[(size_t)(k + 1) * ld + col];
-            R[(size_t)k * ld + col] = cs * u + sn * v;
-            R[(size_t)(k + 1) * ld + col] = -sn * u + cs * v;
-        }
-        const double u = g[k], v = g[k + 1];
-        g[k] = cs * u + sn * v;
-        g[k + 1] = -sn * u + cs * v;
-    }
-    for (int k = ncols - 1; k >= 0; --k) {
-        double acc = g[k];
-        for (int col = k + 1; col < ncols; ++col) acc -= R[(size_t)k * ld + col] * coef[col];
-        const double piv = R[(size_t)k * ld + k];
-        coef[k] = (piv != 0.0) ? acc / piv : 0.0;
-    }
+    nk2d_hm_hessenberg_lstsq(ncols, H, ld, beta, coef);
 }
 
 struct VecSet {

@@ -278,6 +278,153 @@ __global__ void __launch_bounds__(256) k_pc_gj_update(int m, int p0, int nb, con
     }
 }
 
+// The same rank-nb update on the matrix cores: v_mfma_f64_16x16x4_f64.  A wave owns a 32 x 32 quadrant of the
+// 64 x 64 tile = 2 x 2 MFMA tiles, 8 k-steps of 4 pivots each: 32 MFMAs per wave instead of 512 VALU FMAs and a
+// quarter of the LDS reads.  Operand lane maps (cdna_hip_programming.md section 3, f64): A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15], one double each; C/D row = (lane >> 4) + 4 reg, col = lane & 15.  On gfx950 the
+// fp64 matrix rate equals the fp64 vector rate, so this buys instruction and LDS slots, not flops -- the kernel
+// streams the m x m matrix through HBM once per nb pivots either way (section 4 of DESIGN.md).
+typedef double pc_v4d __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_pc_gj_update_mfma(int m, int p0, int nb, const double* __restrict__ src,
+                                                           const double* __restrict__ rows, double* __restrict__ dst) {
+    __shared__ double sf[64][PC_NB + 1];   // src[i, pb]
+    __shared__ double sr[PC_NB][64 + 1];   // R[:, c]
+    const int tr = blockIdx.z;
+    const size_t base = (size_t)tr * m * m;
+    const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int ib = (wv >> 1) * 32, jb = (wv & 1) * 32;
+    const int lr16 = l >> 4, lc16 = l & 15;
+    double lf[8], lrr[8], tile[2][2][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int ii = idx / PC_NB, q = idx - ii * PC_NB;
+        const int i = i0 + ii;
+        lf[k] = (i < m && q < nb) ? src[base + (size_t)i * m + p0 + q] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int q = idx / 64, cc = idx - q * 64;
+        const int c = c0 + cc;
+        lrr[k] = (c < m && q < nb) ? rows[((size_t)tr * PC_NB + q) * m + c] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
+                tile[ti][tj][reg] = (i < m && c < m) ? src[base + (size_t)i * m + c] : 0.0;
+            }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        sf[idx / PC_NB][idx % PC_NB] = lf[k];
+        sr[idx / 64][idx % 64] = lrr[k];
+    }
+    __syncthreads();
+    pc_v4d acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (pc_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < PC_NB / 4; ++ks) {
+        const int k = 4 * ks + lr16;      // pivots beyond nb were staged as zeros
+        const double a0 = sf[ib + lc16][k], a1 = sf[ib + 16 + lc16][k];
+        const double b0 = sr[k][jb + lc16], b1 = sr[k][jb + 16 + lc16];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
+                if (i >= m || c >= m) continue;
+                double val;
+                if (i >= p0 && i < p0 + nb) {
+                    val = sr[i - p0][c - c0];
+                } else {
+                    const bool pivot_col = c >= p0 && c < p0 + nb;
+                    val = (pivot_col ? 0.0 : tile[ti][tj][reg]) - acc[ti][tj][reg];
+                }
+                dst[base + (size_t)i * m + c] = val;
+            }
+}
+
+// Dense mat-vec of the block substitution for even m: 16-byte loads, the whole row of a wave requested at once
+// (up to 10 x 1 KB per wave in flight), the vector staged once per workgroup in LDS instead of being re-read
+// through L1 by every wave.  Same epilogues as k_pc_gemv below.
+#define PC_GEMV_CHUNK 10
+#define PC_GEMV_XMAX 4096
+__global__ void __launch_bounds__(256) k_pc_gemv2(PcDev P, int mode, int j, const double* __restrict__ M,
+                                                  size_t m_tr_stride, const double* __restrict__ a,
+                                                  const double* __restrict__ rhs, size_t v_tr_stride,
+                                                  double* __restrict__ out, double* __restrict__ prev) {
+    __shared__ double2 xs[PC_GEMV_XMAX / 2];
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tr = blockIdx.y;
+    const int m2 = P.m >> 1;
+    const double2* av2 = reinterpret_cast<const double2*>(a + (size_t)tr * v_tr_stride);
+    const bool live = r < P.m;
+    const double2* row2 = reinterpret_cast<const double2*>(M + (size_t)tr * m_tr_stride + (size_t)(live ? r : 0) * P.m);
+    // the matrix row first (it comes from HBM), then the vector (L2)
+    double2 mv[PC_GEMV_CHUNK];
+#pragma unroll
+    for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
+        const int c = lane + 64 * q;
+        mv[q] = (live && c < m2) ? row2[c] : make_double2(0.0, 0.0);
+    }
+    for (int i = threadIdx.x; i < m2; i += blockDim.x) xs[i] = av2[i];
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
+        const int c = lane + 64 * q;
+        const double2 xv = (c < m2) ? xs[c] : make_double2(0.0, 0.0);
+        acc[(2 * q) & 3] = __builtin_fma(mv[q].x, xv.x, acc[(2 * q) & 3]);
+        acc[(2 * q + 1) & 3] = __builtin_fma(mv[q].y, xv.y, acc[(2 * q + 1) & 3]);
+    }
+    for (int c0 = 64 * PC_GEMV_CHUNK; c0 < m2; c0 += 64 * PC_GEMV_CHUNK) {   // rows longer than one chunk
+        double2 mw[PC_GEMV_CHUNK];
+#pragma unroll
+        for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
+            const int c = c0 + lane + 64 * q;
+            mw[q] = (live && c < m2) ? row2[c] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
+            const int c = c0 + lane + 64 * q;
+            const double2 xv = (c < m2) ? xs[c] : make_double2(0.0, 0.0);
+            acc[(2 * q) & 3] = __builtin_fma(mw[q].x, xv.x, acc[(2 * q) & 3]);
+            acc[(2 * q + 1) & 3] = __builtin_fma(mw[q].y, xv.y, acc[(2 * q + 1) & 3]);
+        }
+    }
+    if (!live) return;
+    const double sum = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane == 0) {
+        const int slot = r / P.nz, k = r - slot * P.nz;
+        const size_t at = (size_t)tr * v_tr_stride + r;
+        if (mode == 0) {
+            out[at] = rhs[at] - lat_l(P, slot, k, j) * sum;
+        } else {
+            out[at] = sum;
+            if (prev) prev[at] = prev[at] - lat_u(P, slot, k, j - 1) * sum;
+        }
+    }
+}
+
 // dense mat-vec with the block-Thomas epilogues; one wave per row, eight 512-byte requests per wave in flight
 //   mode 0 (forward):  out[r] = rhs[r] - l[r] * sum_c M[r][c] a[c]
 //   mode 1 (backward): out[r] = x_j[r] = sum_c M[r][c] a[c], where a = y_j - U_j x_{j+1} was left behind by the
@@ -483,8 +630,12 @@ int precond_eliminate(nk2d_ctx* c) {
             double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
             hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, c->stream, m, p0, nbk, from,
                                pc->ROWS);
-            hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream, m, p0,
-                               nbk, from, pc->ROWS, to);
+            if (c->pc_valu)
+                hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream, m, p0,
+                                   nbk, from, pc->ROWS, to);
+            else
+                hipLaunchKernelGGL(k_pc_gj_update_mfma, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream,
+                                   m, p0, nbk, from, pc->ROWS, to);
             src = 1 - src;
         }
         for (int sys = 0; sys < nsys; ++sys)
@@ -516,19 +667,33 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     double* yv = pc->YV + (size_t)sys0 * vstride;
     double* xv = pc->XV + (size_t)sys0 * vstride;
     const dim3 blk(256), grd((m + 3) / 4, nsys);
+    // even m (16-byte aligned rows) and a vector that fits the LDS staging: the wide kernel
+    const bool wide = !c->pc_valu && (m % 2 == 0) && m <= PC_GEMV_XMAX;
     // y_0 = r_0
     for (int sys = 0; sys < nsys; ++sys)
         NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
                                      hipMemcpyDeviceToDevice, c->stream));
-    for (int j = 1; j < nb; ++j)
-        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
-                           yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
-                           (double*)nullptr);
+    for (int j = 1; j < nb; ++j) {
+        if (wide)
+            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
+                               yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
+                               (double*)nullptr);
+        else
+            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
+                               yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
+                               (double*)nullptr);
+    }
     // backward: x_j = Sinv_j (y_j - U_j x_{j+1}); each launch leaves y_{j-1} - U_{j-1} x_j behind for the next
-    for (int j = nb - 1; j >= 0; --j)
-        hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
-                           yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
-                           (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
+    for (int j = nb - 1; j >= 0; --j) {
+        if (wide)
+            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
+                               yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
+                               (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
+        else
+            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
+                               yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
+                               (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
+    }
     NK2D_CHECK(c, hipGetLastError());
     return 0;
 }

@@ -576,7 +576,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.t1 = c->d.t1;
     s.max_step = (c->d.t1 - c->d.t0) * c->d.max_step_frac;
     s.n_total = (c->norm_hook && c->global_n > 0.0) ? c->global_n : (double)c->tc * c->nz * c->ny;
-    if (c->norm_hook && c->device_ctl != 0 && !replay)
+    if (c->norm_hook && c->device_ctl != 0 && c->device_ctl != 3 && !replay)
         return nk2d_fail(c, "nk2d_comp_fcn: a norm hook (sharded tracer module) needs host-side decisions (device_ctl 0)");
     s.newton_tol = std::max(10 * std::numeric_limits<double>::epsilon() / c->d.rtol, std::min(0.03, std::sqrt(c->d.rtol)));
     s.has_old_h = s.has_old_err = false;
@@ -584,7 +584,10 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.have_lu = false; s.have_dense = false;
     s.h_lu = 0; s.dense_t_old = 0; s.dense_h = 0;
     s.m_real = s.m_cplx = 1;
-    s.device_ctl = c->device_ctl;
+    // 3: the stepping loop runs in one persistent kernel (nk2d_year_persistent); history sampling, a norm
+    // hook (sharded module) and the state dependent modules keep the host-controlled loop
+    const bool persistent = c->device_ctl == 3 && !replay && c->hist_n == 0 && !c->norm_hook && c->kind == 0;
+    s.device_ctl = (c->device_ctl == 3) ? 0 : c->device_ctl;
     // per-column partials go to pinned host memory while the host takes the decisions; the flag is
     // dropped on every way out of this function
     struct PartGuard {
@@ -611,7 +614,14 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         NK2D_TRY(refresh_jac(s, s.t, true));
         c->st.njev = 1;
         s.current_jac = true;
-        if (replay) NK2D_TRY(run_replay(s, replay, replay_n));
+        bool stepped = false;
+        if (persistent) {
+            const int rc = nk2d_year_persistent(c, s.h_abs, s.newton_tol, s.max_step, s.n_total, record, record_cap, record_n);
+            if (rc < 0) return rc;
+            stepped = rc == 0;      // 1: the grid does not fit the chip at once -- host control below
+        }
+        if (stepped) {}
+        else if (replay) NK2D_TRY(run_replay(s, replay, replay_n));
         else NK2D_TRY(run_free(s, record, record_cap, record_n));
         NK2D_TRY(nk2d_r_final(c, (const double*)x, (double*)fx));
     } else {

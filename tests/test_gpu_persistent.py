@@ -1,0 +1,131 @@
+"""The whole forward year in one persistent kernel (nk2d_set_option "device_ctl" 3: grid barriers between the
+phases of the Radau step, SciPy's controller evaluated on the device) against the same references as the
+host-controlled integrator: the solve_ivp goldens at the CI tolerance and within 10 % of SciPy's counters, its own
+recorded schedule replayed under HOST control to 1e-10 (the two control paths run the same phase functions), run
+to run determinism, the single-sweep (no lateral coupling) and many-sweep (strong lateral coupling) solves, and
+the 416 x 416 size.  Timings are written to gpurun_out/r02_persistent.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_iage, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "r02_persistent.json")
+
+
+def record(key, value):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    data = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    data[key] = value
+    with open(OUT, "w") as fptr:
+        json.dump(data, fptr, indent=1, sort_keys=True)
+
+
+def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    return iage_engine(Grid2d.default(nz, ny, vv, kh), **kw)
+
+
+def faithful(eng):
+    eng.set_option("jac_fresh", 0)
+    eng.set_option("growth_cap", 0)
+
+
+@pytest.mark.parametrize("tag,nz,ny,vv,kh", [("20x3_columns", 20, 3, 0.0, 0.0), ("26x26", 26, 26, 0.1, 1000.0),
+                                             ("52x52", 52, 52, 0.1, 1000.0), ("104x104", 104, 104, 0.1, 1000.0)])
+def test_persistent_year_against_solve_ivp(golden_dir, tag, nz, ny, vv, kh):
+    g = np.load(f"{golden_dir}/comp_fcn_{tag}.npz")
+    eng = make_engine(nz, ny, vv, kh)
+    faithful(eng)
+    x = eng.upload(g["y0"])
+    fx_host, st_host, _ = eng.comp_fcn(x)
+    eng.set_option("device_ctl", 3)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    got = eng.download(fx).reshape(-1)
+    assert st["nlaunch"] < 40, st["nlaunch"]                 # prologue + ONE stepping kernel + epilogue
+    assert len(sched) == st["nsteps"]
+    assert np.allclose(got, g["fcn"], rtol=1.0e-3, atol=1.0e-6), np.max(np.abs(got - g["fcn"]))
+    for key in ("nfev", "njev", "nlu"):
+        assert abs(st[key] - int(g[key])) <= 0.1 * int(g[key]) + 5, (key, st[key], int(g[key]))
+    # the same run twice: bit-identical (fixed-order reductions, identical decisions in every wave)
+    fx2, st2, sched2 = eng.comp_fcn(x, record=True)
+    assert np.array_equal(eng.download(fx2).reshape(-1), got) and np.array_equal(sched2, sched)
+    # its schedule replayed by the host-controlled integrator: same phase functions, same year
+    eng.set_option("device_ctl", 0)
+    fx3, _, _ = eng.comp_fcn(x, replay=sched)
+    assert rel_err(eng.download(fx3).reshape(-1), got) < 1e-10
+    record(f"year_{tag}", {"persistent_s": st["seconds"], "host_controlled_s": st_host["seconds"],
+                           "nsteps": st["nsteps"], "nnewton": st["nnewton"], "nsweeps": st["nsweeps"],
+                           "host_nlaunch": st_host["nlaunch"],
+                           "dev_vs_host_over_tol": float(np.max(np.abs(got - eng.download(fx_host).reshape(-1))
+                                                                / (1e-6 + 1e-3 * np.abs(got))))})
+
+
+def test_persistent_year_default_mode_and_many_sweeps():
+    """engine defaults (Jacobian at every step start), and a strongly coupled case whose solves need many sweeps
+    (error estimate through the stand-alone sweep path)"""
+    from oracle import radau
+
+    nz, ny = 24, 20
+    _, tm = oracle_iage(nz, ny, 3.0, 3.0e6)
+    col = np.interp(tm.model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    y0 = (np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2)
+          * (1.0 + 0.1 * np.random.default_rng(4).standard_normal((2, nz, ny)))).reshape(-1)
+    want = radau.comp_fcn(tm, y0)
+    eng = make_engine(nz, ny, 3.0, 3.0e6)
+    eng.set_option("device_ctl", 3)
+    fx, st, sched = eng.comp_fcn(eng.upload(y0), record=True)
+    assert st["nsweeps"] > 3 * st["nnewton"]
+    assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
+    eng.set_option("device_ctl", 0)
+    fx2, _, _ = eng.comp_fcn(eng.upload(y0), replay=sched)
+    assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-10
+
+
+def test_persistent_year_416():
+    n = 416
+    eng = make_engine(n, n)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
+    x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])
+    fx_host, st_host, _ = eng.comp_fcn(x)
+    eng.set_option("device_ctl", 3)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    assert st["nlaunch"] < 40
+    got, host = eng.download(fx), eng.download(fx_host)
+    margin = float(np.max(np.abs(got - host) / (1.0e-6 + 1.0e-3 * np.abs(host))))
+    record("year_416x416", {"persistent_s": st["seconds"], "host_controlled_s": st_host["seconds"],
+                            "nsteps": st["nsteps"], "host_nsteps": st_host["nsteps"], "nnewton": st["nnewton"],
+                            "margin_vs_host_over_tol": margin})
+    assert margin < 1.0
+    assert abs(st["nsteps"] - st_host["nsteps"]) <= 0.03 * st_host["nsteps"]
+    eng.set_option("device_ctl", 0)
+    fx3, _, _ = eng.comp_fcn(x, replay=sched)
+    assert rel_err(eng.download(fx3), got) < 1e-10
+
+
+def test_persistent_mode_falls_back_where_it_does_not_apply():
+    """history sampling and the state dependent modules keep the host-controlled loop"""
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = make_engine(26, 26)
+    eng.set_option("device_ctl", 3)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2).copy())
+    _, st, hist = eng.comp_fcn_hist(x, np.linspace(0.0, 365.0 * 86400.0, 61))
+    assert st["nlaunch"] > 1000 and hist.shape == (61, 2, 26, 26)
+    ph = phosphorus_engine(Grid2d.default(22, 9))
+    ph.set_option("device_ctl", 3)
+    prof = [np.interp(ph.grid.depth.mid, zs, vs) for zs, vs in (([1.3e2, 2.6e2], [5.5e-3, 4.1e0]),
+                                                                ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                                ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+    y0 = np.stack([np.broadcast_to(p[:, None], (22, 9)) for p in prof]).copy()
+    _, st, _ = ph.comp_fcn(ph.upload(y0))
+    assert st["nlaunch"] > 1000

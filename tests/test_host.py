@@ -264,3 +264,17 @@ def test_isclose_all_vars_reference_files(golden_dir):
     assert units_conversion_factor("m / d", "m / s") == 1.0 / 86400.0
     assert units_conversion_factor("(mmol / m^3) (m)", "mmol / m^2") == 1.0
     assert units_conversion_factor("m", "s") is None and units_conversion_factor("furlong", "m") is None
+
+
+def test_host_arithmetic_under_address_sanitizer():
+    """csrc/nk2d_hostmath.h (interpolation, interval bracketing, the fixed-order sum, the Hessenberg least squares)
+    built with a plain g++ under -fsanitize=address,undefined and run on the CPU: `make asan-host`"""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host compiler")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "newton-krylov_ooc_amd", "csrc")
+    res = subprocess.run(["make", "-C", csrc, "asan-host"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "hostmath ok" in res.stdout
