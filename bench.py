@@ -177,16 +177,19 @@ def roofline_of(eng, n):
     net_us = max(prof["avg_us"], 1e-3)
     raw_us = net_us + prof["event_overhead_us"] * prof["windows"] / samples
     achieved = bytes_per_launch / (raw_us * 1e-6) / 1e9
+    persistent = getattr(eng, "device_ctl", 0) == 3
     out = {
         "bound": "hbm",
-        "kernel": f"k_newton_fused<{(eng.nz + 63) // 64}, 0, 0, 1>",
+        "kernel": (f"k_year_persistent<{(eng.nz + 63) // 64}, 0> (the whole forward year in one launch: all phases and "
+                   "their grid barriers)" if persistent else f"k_newton_fused<{(eng.nz + 63) // 64}, 0, 0, 1>"),
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": None,
         "avg_launch_us": raw_us,
-        "timing": "HIP event pairs on the context's stream around back-to-back launches, event cost included",
+        "timing": ("HIP event pair on the context's stream around each whole-year launch" if persistent else
+                   "HIP event pairs on the context's stream around back-to-back launches, event cost included"),
         "avg_launch_us_net_of_empty_event_pair": net_us,
         "frac_net_of_empty_event_pair": bytes_per_launch / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "event_pair_empty_us": prof["event_overhead_us"],
@@ -206,7 +209,7 @@ def roofline_of(eng, n):
     stats_fname = os.path.join(ROOT, "profiles", f"r02_rocprof_bench{n}", "kernel_stats.csv")
     if os.path.exists(stats_fname):
         for line in open(stats_fname):
-            if line.startswith('"void ' + out["kernel"]):
+            if not persistent and line.startswith('"void ' + out["kernel"]):
                 avg_ns = float(line.rsplit('",', 1)[1].split(",")[2])
                 out["rocprofv3"] = {"avg_launch_us": avg_ns / 1000.0,
                                     "frac": bytes_per_launch / (avg_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,

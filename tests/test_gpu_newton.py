@@ -166,7 +166,8 @@ def test_ci_py_driver_2d_iage_setup(tmp_path):
     """scripts/ci_py_driver_2d_iage.sh on the GPU: the 30 x 30 set-up with one fixed-point year, compared file by
     file with the reference's committed baselines by the comparer with the reference's CLI semantics
     (grid_vars.nc at the default tolerances; fcn_0000 / init_iterate / init_iterate_0000 at atol 1e-6,
-    rtol 1e-3; the committed fixture leaves out hist_0000.nc for its size)"""
+    rtol 1e-3); hist_0000.nc, 2.3 MB in the reference tree, against a reduced copy of it (every variable; the 3-d ones
+    at every 10th time sample, tests/golden/gen_hist_subset.py) at the same tolerances"""
     from nk_ooc_amd import baseline_cmp
     from nk_ooc_amd.model_state import ModelState
     from nk_ooc_amd.setup_solver import make_config, setup
@@ -185,3 +186,16 @@ def test_ci_py_driver_2d_iage_setup(tmp_path):
         assert baseline_cmp.compare(fname, gen, base, rtol=1.0e-3, atol=1.0e-6), fname
     assert baseline_cmp.compare("init_iterate.nc", os.path.dirname(cfg["solverinfo"]["init_iterate_fname"]), base,
                                 rtol=1.0e-3, atol=1.0e-6)
+    from nk_ooc_amd import ncio
+
+    want = np.load(os.path.join(base, "hist_0000_subset.npz"))
+    got, _ = ncio.read_file(os.path.join(gen, "hist_0000.nc"))
+    dims = ncio.read_var_dims(os.path.join(gen, "hist_0000.nc"), list(got))
+    names = [key[4:] for key in want.files if key.startswith("var_")]
+    assert set(names) <= set(got), set(names) - set(got)
+    for name in names:
+        ref = want["var_" + name]
+        assert ",".join(dims[name]) == str(want["dims_" + name]), name
+        val = got[name][want["time_index"]] if got[name].ndim == 3 else got[name]
+        assert val.shape == ref.shape, name
+        assert np.all(np.isclose(val, ref, rtol=1.0e-3, atol=1.0e-6)), (name, float(np.max(np.abs(val - ref))))

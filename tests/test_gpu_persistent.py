@@ -44,6 +44,7 @@ def test_persistent_year_against_solve_ivp(golden_dir, tag, nz, ny, vv, kh):
     eng = make_engine(nz, ny, vv, kh)
     faithful(eng)
     x = eng.upload(g["y0"])
+    eng.set_option("device_ctl", 0)
     fx_host, st_host, _ = eng.comp_fcn(x)
     eng.set_option("device_ctl", 3)
     fx, st, sched = eng.comp_fcn(x, record=True)
@@ -78,14 +79,24 @@ def test_persistent_year_default_mode_and_many_sweeps():
     y0 = (np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2)
           * (1.0 + 0.1 * np.random.default_rng(4).standard_normal((2, nz, ny)))).reshape(-1)
     want = radau.comp_fcn(tm, y0)
-    eng = make_engine(nz, ny, 3.0, 3.0e6)
+    # inner tolerance 1e-3 = what a replay solves to (include/nk2d.h): recorded and replayed year are then the
+    # same arithmetic, decisions taken on the device vs read from the schedule
+    eng = make_engine(nz, ny, 3.0, 3.0e6, lin_tol=1.0e-3)
     eng.set_option("device_ctl", 3)
     fx, st, sched = eng.comp_fcn(eng.upload(y0), record=True)
-    assert st["nsweeps"] > 3 * st["nnewton"]
+    assert st["nsweeps"] > 3 * st["nnewton"] and st["nlaunch"] < 40
     assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
     eng.set_option("device_ctl", 0)
     fx2, _, _ = eng.comp_fcn(eng.upload(y0), replay=sched)
     assert rel_err(eng.download(fx2), eng.download(fx)) < 1e-10
+    # and under the engine's default inner tolerance the two controllers take the same year
+    dflt = make_engine(nz, ny, 3.0, 3.0e6)
+    dflt.set_option("device_ctl", 0)
+    fx_h, st_h, _ = dflt.comp_fcn(dflt.upload(y0))
+    dflt.set_option("device_ctl", 3)
+    fx_p, st_p, _ = dflt.comp_fcn(dflt.upload(y0))
+    assert np.allclose(dflt.download(fx_p), dflt.download(fx_h), rtol=1.0e-3, atol=1.0e-6)
+    assert abs(st_p["nsteps"] - st_h["nsteps"]) <= 0.05 * st_h["nsteps"] + 3
 
 
 def test_persistent_year_416():
@@ -94,7 +105,9 @@ def test_persistent_year_416():
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
     x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])
+    eng.set_option("device_ctl", 0)
     fx_host, st_host, _ = eng.comp_fcn(x)
+    assert st_host["nlaunch"] > 10000
     eng.set_option("device_ctl", 3)
     fx, st, sched = eng.comp_fcn(x, record=True)
     assert st["nlaunch"] < 40
@@ -105,9 +118,12 @@ def test_persistent_year_416():
                             "margin_vs_host_over_tol": margin})
     assert margin < 1.0
     assert abs(st["nsteps"] - st_host["nsteps"]) <= 0.03 * st_host["nsteps"]
+    # replay check with the inner tolerance a replay uses (1e-3), as tests/test_gpu_fullsize.py does for host control
+    eng.set_option("lin_tol", 1.0e-3)
+    fx4, st4, sched4 = eng.comp_fcn(x, record=True)
     eng.set_option("device_ctl", 0)
-    fx3, _, _ = eng.comp_fcn(x, replay=sched)
-    assert rel_err(eng.download(fx3), got) < 1e-10
+    fx3, _, _ = eng.comp_fcn(x, replay=sched4)
+    assert rel_err(eng.download(fx3), eng.download(fx4)) < 1e-10
 
 
 def test_persistent_mode_falls_back_where_it_does_not_apply():
