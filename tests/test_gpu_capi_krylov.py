@@ -185,6 +185,7 @@ def test_norm_hook_couples_two_single_tracer_engines():
     assert comm.calls >= out[0][1]["nnewton"]               # one all-reduce per norm the controller read
     sharded = np.concatenate([out[0][0], out[1][0]])
     whole = iage_engine(grid)
+    whole.set_option("device_ctl", 0)       # host control, as a hooked engine runs (the hook lives on the host)
     whole.set_option("jac_fresh", 0)
     whole.set_option("growth_cap", 0)
     fx, _, _ = whole.comp_fcn(whole.upload(y0), replay=out[0][2])
@@ -235,7 +236,9 @@ def test_plugin_backend_on_the_device():
     t_eval = np.linspace(0.0, year, 61)
     t, y = backend.forward_year(tm, y0.reshape(-1), t_eval)
     assert y.shape == (y0.size, 61) and np.array_equal(t, t_eval)
-    assert np.allclose(y[:, -1] - y0.reshape(-1), want.reshape(-1), rtol=1e-12, atol=1e-15)
+    # the sampled year runs under host control, the plain one (26 levels) in the persistent kernel: two free-running
+    # years of the same state
+    assert np.allclose(y[:, -1] - y0.reshape(-1), want.reshape(-1), rtol=1.0e-3, atol=1.0e-6)
     v = np.random.default_rng(1).standard_normal(y0.shape)
     assert np.array_equal(backend.precond_apply(tm, v), eng.download(eng.precond_apply(eng.upload(v))))
     with pytest.raises(NotImplementedError):
