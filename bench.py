@@ -275,8 +275,11 @@ def run_ladder(device_ordinal, device, args):
     return rows
 
 
-def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms):
-    """SURVEY.md section 8(e) level 2, measured: ONE iage module, its two tracers on ranks 0 and 1"""
+def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, allreduces_hint):
+    """SURVEY.md section 8(e) level 2, measured: ONE iage module, its two tracers on ranks 0 and 1.  One Krylov
+    iteration (perturbed forward year with every Radau norm all-reduced, preconditioner, CGS-2 with fused
+    multi-dots, residual) is timed after the all-reduce latency itself; when latency x expected count exceeds
+    --shard-budget seconds the leg is skipped and says so."""
     import numpy as np
     import torch
     import torch.distributed as tdist
@@ -287,35 +290,44 @@ def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms):
     group = tdist.new_group([0, 1])
     result = None
     if rank < 2:
-        n = args.grid
+        n = args.shard_grid or args.grid
         grid = Grid2d.default(n, n)
         comm = nkdist.ShardComm(device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu", group=group)
-        eng = nkdist.iage_shard_engine(grid, rank, comm, device_id=local_rank)
-        eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(grid.depth.delta, grid.ypos.delta))
-        col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
-        x = eng.upload(np.broadcast_to(col[:, None], (1, n, n)).copy())
-        fx0, _, _ = eng.comp_fcn(x)
-        x = eng.axpby(1.0, x, 1.0, fx0)
-        fx, _, _ = eng.comp_fcn(x)
-        eng.precond_setup()
-        eng.sync()
-        k = max(1, min(args.steps, 2))
-        nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 1)     # warm-up
-        calls0 = comm.calls
-        tdist.barrier(group=group)
+        for _ in range(20):
+            comm.allreduce_scalar(1.0)
         t0 = time.perf_counter()
-        _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, k)
-        eng.sync()
-        tdist.barrier(group=group)
-        elapsed = time.perf_counter() - t0
+        for _ in range(200):
+            comm.allreduce_scalar(1.0)
+        latency = (time.perf_counter() - t0) / 200
+        scale = (n / float(args.grid)) ** 0.5 if args.grid else 1.0       # steps grow like sqrt(n) on this ladder
+        expected = 2.0 * (allreduces_hint * scale * latency + one_gpu_ms / 1000.0)
+        verdict = torch.tensor([expected], dtype=torch.float64)
         result = {"layout": "ONE iage module, tracer per rank on ranks 0 and 1 (block-diagonal Jacobian); every "
                             "Radau norm and every Krylov inner product is an all-reduce(SUM) of 1 .. (j+1) nreg doubles",
-                  "backend": backend, "grid": [n, n], "krylov_iterations": k,
-                  "ms_per_jvp": 1000.0 * elapsed / k, "jvps_per_s": k / elapsed,
-                  "allreduces_per_jvp": (info["allreduces"] - calls0) / k,
-                  "one_gpu_ms_per_jvp": one_gpu_ms,
-                  "speedup_over_one_gpu": (one_gpu_ms / (1000.0 * elapsed / k)) if one_gpu_ms else None}
-        eng.close()
+                  "backend": backend, "grid": [n, n], "allreduce_latency_us": 1.0e6 * latency,
+                  "expected_seconds": expected, "one_gpu_ms_per_jvp": one_gpu_ms}
+        if expected > args.shard_budget:
+            result["skipped"] = f"expected {expected:.0f} s exceeds --shard-budget {args.shard_budget:.0f} s"
+        else:
+            eng = nkdist.iage_shard_engine(grid, rank, comm, device_id=local_rank)
+            eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(grid.depth.delta, grid.ypos.delta))
+            col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+            x = eng.upload(np.broadcast_to(col[:, None], (1, n, n)).copy())
+            fx, _, _ = eng.comp_fcn(x)                      # F(x): a coupled year, untimed
+            eng.precond_setup()
+            eng.sync()
+            calls0 = comm.calls
+            tdist.barrier(group=group)
+            t0 = time.perf_counter()
+            _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 1)
+            eng.sync()
+            tdist.barrier(group=group)
+            elapsed = time.perf_counter() - t0
+            result.update({"krylov_iterations": 1, "ms_per_jvp": 1000.0 * elapsed, "jvps_per_s": 1.0 / elapsed,
+                           "allreduces_per_jvp": info["allreduces"] - calls0,
+                           "speedup_over_one_gpu": (one_gpu_ms / (1000.0 * elapsed)) if (one_gpu_ms and n == args.grid) else None})
+            eng.close()
+        del verdict
     tdist.barrier()
     return result
 
@@ -331,6 +343,9 @@ def main():
     ap.add_argument("--no-ladder", action="store_true", help="skip the 26..208 grid ladder")
     ap.add_argument("--ladder-steps", type=int, default=3)
     ap.add_argument("--no-shard", action="store_true", help="skip the sharded-module leg of N >= 2 runs")
+    ap.add_argument("--shard-grid", type=int, default=0, help="grid of the sharded-module leg (default: --grid)")
+    ap.add_argument("--shard-budget", type=float, default=120.0,
+                    help="skip the sharded-module leg when its expected wall time exceeds this many seconds")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, all-reduce their ranks over gloo and print the world size "
                          "(CPU check of the self-launch path, tests/test_dist.py)")
@@ -442,7 +457,8 @@ def main():
         wl.close()
         wl = None
         if world >= 2 and not args.no_shard:
-            shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms)
+            hint = jvp_stats["nnewton"] + 2 * (jvp_stats["nsteps"] + jvp_stats["nrejected"]) + 10
+            shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
             if rank == 0:
                 out["shard_e2"] = shard
         if rank == 0:

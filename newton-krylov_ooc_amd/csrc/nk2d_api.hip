@@ -131,7 +131,6 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
-    if (key == "pc_chain") { c->pc_chain_off = value == 0.0; return 0; }
     if (key == "factor_fp32") {
         // the single precision copy is written by the next factorisation: drop the cached one
         c->factor_fp32 = value != 0.0;
@@ -446,8 +445,6 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->stage_elems = 0;
     c->precond = nullptr;
     c->pc_valu = 0;
-    c->PC_SYNC = nullptr;
-    c->pc_chain_off = 0;
     c->st = nk2d_stats();
     c->prof_every = 0;
     c->hSNAP = nullptr;
@@ -494,7 +491,6 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
         if (b) (void)hipFree(b);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->timer_ready) { (void)hipEventDestroy(c->timer_ev[0]); (void)hipEventDestroy(c->timer_ev[1]); }
-    if (c->PC_SYNC) (void)hipFree(c->PC_SYNC);
     if (c->YR_OUT) {
         (void)hipFree(c->YR_PART); (void)hipFree(c->YR_OUT); (void)hipFree(c->YR_SYNC); (void)hipFree(c->YR_MTAB);
         if (c->YR_REC) (void)hipFree(c->YR_REC);

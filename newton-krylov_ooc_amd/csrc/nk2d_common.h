@@ -122,8 +122,6 @@ struct nk2d_ctx {
     double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
-    void* PC_SYNC;     // arrival counters + abort flag of the one-launch block substitution (k_pc_subst)
-    int pc_chain_off;  // 1: launch the substitution link by link (option "pc_chain" 0, or the grid is not resident at once)
     int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
 
     // optional dense-output sampling of the running comp_fcn (history files)

@@ -2025,6 +2025,13 @@ struct YearArgs {
     long long record_cap;
 };
 
+// Arrival counter in NK2D_BAR_SHARDS shards, each on a 128-byte line of its own: an agent-scope atomic executes at
+// the memory side and adds to ONE address serialise (MI355X_MICROARCH.md, global atomics: ~50 ns each) -- with 200
+// workgroups on one counter the arrivals alone cost 10 us.  A workgroup adds to shard (blockIdx & 31); the polling
+// wave reads all shards with one load instruction (lane i reads shard i) and sums them.
+#define NK2D_BAR_SHARDS 32
+#define NK2D_BAR_STRIDE 32   /* unsigned ints between shards = 128 bytes */
+
 struct GridBarrier {
     unsigned* arrive;
     int* abort_flag;
@@ -2033,21 +2040,32 @@ struct GridBarrier {
     __device__ __forceinline__ bool sync() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {     // the first wave arrives for the workgroup and polls
+            const int lane = threadIdx.x;
             const unsigned target = (epoch + 1u) * nwg;
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0)
+                __hip_atomic_fetch_add(arrive + (size_t)(blockIdx.x % NK2D_BAR_SHARDS) * NK2D_BAR_STRIDE, 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int good = 1;
             long long spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (++spins > NK2D_SPIN_LIMIT ||
-                    __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                unsigned v = 0u;
+                if (lane < NK2D_BAR_SHARDS)
+                    v = __hip_atomic_load(arrive + (size_t)lane * NK2D_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+                const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                if (total >= target) break;
+                const int ab = __builtin_amdgcn_readfirstlane(
+                    (lane == 0) ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+                if (++spins > NK2D_SPIN_LIMIT || ab != 0) {
+                    if (lane == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = 0;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            *lds_ok = good;
+            if (lane == 0) *lds_ok = good;
         }
         __syncthreads();
         ++epoch;
@@ -2463,7 +2481,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     if (!c->YR_OUT) {
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_PART, sizeof(double) * 2 * c->ncol));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_OUT, sizeof(double) * 32));
-        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 256));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 8192));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_MTAB, sizeof(int) * std::max<size_t>(c->rho_tab.size(), 1)));
         NK2D_CHECK(c, hipHostMalloc((void**)&c->hYR_OUT, sizeof(double) * 32));
         NK2D_CHECK(c, hipEventCreate(&c->yr_ev[0]));
@@ -2486,7 +2504,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * record_cap));
         c->yr_rec_cap = record_cap;
     }
-    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 256, c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 8192, c->stream));
     YearArgs A = {};
     A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.W = c->W;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
@@ -2501,7 +2519,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     for (int i = 0; i < 4; ++i) { A.bld_t[i] = c->d.bld_tvals[i]; A.bld_f[i] = c->d.bld_fvals[i]; }
     A.bldmin = c->d.bldepth_min; A.vy0 = c->d.vmix_log_shallow; A.vy1 = c->d.vmix_log_deep; A.hw = c->d.vmix_half_width;
     A.m_tab = c->YR_MTAB; A.n_tab = (int)c->rho_tab.size(); A.rho_c0 = c->rho_c0; A.rho_dlog = c->rho_dlog;
-    A.arrive = (unsigned*)c->YR_SYNC; A.abort_flag = (int*)((char*)c->YR_SYNC + 128);
+    A.arrive = (unsigned*)c->YR_SYNC; A.abort_flag = (int*)((char*)c->YR_SYNC + 4096);
     A.out = c->YR_OUT;
     A.record = record ? c->YR_REC : nullptr;
     A.record_cap = record ? record_cap : 0;

@@ -425,128 +425,6 @@ __global__ void __launch_bounds__(256) k_pc_gemv2(PcDev P, int mode, int j, cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The whole block substitution in ONE launch.  The 2 nb mat-vecs of an apply form a dependent chain (y_j needs
-// all of y_{j-1}); as separate launches every link pays the launch hand-over AFTER its matrix has been
-// streamed.  Here a wave keeps its row index for the whole chain and requests the NEXT block's row (10 KB from
-// HBM, independent of the chain) before it waits at the grid barrier that completes the CURRENT vector: the
-// stream of one link overlaps the synchronisation of the previous one.  Barrier and visibility as in
-// k_year_persistent (nk2d_kernels.hip): vectors are stored write-through and loaded L1-bypassing (agent-scope
-// relaxed atomics), every wave drains its stores before the workgroup joins, one lane arrives and polls; one
-// arrival counter per system; spins are bounded, a timeout raises the abort flag.  Rows of at most
-// 64 * PC_GEMV_CHUNK double2 (m <= 1280), even m.
-// ---------------------------------------------------------------------------------------------------
-#define PC_SPIN_LIMIT 4000000
-
-__device__ __forceinline__ double pc_ld(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void pc_st(double* p, double v) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void __launch_bounds__(256, 3) k_pc_subst(PcDev P, const double* __restrict__ sinv, size_t mstride,
-                                                  double* __restrict__ yv, double* __restrict__ xv, size_t vstride,
-                                                  unsigned* __restrict__ arrive, int* __restrict__ abort_flag) {
-    __shared__ double xs[2 * 64 * PC_GEMV_CHUNK];
-    __shared__ int lds_ok;
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int tr = blockIdx.y;
-    const int m = P.m, nb = P.nb, m2 = m >> 1;
-    const bool live = r < m;
-    const size_t mm = (size_t)m * m;
-    const double* M = sinv + (size_t)tr * mstride;
-    double* Y = yv + (size_t)tr * vstride;
-    double* X = xv + (size_t)tr * vstride;
-    unsigned* cnt = arrive + tr;
-    const unsigned nwg = gridDim.x;
-    unsigned epoch = 0;
-    const int slot = live ? r / P.nz : 0, k = live ? r - slot * P.nz : 0;
-
-    auto barrier = [&]() -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned target = (epoch + 1u) * nwg;
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int good = 1;
-            long long spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (++spins > PC_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    good = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            lds_ok = good;
-        }
-        __syncthreads();
-        ++epoch;
-        return lds_ok != 0;
-    };
-    auto load_row = [&](const double* blk, double2 (&mv)[PC_GEMV_CHUNK]) {
-        const double2* row2 = reinterpret_cast<const double2*>(blk + (size_t)(live ? r : 0) * m);
-#pragma unroll
-        for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
-            const int c = lane + 64 * q;
-            mv[q] = (live && c < m2) ? row2[c] : make_double2(0.0, 0.0);
-        }
-    };
-    // the vector of block jv into LDS (every workgroup needs all of it), then this wave's dot product
-    auto dot_with = [&](const double* vec, const double2 (&mv)[PC_GEMV_CHUNK]) -> double {
-        __syncthreads();   // the previous use of xs is over
-        for (int i = threadIdx.x; i < m; i += blockDim.x) xs[i] = pc_ld(vec + i);
-        __syncthreads();
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
-            const int c = lane + 64 * q;
-            const double x0 = (c < m2) ? xs[2 * c] : 0.0, x1 = (c < m2) ? xs[2 * c + 1] : 0.0;
-            acc[(2 * q) & 3] = __builtin_fma(mv[q].x, x0, acc[(2 * q) & 3]);
-            acc[(2 * q + 1) & 3] = __builtin_fma(mv[q].y, x1, acc[(2 * q + 1) & 3]);
-        }
-        return wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-    };
-
-    double2 cur[PC_GEMV_CHUNK], nxt[PC_GEMV_CHUNK];
-    // forward: y_0 = r_0;  y_j = r_j - l_j (Sinv_{j-1} y_{j-1})
-    if (live && lane == 0) pc_st(Y + r, pc_ld(X + r));
-    load_row(M, cur);                                   // Sinv_0, on its way while y_0 completes
-    if (!barrier()) return;
-    for (int j = 1; j < nb; ++j) {
-        if (j + 1 < nb) load_row(M + (size_t)j * mm, nxt);            // Sinv_j for the next link
-        else load_row(M + (size_t)(nb - 1) * mm, nxt);               // first link of the backward sweep
-        const double sum = dot_with(Y + (size_t)(j - 1) * m, cur);
-        if (live && lane == 0) {
-            const size_t at = (size_t)j * m + r;
-            pc_st(Y + at, pc_ld(X + at) - lat_l(P, slot, k, j) * sum);
-        }
-#pragma unroll
-        for (int q = 0; q < PC_GEMV_CHUNK; ++q) cur[q] = nxt[q];
-        if (!barrier()) return;
-    }
-    if (nb == 1) load_row(M, cur);
-    // backward: x_j = Sinv_j a_j with a_j = y_j - U_j x_{j+1} left behind by the link before
-    for (int j = nb - 1; j >= 0; --j) {
-        if (j > 0) load_row(M + (size_t)(j - 1) * mm, nxt);
-        const double sum = dot_with(Y + (size_t)j * m, cur);
-        if (live && lane == 0) {
-            pc_st(X + (size_t)j * m + r, sum);
-            if (j > 0) {
-                const size_t at = (size_t)(j - 1) * m + r;
-                pc_st(Y + at, pc_ld(Y + at) - lat_u(P, slot, k, j - 1) * sum);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < PC_GEMV_CHUNK; ++q) cur[q] = nxt[q];
-        if (j > 0 && !barrier()) return;
-    }
-}
-
 // dense mat-vec with the block-Thomas epilogues; one wave per row, eight 512-byte requests per wave in flight
 //   mode 0 (forward):  out[r] = rhs[r] - l[r] * sum_c M[r][c] a[c]
 //   mode 1 (backward): out[r] = x_j[r] = sum_c M[r][c] a[c], where a = y_j - U_j x_{j+1} was left behind by the
@@ -791,27 +669,6 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     const dim3 blk(256), grd((m + 3) / 4, nsys);
     // even m (16-byte aligned rows) and a vector that fits the LDS staging: the wide kernel
     const bool wide = !c->pc_valu && (m % 2 == 0) && m <= PC_GEMV_XMAX;
-    if (wide && !c->pc_chain_off && m <= 2 * 64 * PC_GEMV_CHUNK) {
-        // the whole chain in one cooperative launch (k_pc_subst); rejected when the grid is not resident at once
-        if (!c->PC_SYNC) NK2D_CHECK(c, hipMalloc((void**)&c->PC_SYNC, 256));
-        NK2D_CHECK(c, hipMemsetAsync(c->PC_SYNC, 0, 256, c->stream));
-        unsigned* arrive = (unsigned*)c->PC_SYNC;
-        int* abort_flag = (int*)((char*)c->PC_SYNC + 128);
-        size_t ms_ = mstride, vs_ = vstride;
-        const double* sinv_ = sinv;
-        void* args[] = {&D, &sinv_, &ms_, &yv, &xv, &vs_, &arrive, &abort_flag};
-        const hipError_t rc = hipLaunchCooperativeKernel((const void*)k_pc_subst, grd, blk, args, 0, c->stream);
-        if (rc == hipSuccess) {
-            int aborted = 0;
-            NK2D_CHECK(c, hipMemcpyAsync(&aborted, abort_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-            if (aborted) return nk2d_fail(c, "nk2d_precond_apply: a grid barrier of the block substitution timed out", -6);
-            return 0;
-        }
-        (void)hipGetLastError();
-        if (rc != hipErrorCooperativeLaunchTooLarge) NK2D_CHECK(c, rc);
-        c->pc_chain_off = 1;    // does not fit the chip at once: launch per link from now on
-    }
     // y_0 = r_0
     for (int sys = 0; sys < nsys; ++sys)
         NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,

@@ -15,9 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 416
 eng = iage_engine(Grid2d.default(n, n))
 v = eng.upload(np.random.default_rng(0).standard_normal((2, n, n)))
 res = {}
-for valu, chain in ((1, 0), (0, 0), (0, 1), (1, 0), (0, 0), (0, 1)):
+for valu, chain in ((1, 0), (0, 0), (1, 0), (0, 0)):
     eng.set_option("pc_valu", valu)
-    eng.set_option("pc_chain", chain)
     t0 = time.perf_counter()
     eng.precond_setup()
     eng.sync()
@@ -28,10 +27,10 @@ for valu, chain in ((1, 0), (0, 0), (0, 1), (1, 0), (0, 0), (0, 1)):
     for _ in range(5):
         eng.precond_apply(v, out=out)
     ms = eng.timer_end() / 5
-    res[(valu, chain)] = eng.download(out)
+    res[(valu, 0)] = eng.download(out)
     nbytes = 2.0 * n * 2 * (3 * n) ** 2 * 8.0
-    print(f"pc_valu={valu} pc_chain={chain}: setup {setup:.3f} s, apply {ms:.3f} ms = {nbytes / ms / 1e6:.0f} GB/s "
+    print(f"pc_valu={valu}: setup {setup:.3f} s, apply {ms:.3f} ms = {nbytes / ms / 1e6:.0f} GB/s "
           f"({nbytes / ms / 1e6 / 8000:.3f} of the HBM peak)", flush=True)
-for key in ((0, 0), (0, 1)):
+for key in ((0, 0),):
     print("apply results,", key, "vs round-1 kernels: max rel diff",
           float(np.max(np.abs(res[key] - res[(1, 0)])) / np.max(np.abs(res[(1, 0)]))))
