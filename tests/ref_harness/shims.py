@@ -251,7 +251,7 @@ class Dataset:
 class DataArray:
     def __init__(self, data, dims=None, **_):
         self.values = np.array(data, dtype=float, copy=True)
-        self.dims = tuple(dims) if dims is not None else ()
+        self.dims = (dims,) if isinstance(dims, str) else (tuple(dims) if dims is not None else ())
 
     shape = property(lambda self: self.values.shape)
 
