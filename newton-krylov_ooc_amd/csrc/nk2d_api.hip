@@ -322,6 +322,9 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->F, c->nv));
     NK2D_TRY(dev_alloc(c, &c->Z, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->ZP, 3 * c->nv));
+    NK2D_TRY(dev_alloc(c, &c->ZN, 3 * c->nv));
+    c->single_swap = 0;
+    c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));
     NK2D_TRY(dev_alloc(c, &c->BCR, c->nv));
@@ -365,6 +368,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hRED, sizeof(double) * 4096));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART2, sizeof(double) * c->ncol));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hPARTB, sizeof(double) * c->ncol));
     c->part_on_host = 0;
     c->speculate = 1;
     c->factor_pending = 0;
@@ -477,7 +481,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     nk2d_precond_free(c);
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
-                      c->YOLD, c->F, c->Z, c->ZP, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
+                      c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF,
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN,
                       c->SMSREC, c->RESTREC};
@@ -501,6 +505,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->hRED) (void)hipHostFree(c->hRED);
     if (c->hPART) (void)hipHostFree(c->hPART);
     if (c->hPART2) (void)hipHostFree(c->hPART2);
+    if (c->hPARTB) (void)hipHostFree(c->hPARTB);
     if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
     if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
     if (c->hCTL) (void)hipHostFree(c->hCTL);

@@ -70,6 +70,11 @@ struct nk2d_ctx {
     double* KV[5];
     // Radau work vectors (nv each unless noted)
     double *Y, *YOLD, *F, *Z /*3nv*/, *ZP /*3nv*/, *W /*3nv*/;
+    // third stage buffer: a simplified-Newton iteration whose solve needs ONE sweep runs as a single launch
+    // (stage + sweep + update); its update writes the new stage values here while the neighbouring columns still read
+    // the old ones from Z in the same launch, then Z and ZN swap
+    double* ZN /*3nv*/;
+    int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
     double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
@@ -99,6 +104,8 @@ struct nk2d_ctx {
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
     double* hPART2;  // same, for an error estimate queued behind a Newton iteration not yet judged
+    double* hPARTB;  // same, second buffer for Newton iterations queued one ahead of the one being judged
+    double* part_cur;  // where the next fused launch with the update puts its partials (null: hPART / PART)
     int part_on_host;
     int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch
     double lu_cre, lu_ccr, lu_cci;  // shifts of the current line factorisation
@@ -491,6 +498,7 @@ int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);
 int nk2d_sweeps_for(nk2d_ctx* c, double c_real);
+bool nk2d_has_lateral(const nk2d_ctx* c);
 int nk2d_profile_collect(nk2d_ctx* c);
 int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2);
 int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,

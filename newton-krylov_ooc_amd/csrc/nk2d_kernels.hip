@@ -943,12 +943,18 @@ int nk2d_sweeps_for(nk2d_ctx* c, double c_real) {
     if (rho <= 0.0) return 1;  // no horizontal coupling: the line solve is exact
     if (rho >= 0.999) return 400;
     int m = (int)std::ceil(std::log(c->d.lin_tol) / std::log(rho));
-    // at least two sweeps whenever there is lateral coupling: with one, the stage part and the update
-    // would share a launch, and the update of one column would race with the stage reads of its
-    // neighbours (a single launch is only used when the columns do not couple at all, rho = 0)
-    if (m < 2) m = 2;
+    // m = 1 (rho <= lin_tol: short steps) is a Newton iteration in ONE launch; its update writes the spare stage
+    // buffer ZN so that it cannot race with the stage reads of the neighbouring columns (nk2d_r_newton_fused).
+    // The integrator raises this to two where it cannot swap buffers (device-side decisions, set_lu).
+    if (m < 1) m = 1;
     if (m > 400) m = 400;
     return m;
+}
+
+bool nk2d_has_lateral(const nk2d_ctx* c) {
+    for (double rho : c->rho_tab)
+        if (rho > 0.0) return true;
+    return false;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1181,6 +1187,7 @@ __global__ void k_attempt_setup(DevP P, VmixArgs V, int nblk_vmix, PredictArgs A
 // f_complex = F^T TI_COMPLEX - M_complex (W1 + i W2)  (radau.py:104-111)
 struct StageArgs {
     const double *y, *z, *w;
+    double* zout;            // where the update writes Z = T W (z itself, or the spare buffer of a single-launch iteration)
     const double* kv[3];
     double *br, *bcr, *bci;
     size_t nv;
@@ -1421,7 +1428,7 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
     acc = wave_sum(acc);
     if (lane == 0) st_mp<MP>(A.part + task, acc);
     double* wout = const_cast<double*>(A.st.w);
-    double* zout = const_cast<double*>(A.st.z);
+    double* zout = A.st.zout;
     store_col<E>(wout, task, lane, w0);
     store_col<E>(wout + A.st.nv, task, lane, w1);
     store_col<E>(wout + 2 * A.st.nv, task, lane, w2);
@@ -1813,6 +1820,10 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
                         double mci, int src, bool delta) {
     FusedArgs A = {};
     A.st.y = c->Y; A.st.z = c->Z; A.st.w = c->W;
+    // stage and update in ONE launch (single-sweep solve): the update must not overwrite stage values the
+    // neighbouring columns are still reading -- it writes the spare buffer, the buffers swap after the launch
+    const bool swap_z = do_stage && do_update && c->single_swap;
+    A.st.zout = swap_z ? c->ZN : c->Z;
     A.st.kv[0] = c->KV[0]; A.st.kv[1] = c->KV[1]; A.st.kv[2] = c->KV[2];
     A.st.br = c->BR; A.st.bcr = c->BCR; A.st.bci = c->BCI;
     A.st.nv = c->nv; A.st.mreal = mreal; A.st.mcr = mcr; A.st.mci = mci;
@@ -1821,7 +1832,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     A.sw.xr_old = c->XR[src]; A.sw.xcr_old = c->XCR[src]; A.sw.xci_old = c->XCI[src];
     A.sw.xr_new = c->XR[1 - src]; A.sw.xcr_new = c->XCR[1 - src]; A.sw.xci_new = c->XCI[1 - src];
     A.sw.first = first ? 1 : 0;
-    A.part = c->part_on_host ? c->hPART : c->PART;
+    A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : c->PART;
     A.do_stage = do_stage ? 1 : 0;
     A.do_update = do_update ? 1 : 0;
     A.delta = delta ? 1 : 0;
@@ -1868,6 +1879,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     }
     NK2D_CHECK(c, hipGetLastError());
+    if (swap_z) std::swap(c->Z, c->ZN);
     c->st.nlaunch++;
     c->st.nsweeps++;
     return 0;
@@ -2007,7 +2019,7 @@ int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out) {
 #define NK2D_SPIN_LIMIT 4000000
 
 struct YearArgs {
-    double *Y, *YOLD, *F, *Z, *ZP, *W;
+    double *Y, *YOLD, *F, *Z, *ZP, *ZN, *W;
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP;
     double* KV[4];
     SweepArgs fac;             // Jacobian planes + factor pointers (the other members are set per phase)
@@ -2139,11 +2151,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
     const size_t nv = (size_t)P.ncol * (E * 64);
 
     // buffers that swap roles: parities, the pointers are selected where they are used
-    int swapY = 0, swapZ = 0, swapKV = 0;
+    // the three stage buffers rotate: current iterate, previous step's (dense output), spare (single-launch iterations)
+    int swapY = 0, swapKV = 0, zc = 0, zp = 1, zn = 2;
+#define YR_ZBUF(i) (((i) == 0) ? A.Z : (((i) == 1) ? A.ZP : A.ZN))
 #define YR_Y (swapY ? A.YOLD : A.Y)
 #define YR_YOLD (swapY ? A.Y : A.YOLD)
-#define YR_Z (swapZ ? A.ZP : A.Z)
-#define YR_ZP (swapZ ? A.Z : A.ZP)
+#define YR_Z YR_ZBUF(zc)
+#define YR_ZP YR_ZBUF(zp)
+#define YR_ZN YR_ZBUF(zn)
 #define YR_KV2 (swapKV ? A.KV[3] : A.KV[2])
 #define YR_KV3 (swapKV ? A.KV[2] : A.KV[3])
     // controller state (identical in every wave)
@@ -2251,6 +2266,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
                         const bool do_factor = factor_pending && it == 0;
                         FusedArgs FA = {};
                         FA.st.y = YR_Y; FA.st.z = YR_Z; FA.st.w = A.W;
+                        // a single-sweep solve is ONE phase: its update writes the spare buffer (the neighbours still
+                        // read the old stage values in this phase), then the buffers swap
+                        FA.st.zout = (do_stage && do_update) ? YR_ZN : YR_Z;
                         FA.st.kv[0] = A.KV[0]; FA.st.kv[1] = A.KV[1]; FA.st.kv[2] = YR_KV2;
                         FA.st.br = A.BR; FA.st.bcr = A.BCR; FA.st.bci = A.BCI;
                         FA.st.nv = nv; FA.st.mreal = mreal; FA.st.mcr = mcr; FA.st.mci = mci;
@@ -2283,6 +2301,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
                         ++nsweeps;
                         if (it == 0) factor_pending = false;
                         src = 1 - src;
+                        if (do_stage && do_update) { const int tmp = zc; zc = zn; zn = tmp; }
                         YEAR_SYNC()
                     }
                     nsolve += 2; nfev += 3; ++nnewton;
@@ -2436,7 +2455,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
         }
         if (col_wave) commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV3, YR_YOLD, A.F, wave, lane);
         swapY ^= 1;
-        swapZ ^= 1;
+        { const int tmp = zc; zc = zp; zp = tmp; }
         have_dense = true; dense_t_old = t; dense_h = uni_d(t_new - t);
         t = t_new;
         ++nsteps; ++nfev;
@@ -2457,7 +2476,7 @@ finish:
         double* o = A.out;
         o[0] = (double)status; o[1] = t; o[2] = (double)nfev; o[3] = (double)njev; o[4] = (double)nlu;
         o[5] = (double)nsteps; o[6] = (double)nrejected; o[7] = (double)nnewton; o[8] = (double)nsolve;
-        o[9] = (double)nsweeps; o[10] = (double)nrec; o[11] = (double)swapY; o[12] = (double)swapZ;
+        o[9] = (double)nsweeps; o[10] = (double)nrec; o[11] = (double)swapY; o[12] = (double)(zc + 4 * zp + 16 * zn);
         o[13] = (double)swapKV; o[14] = 8.0 * words; o[15] = (double)bar.epoch; o[16] = t_jac;
     }
 #undef YEAR_SYNC
@@ -2466,6 +2485,8 @@ finish:
 #undef YR_YOLD
 #undef YR_Z
 #undef YR_ZP
+#undef YR_ZN
+#undef YR_ZBUF
 #undef YR_KV2
 #undef YR_KV3
 #undef YEAR_PART
@@ -2490,11 +2511,12 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         c->yr_rec_cap = 0;
         c->YR_REC = nullptr;
     }
+    const int min_sweeps = 1;
     if (c->yr_lin_tol != c->d.lin_tol) {
         // sweeps per shift bucket with the host's arithmetic (nk2d_sweeps_for), looked up on the device
         std::vector<int> mtab(c->rho_tab.size());
         for (size_t k = 0; k < mtab.size(); ++k)
-            mtab[k] = nk2d_sweeps_for(c, c->rho_c0 * std::pow(10.0, ((double)k + 0.5) * c->rho_dlog));
+            mtab[k] = std::max(nk2d_sweeps_for(c, c->rho_c0 * std::pow(10.0, ((double)k + 0.5) * c->rho_dlog)), min_sweeps);
         if (!mtab.empty())
             NK2D_CHECK(c, hipMemcpy(c->YR_MTAB, mtab.data(), sizeof(int) * mtab.size(), hipMemcpyHostToDevice));
         c->yr_lin_tol = c->d.lin_tol;
@@ -2506,7 +2528,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     }
     NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 8192, c->stream));
     YearArgs A = {};
-    A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.W = c->W;
+    A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.ZN = c->ZN; A.W = c->W;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
     for (int i = 0; i < 2; ++i) { A.XR[i] = c->XR[i]; A.XCR[i] = c->XCR[i]; A.XCI[i] = c->XCI[i]; }
     A.TMP = c->TMP;
@@ -2539,7 +2561,11 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     const int status = (int)o[0];
     // the buffers swapped roles on the device an odd or even number of times
     if ((int)o[11]) std::swap(c->Y, c->YOLD);
-    if ((int)o[12]) std::swap(c->Z, c->ZP);
+    {   // the three stage buffers in the roles the device left them in
+        double* bufs[3] = {c->Z, c->ZP, c->ZN};
+        const int code = (int)o[12];
+        c->Z = bufs[code & 3]; c->ZP = bufs[(code >> 2) & 3]; c->ZN = bufs[(code >> 4) & 3];
+    }
     if ((int)o[13]) std::swap(c->KV[2], c->KV[3]);
     c->st.nfev += (int64_t)o[2]; c->st.njev += (int64_t)o[3]; c->st.nlu += (int64_t)o[4];
     c->st.nsteps += (int64_t)o[5]; c->st.nrejected += (int64_t)o[6]; c->st.nnewton += (int64_t)o[7];

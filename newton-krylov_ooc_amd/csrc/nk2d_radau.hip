@@ -75,6 +75,12 @@ int set_lu(Ctl& s, double h) {
     s.have_lu = true;
     s.m_real = nk2d_sweeps_for(s.c, MU_REAL / h);
     s.m_cplx = nk2d_sweeps_for(s.c, MU_CR / h);
+    if (!s.c->single_swap && nk2d_has_lateral(s.c)) {
+        // device-side decisions: a launch may return at entry, the host cannot swap stage buffers behind it, and an
+        // in-place single launch would let the update of one column race with the stage reads of its neighbours
+        s.m_real = std::max(s.m_real, 2);
+        s.m_cplx = std::max(s.m_cplx, 2);
+    }
     s.c->st.nlu += 2;
     // the factorisation itself happens inside the first fused Newton launch that needs it
     s.c->lu_cre = MU_REAL / h; s.c->lu_ccr = MU_CR / h; s.c->lu_cci = MU_CI / h;
@@ -192,61 +198,92 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
            int* err_buf = nullptr) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+    const bool single = std::max(s.m_real, s.m_cplx) == 1;   // the whole iteration is ONE launch
     double dW_norm_old = 0.0, rate = 0.0;
     bool has_old = false, has_rate = false;
     *converged = false;
     const int kmax = force_iters >= 0 ? force_iters : NEWTON_MAXITER;
     const bool speculate = c->part_on_host && force_iters < 0 && c->speculate;
-    bool front_queued = false;
+    // work queued ahead of the verdict on the iteration before: the launches before the last one (several sweeps),
+    // or the whole next iteration (single launch: its update goes to the spare stage buffer and to the other
+    // partial buffer, so an unwanted one is dropped by swapping the stage buffers back)
+    bool front_queued = false, whole_queued = false;
     if (err_buf) *err_buf = -1;
     int k = -1;
+    auto part_of = [&](int it) { return (single && (it & 1)) ? c->hPARTB : c->hPART; };
+    auto event_of = [&](int it) { return single ? c->snap_ev[2 + (it & 1)] : c->snap_ev[0]; };
     for (k = 0; k < kmax; ++k) {
         if (err_buf) *err_buf = -1;   // an estimate queued behind a non-final iteration is void
-        const bool timed = !front_queued;   // front and back launches are queued back to back
-        if (timed) {
-            NK2D_TRY(nk2d_prof_window_begin(c));
-            NK2D_TRY(newton_front(s, mreal, mcr, mci));
+        if (!whole_queued) {
+            const bool timed = !front_queued;   // front and back launches are queued back to back
+            if (timed) {
+                NK2D_TRY(nk2d_prof_window_begin(c));
+                NK2D_TRY(newton_front(s, mreal, mcr, mci));
+            }
+            front_queued = false;
+            c->part_cur = c->part_on_host ? part_of(k) : nullptr;
+            NK2D_TRY(newton_back(s, mreal, mcr, mci));
+            if (timed) NK2D_TRY(nk2d_prof_window_end(c));
+            if (speculate) NK2D_CHECK(c, hipEventRecord(event_of(k), c->stream));
         }
-        front_queued = false;
-        NK2D_TRY(newton_back(s, mreal, mcr, mci));
-        if (timed) NK2D_TRY(nk2d_prof_window_end(c));
+        whole_queued = false;
         c->st.nfev += 3;
         c->st.nnewton++;
         if (force_iters >= 0) continue;
         double sum = 0.0;
+        bool spec_whole = false;
         if (speculate) {
-            NK2D_CHECK(c, hipEventRecord(c->snap_ev[0], c->stream));
-            // queue the next iteration's front launches unless the last known contraction rate says
-            // that the iteration now in flight will pass SciPy's convergence test
+            // queue the next iteration unless the last known contraction rate says that the iteration now in
+            // flight will pass SciPy's convergence test
             bool likely_last = false;
             if (has_rate && rate < 1.0) {
                 const double next_norm = rate * dW_norm_old;
                 likely_last = rate / (1.0 - rate) * next_norm < s.newton_tol;
             }
             if (k + 1 < kmax && !likely_last) {
-                NK2D_TRY(newton_front(s, mreal, mcr, mci));
-                front_queued = true;
+                if (single) {
+                    c->part_cur = part_of(k + 1);
+                    NK2D_TRY(newton_back(s, mreal, mcr, mci));
+                    NK2D_CHECK(c, hipEventRecord(event_of(k + 1), c->stream));
+                    spec_whole = true;
+                } else {
+                    NK2D_TRY(newton_front(s, mreal, mcr, mci));
+                    front_queued = true;
+                }
             } else if (likely_last && err_buf && s.m_real <= 2) {
                 NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, c->hPART2));
                 NK2D_CHECK(c, hipEventRecord(c->snap_ev[1], c->stream));
             }
-            NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[0]));
-            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, nullptr));
+            NK2D_CHECK(c, hipEventSynchronize(event_of(k)));
+            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, part_of(k)));
         } else {
             NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
         }
         couple(c, &sum);
         const double dW_norm = rms_from_sum(sum, 3.0 * s.n_total);
-        if (!(dW_norm == dW_norm)) break;  // NaN: treat as divergence
-        if (has_old) { rate = dW_norm / dW_norm_old; has_rate = true; }
-        if (has_rate && (rate >= 1.0 || std::pow(rate, NEWTON_MAXITER - k) / (1.0 - rate) * dW_norm > s.newton_tol)) break;
-        if (dW_norm == 0.0 || (has_rate && rate / (1.0 - rate) * dW_norm < s.newton_tol)) {
+        bool stop = false;
+        if (!(dW_norm == dW_norm)) stop = true;  // NaN: treat as divergence
+        if (!stop) {
+            if (has_old) { rate = dW_norm / dW_norm_old; has_rate = true; }
+            if (has_rate && (rate >= 1.0 || std::pow(rate, NEWTON_MAXITER - k) / (1.0 - rate) * dW_norm > s.newton_tol)) stop = true;
+        }
+        if (!stop && (dW_norm == 0.0 || (has_rate && rate / (1.0 - rate) * dW_norm < s.newton_tol))) {
             *converged = true;
+            stop = true;
+        }
+        if (stop) {
+            if (spec_whole) {
+                // the iteration queued ahead is not wanted: its stage values sit in the spare buffer, swap back
+                std::swap(c->Z, c->ZN);
+                c->st.nsolve -= 2;
+            }
             break;
         }
+        whole_queued = spec_whole;
         dW_norm_old = dW_norm;
         has_old = true;
     }
+    c->part_cur = nullptr;
     if (force_iters >= 0) { *converged = true; *n_iter = force_iters; }
     else *n_iter = k + 1;
     *rate_out = rate;
@@ -595,6 +632,13 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         ~PartGuard() { c->part_on_host = 0; }
     } part_guard{c};
     c->part_on_host = (s.device_ctl == 0 && !replay) ? 1 : 0;
+    // single-launch Newton iterations (one-sweep solves) swap stage buffers on the host: host-side decisions and
+    // step replay only
+    struct SwapGuard {
+        nk2d_ctx* c;
+        ~SwapGuard() { c->single_swap = 0; c->part_cur = nullptr; }
+    } swap_guard{c};
+    c->single_swap = (s.device_ctl == 0) ? 1 : 0;
     // A free-running year checks the convergence of every simplified Newton iteration on the iterates
     // themselves, inexact inner solves included.  A replayed schedule dictates the iteration counts of an
     // integrator with direct solves, so there the inner solves must not be what limits the accuracy.
