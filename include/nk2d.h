@@ -277,7 +277,10 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    control, different -- shorter -- sequence of Newton iterations), "growth_cap" (> 0: largest
    growth factor of the step size after a step whose Newton iteration failed and was repeated with
    half the step; 1.0 is the rule of Hairer & Wanner's RADAU5, 0 = SciPy, which has none),
-   "sweep_wpb" */
+   "min_sweeps" (1, default: a solve whose contraction bound meets lin_tol after ONE sweep runs the whole simplified
+   Newton iteration as a single launch, its update written to a spare stage buffer; 2: at least two sweeps wherever
+   columns couple, the round-1 rule -- also what the device-side controllers 1 and 2 always use),
+   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "sweep_wpb" */
 int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);
 
 /* block until every operation queued on the context's stream has finished */

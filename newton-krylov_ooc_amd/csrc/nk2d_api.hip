@@ -131,6 +131,12 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "min_sweeps") {
+        if (value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: min_sweeps must be 1 or 2");
+        c->min_sweeps = (int)value;
+        c->yr_lin_tol = -1.0;   // the persistent kernel's sweep table is rebuilt
+        return 0;
+    }
     if (key == "factor_fp32") {
         // the single precision copy is written by the next factorisation: drop the cached one
         c->factor_fp32 = value != 0.0;
@@ -324,6 +330,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->ZP, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->ZN, 3 * c->nv));
     c->single_swap = 0;
+    c->min_sweeps = 1;
     c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));

@@ -74,6 +74,7 @@ struct nk2d_ctx {
     // (stage + sweep + update); its update writes the new stage values here while the neighbouring columns still read
     // the old ones from Z in the same launch, then Z and ZN swap
     double* ZN /*3nv*/;
+    int min_sweeps;    // least sweeps per solve where columns couple (option "min_sweeps": 1 default, 2 = round-1 rule)
     int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables

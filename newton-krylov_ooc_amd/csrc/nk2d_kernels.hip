@@ -2511,7 +2511,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         c->yr_rec_cap = 0;
         c->YR_REC = nullptr;
     }
-    const int min_sweeps = 1;
+    const int min_sweeps = (c->min_sweeps > 1 && nk2d_has_lateral(c)) ? 2 : 1;
     if (c->yr_lin_tol != c->d.lin_tol) {
         // sweeps per shift bucket with the host's arithmetic (nk2d_sweeps_for), looked up on the device
         std::vector<int> mtab(c->rho_tab.size());

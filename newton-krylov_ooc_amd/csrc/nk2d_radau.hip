@@ -75,7 +75,7 @@ int set_lu(Ctl& s, double h) {
     s.have_lu = true;
     s.m_real = nk2d_sweeps_for(s.c, MU_REAL / h);
     s.m_cplx = nk2d_sweeps_for(s.c, MU_CR / h);
-    if (!s.c->single_swap && nk2d_has_lateral(s.c)) {
+    if ((!s.c->single_swap || s.c->min_sweeps > 1) && nk2d_has_lateral(s.c)) {
         // device-side decisions: a launch may return at entry, the host cannot swap stage buffers behind it, and an
         // in-place single launch would let the update of one column race with the stage reads of its neighbours
         s.m_real = std::max(s.m_real, 2);
