@@ -494,6 +494,8 @@ int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out);
 int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part);
 int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part);
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv);
+int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
+                         double x0, double x1, double x2);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);

@@ -1661,6 +1661,74 @@ __global__ void __launch_bounds__(NK2D_BLOCK)
     commit_tend_body<E, KIND, 0>(P, y, z2, kvp, ynew, f, task, lane);
 }
 
+// The boundary between two steps in ONE launch: accepted step committed (y_new = y + Z2, f_new = fun(t_new, y_new)),
+// Jacobian planes at t_new (optional), and the next attempt's set-up (vertical mixing planes at its three stage times,
+// predicted stage values from the dense output of the step just taken).  Every piece reads only what the Newton
+// iteration left behind or what its own wave writes: the commit and the prediction of a column are the same wave
+// (the prediction reads the y_new that wave has just stored), the Jacobian of the modules served here does not depend
+// on the state, and the new planes / stage values go to buffers nobody reads in this launch.
+struct BoundaryArgs {
+    const double *y, *z2, *kv_new;     // commit: state and third stage value of the step taken, plane at t_new
+    double *ynew, *f;
+    double *JL, *JU, *JS, *JN, *JC;
+    int do_jac, nblk_vmix, nblk_jac;
+};
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V, BoundaryArgs B, PredictArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    int blk = blockIdx.x;
+    if (blk < B.nblk_vmix) {
+        const int task = blk * wpb + wave;
+        if (task < P.ny * 3) vmix_body<E>(P, V, task, lane);
+        return;
+    }
+    blk -= B.nblk_vmix;
+    if (blk < B.nblk_jac) {
+        const int task = blk * wpb + wave;
+        if (task < P.ny) jac_body<E, 0>(P, B.kv_new, B.JL, B.JU, B.JS, B.JN, B.JC, nullptr, nullptr, task, lane);
+        return;
+    }
+    blk -= B.nblk_jac;
+    const int task = blk * wpb + wave;
+    if (task >= P.ncol) return;
+    commit_tend_body<E, KIND, 0>(P, B.y, B.z2, B.kv_new, B.ynew, B.f, task, lane);
+    predict_body<E>(A, task, lane);
+}
+
+// commit of the step just taken + (optionally) the Jacobian at t_new + set-up of the attempt that starts at t_new
+// with stage times `times` (planes into out[0..2]) and dense-output abscissae x0..x2.  Buffers are taken in their
+// roles BEFORE the caller swaps them: y_new goes to YOLD, the predicted stage values to ZP.
+int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
+                         double x0, double x1, double x2) {
+    VmixArgs V;
+    for (int i = 0; i < 3; ++i) {
+        nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
+        V.out[i] = out[i];
+    }
+    vmix_forcing_args(c, 3, times, V);
+    V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
+    V.hw = c->d.vmix_half_width;
+    BoundaryArgs B;
+    B.y = c->Y; B.z2 = c->Z + 2 * c->nv; B.kv_new = kv_new; B.ynew = c->YOLD; B.f = c->F;
+    B.JL = c->JL; B.JU = c->JU; B.JS = c->JS; B.JN = c->JN; B.JC = c->JC;
+    B.do_jac = do_jac ? 1 : 0;
+    B.nblk_vmix = nk2d_grid(c->ny * 3);
+    B.nblk_jac = do_jac ? nk2d_grid(c->ny) : 0;
+    PredictArgs A;
+    A.y = c->YOLD; A.yold = c->Y; A.zp = c->Z; A.z = c->ZP; A.w = c->W;
+    A.nv = c->nv;
+    A.x0 = x0; A.x1 = x1; A.x2 = x2;
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol)),
+                                                         dim3(NK2D_BLOCK), 0, c->stream, P, V, B, A));
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
+}
+
 // sum((err / (atol + max(|y|, |y + Z2|) rtol))^2)  (radau.py:480-481)
 template <int E, int MP = 0>
 __device__ __forceinline__ void err_norm_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ z2p,
@@ -2167,6 +2235,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
     double h_lu = 0.0, t_jac = A.t0, dense_t_old = 0.0, dense_h = 0.0;
     int m_real = 1, m_cplx = 1;
     bool factor_pending = false;
+    bool pre_setup = false;      // the next attempt's planes and predicted stage values came with the commit phase
+    double pre_h = 0.0;
     double lu_cre = 0.0, lu_ccr = 0.0, lu_cci = 0.0;
     int nfev = 0, njev = 0, nlu = 0, nsteps = 0, nrejected = 0, nnewton = 0, nsolve = 0, nsweeps = 0, nrec = 0;
     double words = 0.0;
@@ -2210,8 +2280,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
             h = uni_d(t_new - t);
             t_new = uni_d(t_new);
             h_abs = fabs(h);
-            // stage planes at the three collocation times + predicted stage values (radau.py:445-448)
-            {
+            // stage planes at the three collocation times + predicted stage values (radau.py:445-448); the first
+            // attempt of a step normally got them in the commit phase of the step before
+            const bool have_setup = pre_setup && uni_b(h == pre_h);
+            pre_setup = false;
+            if (!have_setup) {
                 const double f0 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC0)));
                 const double f1 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC1)));
                 const double f2 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC2)));
@@ -2446,30 +2519,82 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
         }
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
-        if (uni_b(t + h == t_new)) {
-            swapKV ^= 1;        // the third stage plane is the plane at t_new
-        } else {
-            const double fr = uni_d(year_interp4(A.bld_t, A.bld_f, t_new));
-            for (int j = wave; j < P.ny; j += nwaves) vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, fr, YR_KV3, j, lane);
-            YEAR_SYNC()
+        const double h_abs_next = uni_d(h_abs * factor);
+        const bool jac_due = recompute_jac || (A.jac_fresh != 0);
+        bool fusedb = uni_b(t + h == t_new) && uni_b(t_new < A.t1);
+        double h2 = 0.0;
+        if (fusedb) {
+            const double min_step2 = 10.0 * fabs(nextafter(t_new, INFINITY) - t_new);
+            double h_abs2 = h_abs_next;
+            if (h_abs2 > A.max_step) h_abs2 = A.max_step;
+            else if (h_abs2 < min_step2) h_abs2 = min_step2;
+            double t_new2 = t_new + h_abs2;
+            if (t_new2 - A.t1 > 0) t_new2 = A.t1;
+            h2 = uni_d(t_new2 - t_new);
+            fusedb = uni_b(isfinite(h2) && h2 > 0.0);
         }
-        if (col_wave) commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV3, YR_YOLD, A.F, wave, lane);
-        swapY ^= 1;
-        { const int tmp = zc; zc = zp; zp = tmp; }
-        have_dense = true; dense_t_old = t; dense_h = uni_d(t_new - t);
-        t = t_new;
-        ++nsteps; ++nfev;
-        YEAR_SYNC()
-        if (recompute_jac) {
-            YEAR_JAC(YR_KV3)
+        if (fusedb) {
+            // ONE phase for the whole boundary: commit, Jacobian at t_new where due, and the next attempt's planes and
+            // predicted stage values (every piece reads what the Newton iteration left or what its own wave writes)
+            const double f0 = uni_d(year_interp4(A.bld_t, A.bld_f, t_new + (h2 * RC0)));
+            const double f1 = uni_d(year_interp4(A.bld_t, A.bld_f, t_new + (h2 * RC1)));
+            const double f2 = uni_d(year_interp4(A.bld_t, A.bld_f, t_new + (h2 * RC2)));
+            for (int task = wave; task < 3 * P.ny; task += nwaves) {
+                const int ti = task / P.ny, j = task - ti * P.ny;
+                vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2),
+                               (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV3), j, lane);
+            }
+            if (jac_due) { YEAR_JAC(YR_KV2) }      // the third stage plane is the plane at t_new
+            if (col_wave) {
+                commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV2, YR_YOLD, A.F, wave, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's y_new is in memory before it reads it back
+                PredictArgs PA;
+                PA.y = YR_YOLD; PA.yold = YR_Y; PA.zp = YR_Z; PA.z = YR_ZP; PA.w = A.W; PA.nv = nv;
+                PA.x0 = ((t_new + h2 * RC0) - t) / (t_new - t);
+                PA.x1 = ((t_new + h2 * RC1) - t) / (t_new - t);
+                PA.x2 = ((t_new + h2 * RC2) - t) / (t_new - t);
+                predict_body<E, 1>(PA, wave, lane);
+            }
+            swapKV ^= 1;
+            swapY ^= 1;
+            { const int tmp = zc; zc = zp; zp = tmp; }
+            have_dense = true; dense_t_old = t; dense_h = uni_d(t_new - t);
+            t = t_new;
+            ++nsteps; ++nfev;
             YEAR_SYNC()
-            t_jac = t; ++njev; current_jac = true;
+            pre_setup = true; pre_h = h2;
+            if (jac_due) {
+                t_jac = t; ++njev; current_jac = true;
+                if (!recompute_jac) have_lu = false;
+            } else {
+                current_jac = false;
+            }
         } else {
-            current_jac = false;
+            if (uni_b(t + h == t_new)) {
+                swapKV ^= 1;        // the third stage plane is the plane at t_new
+            } else {
+                const double fr = uni_d(year_interp4(A.bld_t, A.bld_f, t_new));
+                for (int j = wave; j < P.ny; j += nwaves) vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, fr, YR_KV3, j, lane);
+                YEAR_SYNC()
+            }
+            if (col_wave) commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV3, YR_YOLD, A.F, wave, lane);
+            swapY ^= 1;
+            { const int tmp = zc; zc = zp; zp = tmp; }
+            have_dense = true; dense_t_old = t; dense_h = uni_d(t_new - t);
+            t = t_new;
+            ++nsteps; ++nfev;
+            YEAR_SYNC()
+            if (recompute_jac) {
+                YEAR_JAC(YR_KV3)
+                YEAR_SYNC()
+                t_jac = t; ++njev; current_jac = true;
+            } else {
+                current_jac = false;
+            }
         }
         h_abs_old_s = h_abs_s; has_old_h = true;
         err_old_s = err; has_old_err = true;
-        h_abs_s = uni_d(h_abs * factor);
+        h_abs_s = h_abs_next;
     }
 finish:
     if (wave == 0 && lane == 0) {

@@ -44,6 +44,10 @@ struct Ctl {
     int m_real, m_cplx;  // sweeps per solve for the current h_lu
     int device_ctl;      // 0 host decisions, 1 device decisions + one read-back per attempt, 2 pipelined
     double n_total;      // number of unknowns (tc*nz*ny)
+    // the set-up of the next step's first attempt (stage planes, predicted stage values) and, where due, the Jacobian
+    // at its start were already queued with the commit of the step before (nk2d_r_step_boundary): for this (t, h)
+    bool pre_setup;
+    double pre_t, pre_h;
 };
 
 double rms_from_sum(double s, double count) { return std::sqrt(s) / std::sqrt(count); }
@@ -444,6 +448,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         if (c->jac_fresh && !s.current_jac) {
             // evaluating J costs two small launches here (SciPy pays a Python double loop and two
             // SuperLU factorisations, hence its reuse heuristics): never start a step on a stale J
+            // (normally done by the step boundary launch of the step before)
             NK2D_TRY(refresh_jac(s, t, true));
             c->st.njev++;
             s.current_jac = true;
@@ -465,12 +470,15 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             h_abs = std::fabs(h);
             // host control: planes and prediction of the first try in one launch
             bool predicted = false;
-            if (s.device_ctl == 0 && s.have_dense) {
+            if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
+                predicted = true;            // queued with the commit of the step before
+            } else if (s.device_ctl == 0 && s.have_dense) {
                 NK2D_TRY(setup_attempt(s, t, h));
                 predicted = true;
             } else {
                 NK2D_TRY(stage_planes(s, t, h));
             }
+            s.pre_setup = false;
             bool converged = false;
             double err_sum = 0.0;
             int buf = 0;
@@ -556,21 +564,71 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         }
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
-        if (t + h == t_new) std::swap(c->KV[3], c->KV[2]);  // stage-3 plane is the plane at t_new
-        else NK2D_TRY(eval_kv(c, t_new, 3));
-        NK2D_TRY(commit_step(s, t, t_new, true));
-        c->st.nfev++;
-        if (c->hist_n > 0) NK2D_TRY(nk2d_hist_sample(c, t, t_new, nrec == 1));
-        if (recompute_jac) {
-            NK2D_TRY(refresh_jac(s, t_new, true));
-            c->st.njev++;
-            s.current_jac = true;
+        const double h_abs_next = h_abs * factor;
+        // One launch for the whole boundary where nothing in between needs the host: the commit, the Jacobian at
+        // t_new when one is due (SciPy's recompute_jac, or the engines' Jacobian at every step start) and the set-up
+        // of the next step's first attempt, whose step size is known now.  Modules whose Jacobian reads the state,
+        // history sampling and the device-side controllers keep the separate launches.
+        const bool jac_due = recompute_jac || c->jac_fresh;
+        const bool jac_needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
+        bool fused = s.device_ctl == 0 && c->hist_n == 0 && t + h == t_new && t_new < s.t1 && !jac_needs_state;
+        double h2 = 0.0;
+        if (fused) {
+            // the next step's first attempt, as the top of this loop will compute it
+            const double min_step2 = 10.0 * std::fabs(std::nextafter(t_new, std::numeric_limits<double>::infinity()) - t_new);
+            double h_abs2 = h_abs_next;
+            if (h_abs2 > s.max_step) h_abs2 = s.max_step;
+            else if (h_abs2 < min_step2) h_abs2 = min_step2;
+            double t_new2 = t_new + h_abs2;
+            if (t_new2 - s.t1 > 0) t_new2 = s.t1;
+            h2 = t_new2 - t_new;
+            fused = std::isfinite(h2) && h2 > 0.0;
+        }
+        if (fused) {
+            double times[3], x[3];
+            for (int i = 0; i < 3; ++i) {
+                times[i] = t_new + (h2 * RC[i]);
+                x[i] = ((t_new + h2 * RC[i]) - t) / (t_new - t);
+            }
+            // planes: the third stage plane of this step IS the plane at t_new; the new stage planes go to the two
+            // stage buffers nobody needs any more and to the buffer of the plane at the old t
+            double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
+            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due, times, out, x[0], x[1], x[2]));
+            std::swap(c->KV[3], c->KV[2]);
+            std::swap(c->Y, c->YOLD);
+            std::swap(c->Z, c->ZP);
+            s.have_dense = true;
+            s.dense_t_old = t;
+            s.dense_h = t_new - t;
+            s.t = t_new;
+            c->st.nsteps++;
+            c->st.nfev++;
+            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2;
+            if (jac_due) {
+                s.t_jac = t_new;
+                c->st.njev++;
+                s.current_jac = true;
+                if (!recompute_jac) s.have_lu = false;   // the Jacobian at every step start drops the factorisation
+            } else {
+                s.current_jac = false;
+            }
         } else {
-            s.current_jac = false;
+            if (t + h == t_new) std::swap(c->KV[3], c->KV[2]);  // stage-3 plane is the plane at t_new
+            else NK2D_TRY(eval_kv(c, t_new, 3));
+            NK2D_TRY(commit_step(s, t, t_new, true));
+            c->st.nfev++;
+            if (c->hist_n > 0) NK2D_TRY(nk2d_hist_sample(c, t, t_new, nrec == 1));
+            if (recompute_jac) {
+                NK2D_TRY(refresh_jac(s, t_new, true));
+                c->st.njev++;
+                s.current_jac = true;
+            } else {
+                s.current_jac = false;
+            }
         }
         s.h_abs_old = s.h_abs; s.has_old_h = true;
         s.err_old = err; s.has_old_err = true;
-        s.h_abs = h_abs * factor;
+        s.h_abs = h_abs_next;
     }
     if (record_n) *record_n = nrec;
     if (record && nrec > record_cap) return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
@@ -625,6 +683,8 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     // hook (sharded module) and the state dependent modules keep the host-controlled loop
     const bool persistent = c->device_ctl == 3 && !replay && c->hist_n == 0 && !c->norm_hook && c->kind == 0;
     s.device_ctl = (c->device_ctl == 3) ? 0 : c->device_ctl;
+    s.pre_setup = false;
+    s.pre_t = s.pre_h = 0.0;
     // per-column partials go to pinned host memory while the host takes the decisions; the flag is
     // dropped on every way out of this function
     struct PartGuard {

@@ -30,12 +30,11 @@ DEFAULT_JAC_FRESH = 1
 DEFAULT_GROWTH_CAP = 0.0
 # Whole forward year in ONE persistent kernel (nk2d_set_option "device_ctl" 3: grid barriers between the phases,
 # SciPy's controller on the device) for grids of at most this many depth levels.  Measured against the host-controlled
-# launch-per-phase loop (tools/probe_persistent_sizes.py, profiles/r02_persistent_sizes.log): 1.48x at 26^2, 1.45x at
-# 52^2, 1.26x at 104^2, 1.07x at 208^2, 0.95x at 416^2 (7 levels per lane: the fused kernel spills inside the
-# persistent one and a launch boundary costs no more than a grid barrier).  Same phase functions,
-# same decisions; history sampling, sharded modules and the state dependent modules keep the host-controlled loop.
+# loop of the same build (tools/probe_persistent_sizes.py, profiles/r02_persistent_sizes.log): 1.25x at 26^2, 1.21x at
+# 52^2, 1.08x at 104^2, 0.98x at 208^2, 0.92x at 416^2.  Same phase functions, same decisions;
+# history sampling, sharded modules and the state dependent modules keep the host-controlled loop.
 # NK2D_DEVICE_CTL in the environment overrides (0 = host control everywhere).
-PERSISTENT_MAX_NZ = 256
+PERSISTENT_MAX_NZ = 128
 
 
 class Nk2dError(RuntimeError):
