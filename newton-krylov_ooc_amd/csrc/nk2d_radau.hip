@@ -567,11 +567,11 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         const double h_abs_next = h_abs * factor;
         // One launch for the whole boundary where nothing in between needs the host: the commit, the Jacobian at
         // t_new when one is due (SciPy's recompute_jac, or the engines' Jacobian at every step start) and the set-up
-        // of the next step's first attempt, whose step size is known now.  Modules whose Jacobian reads the state,
-        // history sampling and the device-side controllers keep the separate launches.
+        // of the next step's first attempt, whose step size is known now.  History sampling and the device-side
+        // controllers keep the separate launches.
         const bool jac_due = recompute_jac || c->jac_fresh;
         const bool jac_needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
-        bool fused = s.device_ctl == 0 && c->hist_n == 0 && t + h == t_new && t_new < s.t1 && !jac_needs_state;
+        bool fused = s.device_ctl == 0 && c->hist_n == 0 && t + h == t_new && t_new < s.t1;
         double h2 = 0.0;
         if (fused) {
             // the next step's first attempt, as the top of this loop will compute it
@@ -593,7 +593,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // planes: the third stage plane of this step IS the plane at t_new; the new stage planes go to the two
             // stage buffers nobody needs any more and to the buffer of the plane at the old t
             double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
-            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due, times, out, x[0], x[1], x[2]));
+            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due && !jac_needs_state, times, out, x[0], x[1], x[2]));
             std::swap(c->KV[3], c->KV[2]);
             std::swap(c->Y, c->YOLD);
             std::swap(c->Z, c->ZP);
@@ -605,6 +605,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             c->st.nfev++;
             s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2;
             if (jac_due) {
+                // a Jacobian that reads the state (phosphorus, forced with a sink threshold) needs y_new complete:
+                // its own launch, after the boundary
+                if (jac_needs_state) NK2D_TRY(refresh_jac(s, t_new, true));
                 s.t_jac = t_new;
                 c->st.njev++;
                 s.current_jac = true;
