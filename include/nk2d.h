@@ -280,7 +280,12 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    "min_sweeps" (1, default: a solve whose contraction bound meets lin_tol after ONE sweep runs the whole simplified
    Newton iteration as a single launch, its update written to a spare stage buffer; 2: at least two sweeps wherever
    columns couple, the round-1 rule -- also what the device-side controllers 1 and 2 always use),
-   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "sweep_wpb" */
+   "team" (1: the Newton-iteration launches run with one workgroup of four waves per column -- stages, real system,
+   complex system on waves of their own -- instead of one wave per column; same arguments, bit-identical results;
+   -1, the default: chosen per context, on for at most 512 columns of at least 5 levels per lane, where all teams fit
+   the chip at once), "xcd_map" (1: workgroup -> column mapping that gives every XCD a contiguous range of columns;
+   0 default -- no measurable gain at 416 x 416), "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs),
+   "sweep_wpb" */
 int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);
 
 /* block until every operation queued on the context's stream has finished */

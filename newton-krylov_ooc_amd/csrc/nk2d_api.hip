@@ -131,6 +131,12 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "xcd_map") { c->xcd_map = value != 0.0; return 0; }
+    if (key == "team") {   // -1: automatic (see nk2d_team_auto), 0 / 1: never / always
+        if (value != 0.0 && value != 1.0 && value != -1.0) return nk2d_fail(c, "nk2d_set_option: team must be -1, 0 or 1");
+        c->team = (value < 0.0) ? nk2d_team_auto(c) : (int)value;
+        return 0;
+    }
     if (key == "min_sweeps") {
         if (value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: min_sweeps must be 1 or 2");
         c->min_sweeps = (int)value;
@@ -331,6 +337,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->ZN, 3 * c->nv));
     c->single_swap = 0;
     c->min_sweeps = 1;
+    c->team = nk2d_team_auto(c);
+    c->xcd_map = 0;
     c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));

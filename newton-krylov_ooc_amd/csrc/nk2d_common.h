@@ -75,6 +75,8 @@ struct nk2d_ctx {
     // the old ones from Z in the same launch, then Z and ZN swap
     double* ZN /*3nv*/;
     int min_sweeps;    // least sweeps per solve where columns couple (option "min_sweeps": 1 default, 2 = round-1 rule)
+    int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
+    int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
     int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
@@ -196,6 +198,18 @@ static inline int nk2d_fail(nk2d_ctx* c, const std::string& msg, int code = -2) 
     return code;
 }
 
+// Whether the Newton-iteration launches run as column teams (k_newton_team: a workgroup of four waves per column) by
+// default.  A team wave holds at most 256 VGPRs, so the chip's 1024 SIMDs take 2048 of them at once: with more than
+// 512 columns the workgroups run in two rounds and the team loses against one wave per column (iage 416^2, 832 columns:
+// 22.5 against 16.4 us per launch); with up to 512 columns of at least five levels per lane it wins (one-tracer module
+// at 416^2: 12.4 against 14.2 us per launch, year 0.60 against 0.66 s); below that the launch floor decides either way.
+static inline int nk2d_team_auto(const nk2d_ctx* c) { return (c->ncol <= 512 && c->E >= 5) ? 1 : 0; }
+
+// grid of a kernel with TASK_PROLOGUE_XCD: tasks_per_block tasks per workgroup, rounded up to a multiple of the 8 XCDs
+static inline int nk2d_grid_xcd(int ntasks, int tasks_per_block) {
+    const int nblk = (ntasks + tasks_per_block - 1) / tasks_per_block;
+    return 8 * ((nblk + 7) / 8);
+}
 static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK - 1) / NK2D_WAVES_PER_BLOCK; }
 
 // run `stmt` with a compile-time constant EE equal to the runtime levels-per-lane

@@ -27,6 +27,7 @@ struct DevP {
     int f_sms, f_restore;
     double f_thres_r;
     size_t np;
+    int xcd;   // 1: XCD-contiguous column ranges (TASK_PROLOGUE_XCD), 0: workgroup b takes block b (option "xcd_map")
 };
 
 static DevP make_devp(const nk2d_ctx* c) {
@@ -41,6 +42,7 @@ static DevP make_devp(const nk2d_ctx* c) {
     p.csrc = c->d.const_src;
     p.atol = c->d.atol; p.rtol = c->d.rtol;
     p.guard = c->cur_guard;
+    p.xcd = c->xcd_map;
     p.ph_hs = c->d.phos_params[0]; p.ph_mu = c->d.phos_params[1]; p.ph_sig = c->d.phos_params[2];
     p.ph_rd = c->d.phos_params[3]; p.ph_rp = c->d.phos_params[4]; p.ph_vs = c->d.phos_params[5];
     p.LIGHT = c->LIGHT; p.UPR = c->UPR;
@@ -73,6 +75,16 @@ __constant__ double cE[3] = {-10.048809399827414, 1.382142733160748, -0.33333333
 #define TASK_PROLOGUE(ntasks)                                              \
     const int lane = threadIdx.x & 63;                                     \
     const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if (task >= (ntasks)) return;
+
+// XCD-aware variant for the kernels that read the neighbouring columns: workgroups go to the eight XCDs round-robin
+// (blockIdx % 8), each XCD with an L2 of its own.  Workgroup b works on the virtual block (b % 8) * (gridDim / 8) + b / 8,
+// so that one XCD owns a contiguous range of columns and a column's neighbours are fetched into the same L2 (all but
+// the eight range ends) instead of into two or three of them.  The grid must be a multiple of 8 (nk2d_grid_xcd).
+#define TASK_PROLOGUE_XCD(ntasks)                                                          \
+    const int lane = threadIdx.x & 63;                                                     \
+    const int vblk_ = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x; \
+    const int task = vblk_ * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
     if (task >= (ntasks)) return;
 
 // ---------------------------------------------------------------------------------
@@ -1444,8 +1456,369 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
 template <int E, int KIND, int FACTOR, int STAGE>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
     GUARD_RETURN(P.guard)
-    TASK_PROLOGUE(P.ncol)
+    TASK_PROLOGUE_XCD(P.ncol)
     newton_fused_body<E, KIND, FACTOR, STAGE, 0>(P, A, task, lane);
+}
+
+// ---------------------------------------------------------------------------------
+// Column team: the same launch as k_newton_fused -- same arguments, bit-identical results -- with one
+// WORKGROUP of four waves per column instead of one wave.  At 416 x 416 k_newton_fused is 416 waves on a
+// chip with 1024 SIMDs, each walking through some forty dependent column loads and five arithmetic
+// phases: it is bound by the latency of that chain, not by bytes.  The team cuts the chain:
+//   phase 1   waves 0..2: stage tendency F_i of stage i = wave (a third of the stage loads each);
+//             wave 3 fetches both line factorisations and W meanwhile: the complex one stays in its
+//             registers, the real one and W go to LDS for wave 0 and the update
+//   phase 2   wave 0: real right-hand side + real line solve; wave 3: the complex ones
+//   phase 3   waves 0..2: W_r += dW_r, Z_r = (T W)_r and the squared scaled increments of component r;
+//             wave 3 adds them up in k_newton_fused's order
+// F_i, dW and the squares travel through LDS.  The two roles live in disjoint branches on the (scalar)
+// wave index, so each is register-allocated on its own: one wave per column needs > 256 VGPRs at seven
+// levels per lane, a team wave fits 256 and two workgroups share a CU.  Every wave passes the same number
+// of barriers on either branch.  The arithmetic of every value is the one of newton_fused_body, operation
+// for operation, so either kernel can run any launch of a year.
+// ---------------------------------------------------------------------------------
+template <int E>
+struct TeamLds {
+    double F[3][E * 64];   // stage tendencies; later the squared scaled increments
+    double D[3][E * 64];   // dW of the real system, real and imaginary part of the complex one
+    double W[3][E * 64];   // W before the update (stage launches)
+    double a[E * 64], c[E * 64], inv[E * 64];   // real system: off-diagonals, pivot reciprocals (FACTOR: the diagonal)
+    double tab[NK2D_TAB * 64];
+};
+
+template <int E>
+__device__ __forceinline__ void lds_put(double* s, int lane, const double (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e * 64 + lane] = v[e];
+}
+template <int E>
+__device__ __forceinline__ void lds_get(const double* s, int lane, double (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s[e * 64 + lane];
+}
+
+template <int E, int KIND, int FACTOR, int STAGE>
+__global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs A) {
+    GUARD_RETURN(P.guard)
+    __shared__ TeamLds<E> S;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int task = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // see TASK_PROLOGUE_XCD
+    if (task >= P.ncol) return;
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    const bool stage = STAGE && A.do_stage;
+
+    if (w == 3) {
+        // =========================== complex system; supplier of the real one ===========================
+        double a[E], cc[E];
+        {
+            double jl[E], ju[E];
+            load_col<E>(A.sw.JL, j, lane, jl);
+            load_col<E>(A.sw.JU, j, lane, ju);
+            line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
+        }
+        cplx cinv[E], ctab[NK2D_TAB];
+        double dre[E];   // FACTOR: real part of the complex diagonal
+        if (stage) {
+            // what wave 0 and the update need, through LDS
+            double rinv[E], rtab[NK2D_TAB], w0[E];
+            if constexpr (FACTOR) {
+                double drr[E];
+                line_diag<E, KIND, 0>(P, A.sw.JC, tr, j, lane, A.sw.cre, drr);
+#pragma unroll
+                for (int e = 0; e < E; ++e) rinv[e] = drr[e];
+            } else if (A.sw.f32) {
+                load_col32<E>(A.sw.fr_inv32, task, lane, rinv);
+                load_tab32(A.sw.fr_tab32, task, lane, rtab);
+            } else {
+                load_col<E>(A.sw.fr_inv, task, lane, rinv);
+                load_tab<E>(A.sw.fr_tab, task, lane, rtab);
+            }
+            load_col<E>(A.st.w, task, lane, w0);
+            lds_put<E>(S.a, lane, a);
+            lds_put<E>(S.c, lane, cc);
+            lds_put<E>(S.inv, lane, rinv);
+            if constexpr (!FACTOR) {
+#pragma unroll
+                for (int i = 0; i < NK2D_TAB; ++i) S.tab[i * 64 + lane] = rtab[i];
+            }
+            lds_put<E>(S.W[0], lane, w0);
+        }
+        if constexpr (FACTOR) {
+            line_diag<E, KIND, 0>(P, A.sw.JC, tr, j, lane, A.sw.ccr, dre);
+        } else {
+            double t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
+            if (A.sw.f32) {
+                load_col32<E>(A.sw.fc_invr32, task, lane, t0);
+                load_col32<E>(A.sw.fc_invi32, task, lane, t1);
+                load_tab32(A.sw.fc_tabr32, task, lane, tr0);
+                load_tab32(A.sw.fc_tabi32, task, lane, ti0);
+            } else {
+                load_col<E>(A.sw.fc_invr, task, lane, t0);
+                load_col<E>(A.sw.fc_invi, task, lane, t1);
+                load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
+                load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) cinv[e] = c_make(t0[e], t1[e]);
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) ctab[i] = c_make(tr0[i], ti0[i]);
+        }
+        double fcr[E], fci[E];
+        if (stage) {
+            double w1[E], w2[E];
+            load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+            load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+            lds_put<E>(S.W[1], lane, w1);
+            lds_put<E>(S.W[2], lane, w2);
+            __syncthreads();   // barrier 1: stage tendencies are in LDS
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double f0 = S.F[0][e * 64 + lane], f1 = S.F[1][e * 64 + lane], f2 = S.F[2][e * 64 + lane];
+                double sr = 0.0, si = 0.0;
+                sr = sr + f0 * cTI[1][0];
+                si = si + f0 * cTI[2][0];
+                sr = sr + f1 * cTI[1][1];
+                si = si + f1 * cTI[2][1];
+                sr = sr + f2 * cTI[1][2];
+                si = si + f2 * cTI[2][2];
+                fcr[e] = sr - (A.st.mcr * w1[e] - A.st.mci * w2[e]);
+                fci[e] = si - (A.st.mcr * w2[e] + A.st.mci * w1[e]);
+            }
+            if (!A.do_update && !A.delta) {  // later sweeps read the right-hand sides back
+                store_col<E>(A.st.bcr, task, lane, fcr);
+                store_col<E>(A.st.bci, task, lane, fci);
+            }
+        } else if (A.delta) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { fcr[e] = 0.0; fci[e] = 0.0; }
+        } else {
+            load_col<E>(A.sw.bcr, task, lane, fcr);
+            load_col<E>(A.sw.bci, task, lane, fci);
+        }
+        if (!A.sw.first) {
+            double js[E], jn[E], xs[E], xn[E];
+            load_col<E>(A.sw.JS, j, lane, js);
+            load_col<E>(A.sw.JN, j, lane, jn);
+            load_col<E>(A.sw.xcr_old, cs_col, lane, xs);
+            load_col<E>(A.sw.xcr_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e]));
+            load_col<E>(A.sw.xci_old, cs_col, lane, xs);
+            load_col<E>(A.sw.xci_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
+            if constexpr (KIND == 1) {
+                double upr[E];
+                load_col<E>(P.UPR, j, lane, upr);
+                phos_couple<E>(P, tr, j, lane, A.sw.xcr_old, upr, fcr);
+                phos_couple<E>(P, tr, j, lane, A.sw.xci_old, upr, fci);
+            }
+        }
+        if constexpr (FACTOR) {
+            cplx d[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) d[e] = c_make(dre[e], ((lane * E + e) < P.nz) ? A.sw.cci : 0.0);
+            tridiag_factor<E, cplx>(a, cc, d, cinv, ctab, lane);
+            double re[E], im[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { re[e] = cinv[e].re; im[e] = cinv[e].im; }
+            store_col<E>(A.sw.fc_invr, task, lane, re);
+            store_col<E>(A.sw.fc_invi, task, lane, im);
+            double* pr = A.sw.fc_tabr + (size_t)task * (NK2D_TAB * 64) + lane;
+            double* pi = A.sw.fc_tabi + (size_t)task * (NK2D_TAB * 64) + lane;
+            double tre[NK2D_TAB], tim[NK2D_TAB];
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) { pr[i * 64] = ctab[i].re; pi[i * 64] = ctab[i].im; tre[i] = ctab[i].re; tim[i] = ctab[i].im; }
+            if (A.sw.f32) {
+                store_col32<E>(A.sw.fc_invr32, task, lane, re);
+                store_col32<E>(A.sw.fc_invi32, task, lane, im);
+                store_tab32(A.sw.fc_tabr32, task, lane, tre);
+                store_tab32(A.sw.fc_tabi32, task, lane, tim);
+            }
+        }
+        cplx r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane * E + e) < P.nz;
+            r[e] = c_make(valid ? fcr[e] : 0.0, valid ? fci[e] : 0.0);
+        }
+        tridiag_apply<E, cplx>(a, cc, cinv, ctab, r, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
+        if (!A.do_stage && A.delta) {  // correction of the first sweep's solution
+            double x1[E];
+            load_col<E>(A.sw.xcr_old, task, lane, x1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fcr[e] = x1[e] + fcr[e];
+            load_col<E>(A.sw.xci_old, task, lane, x1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fci[e] = x1[e] + fci[e];
+        }
+        if (!A.do_update) {
+            store_col<E>(A.sw.xcr_new, task, lane, fcr);
+            store_col<E>(A.sw.xci_new, task, lane, fci);
+            return;
+        }
+        lds_put<E>(S.D[1], lane, fcr);
+        lds_put<E>(S.D[2], lane, fci);
+        __syncthreads();   // barrier 2: dW complete
+        __syncthreads();   // barrier 3: squared scaled increments complete
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc += (S.F[0][e * 64 + lane] + S.F[1][e * 64 + lane]) + S.F[2][e * 64 + lane];
+        acc = wave_sum(acc);
+        if (lane == 0) A.part[task] = acc;
+        return;
+    }
+
+    // =========================== waves 0..2: stages, real system (wave 0), update ===========================
+    double yy[E];
+    if (STAGE && A.do_stage) {
+        const int i = w;
+        const double* __restrict__ zi = A.st.z + (size_t)i * A.st.nv;
+        const double* __restrict__ kvi = (i == 0) ? A.st.kv[0] : ((i == 1) ? A.st.kv[1] : A.st.kv[2]);
+        ColCoef<E> cf;
+        load_coef<E>(P, j, lane, cf);
+        double ys[E], yn[E], c[E], cs[E], cn[E], kv[E], f[E];
+        load_col<E>(A.st.y, task, lane, yy);
+        load_col<E>(A.st.y, cs_col, lane, ys);
+        load_col<E>(A.st.y, cn_col, lane, yn);
+        load_col<E>(zi, task, lane, c);
+        load_col<E>(zi, cs_col, lane, cs);
+        load_col<E>(zi, cn_col, lane, cn);
+        load_col<E>(kvi, j, lane, kv);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { c[e] = yy[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
+        tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
+        if constexpr (KIND == 2) forced_sources<E>(P, kvi, j, lane, c, f);
+        if constexpr (KIND == 1) {
+            double u1[E], u2[E], v1[E], v2[E];
+            phos_load_others<E>(P, tr, j, lane, A.st.y, u1, u2);
+            phos_load_others<E>(P, tr, j, lane, zi, v1, v2);
+            phos_add<E>(u1, u2, v1, v2);
+            phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, f);
+        }
+        lds_put<E>(S.F[i], lane, f);
+        __syncthreads();   // barrier 1
+    }
+    double w0[E], w1[E], w2[E];
+    if (A.do_update) {
+        if (stage) {
+            lds_get<E>(S.W[0], lane, w0);
+            lds_get<E>(S.W[1], lane, w1);
+            lds_get<E>(S.W[2], lane, w2);
+        } else {
+            load_col<E>(A.st.y, task, lane, yy);
+            load_col<E>(A.st.w, task, lane, w0);
+            load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+            load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+        }
+    }
+    if (w == 0) {
+        double a[E], cc[E], rinv[E], rtab[NK2D_TAB], fr[E];
+        if (stage) {
+            lds_get<E>(S.a, lane, a);
+            lds_get<E>(S.c, lane, cc);
+            lds_get<E>(S.inv, lane, rinv);
+            if constexpr (!FACTOR) {
+#pragma unroll
+                for (int i = 0; i < NK2D_TAB; ++i) rtab[i] = S.tab[i * 64 + lane];
+            }
+            double wr0[E];
+            lds_get<E>(S.W[0], lane, wr0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double s = 0.0;
+                s = s + S.F[0][e * 64 + lane] * cTI[0][0];
+                s = s + S.F[1][e * 64 + lane] * cTI[0][1];
+                s = s + S.F[2][e * 64 + lane] * cTI[0][2];
+                fr[e] = s - A.st.mreal * wr0[e];
+            }
+            if (!A.do_update && !A.delta) store_col<E>(A.st.br, task, lane, fr);
+        } else {
+            double jl[E], ju[E];
+            load_col<E>(A.sw.JL, j, lane, jl);
+            load_col<E>(A.sw.JU, j, lane, ju);
+            line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
+            if (A.sw.f32) {
+                load_col32<E>(A.sw.fr_inv32, task, lane, rinv);
+                load_tab32(A.sw.fr_tab32, task, lane, rtab);
+            } else {
+                load_col<E>(A.sw.fr_inv, task, lane, rinv);
+                load_tab<E>(A.sw.fr_tab, task, lane, rtab);
+            }
+            if (A.delta) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) fr[e] = 0.0;
+            } else {
+                load_col<E>(A.sw.br, task, lane, fr);
+            }
+        }
+        if (!A.sw.first) {
+            double js[E], jn[E], xs[E], xn[E];
+            load_col<E>(A.sw.JS, j, lane, js);
+            load_col<E>(A.sw.JN, j, lane, jn);
+            load_col<E>(A.sw.xr_old, cs_col, lane, xs);
+            load_col<E>(A.sw.xr_old, cn_col, lane, xn);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e]));
+            if constexpr (KIND == 1) {
+                double upr[E];
+                load_col<E>(P.UPR, j, lane, upr);
+                phos_couple<E>(P, tr, j, lane, A.sw.xr_old, upr, fr);
+            }
+        }
+        if constexpr (FACTOR) {   // S.inv holds the diagonal
+            double dre[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) dre[e] = rinv[e];
+            tridiag_factor<E, double>(a, cc, dre, rinv, rtab, lane);
+            store_col<E>(A.sw.fr_inv, task, lane, rinv);
+            double* p = A.sw.fr_tab + (size_t)task * (NK2D_TAB * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < NK2D_TAB; ++i) p[i * 64] = rtab[i];
+            if (A.sw.f32) {
+                store_col32<E>(A.sw.fr_inv32, task, lane, rinv);
+                store_tab32(A.sw.fr_tab32, task, lane, rtab);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) fr[e] = ((lane * E + e) < P.nz) ? fr[e] : 0.0;
+        tridiag_apply<E, double>(a, cc, rinv, rtab, fr, lane);
+        if (!A.do_stage && A.delta) {
+            double x1[E];
+            load_col<E>(A.sw.xr_old, task, lane, x1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) fr[e] = x1[e] + fr[e];
+        }
+        if (!A.do_update) store_col<E>(A.sw.xr_new, task, lane, fr);
+        else lds_put<E>(S.D[0], lane, fr);
+    }
+    if (!A.do_update) return;
+    __syncthreads();   // barrier 2
+    {
+        const int r = w;
+        double q[E], zz[E], wr[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double d0 = S.D[0][e * 64 + lane], d1 = S.D[1][e * 64 + lane], d2 = S.D[2][e * 64 + lane];
+            const double sc = P.atol + fabs(yy[e]) * P.rtol;
+            const double dr = (r == 0) ? d0 : ((r == 1) ? d1 : d2);
+            const double dq = dr / sc;
+            q[e] = dq * dq;
+            w0[e] = w0[e] + d0;
+            w1[e] = w1[e] + d1;
+            w2[e] = w2[e] + d2;
+            wr[e] = (r == 0) ? w0[e] : ((r == 1) ? w1[e] : w2[e]);
+            zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+        }
+        lds_put<E>(S.F[r], lane, q);
+        store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wr);
+        store_col<E>(A.st.zout + (size_t)r * A.st.nv, task, lane, zz);
+    }
+    __syncthreads();   // barrier 3
 }
 
 // error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
@@ -1939,12 +2312,20 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
             c->win_bytes += 8.0 * words;
         }
     }
-    if (do_factor) {  // always a launch with the stage part
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+    if (c->team) {    // one workgroup per column (k_newton_team)
+        if (do_factor) {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        } else if (do_stage) {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        } else {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 0>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        }
+    } else if (do_factor) {  // always a launch with the stage part
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     } else if (do_stage || c->kind != 1) {
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     } else {          // phosphorus, sweep-only launch: the lean instantiation
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     }
     NK2D_CHECK(c, hipGetLastError());
     if (swap_z) std::swap(c->Z, c->ZN);

@@ -1,0 +1,111 @@
+"""Column teams (`k_newton_team`, option "team") and the XCD-contiguous column mapping (option "xcd_map") are
+launch-shape choices of the Newton-iteration kernel: every value is computed by the same operations in the same order
+as with one wave per column, so a forward year must come out BIT-IDENTICAL -- results, step schedule and counters --
+for every module kind (iage; phosphorus, whose waves read the other tracers of their column; a forced module with
+forcing files) and for grids that do not fill the last workgroup or the eight XCDs evenly."""
+import numpy as np
+import pytest
+
+from helpers import oracle_iage
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    return iage_engine(Grid2d.default(nz, ny, vv, kh), **kw)
+
+
+def _year_variants(eng, x, counters=("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps")):
+    eng.set_option("device_ctl", 0)
+    ref = None
+    for team, xcd in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        eng.set_option("team", team)
+        eng.set_option("xcd_map", xcd)
+        fx, stats, sched = eng.comp_fcn(x, record=True)
+        got = (eng.download(fx), sched, {k: stats[k] for k in counters})
+        if ref is None:
+            ref = got
+            continue
+        assert np.array_equal(got[0], ref[0]), (team, xcd)
+        assert np.array_equal(got[1], ref[1]), (team, xcd)
+        assert got[2] == ref[2], (team, xcd)
+    eng.set_option("team", -1)
+    eng.set_option("xcd_map", 0)
+    return ref
+
+
+@pytest.mark.parametrize("nz,ny", [(26, 26), (70, 13), (130, 21)])
+def test_team_iage_bitwise(nz, ny):
+    eng = make_engine(nz, ny)
+    model, _ = oracle_iage(nz, ny)
+    rng = np.random.default_rng(5)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2) + 0.01 * rng.standard_normal((2, nz, ny)))
+    res, _, counters = _year_variants(eng, x)
+    assert np.isfinite(res).all() and counters["nsteps"] > 100
+
+
+def test_team_min_sweeps_two_and_replay():
+    """the launches of a two-sweep iteration (stage + first sweep; second sweep in delta form + update) and of a
+    step-replayed year (lin_tol 1e-3: up to several sweeps, right-hand sides written and read back)"""
+    eng = make_engine(26, 26)
+    model, _ = oracle_iage(26, 26)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2).copy())
+    eng.set_option("device_ctl", 0)
+    eng.set_option("min_sweeps", 2)
+    out = []
+    for team in (0, 1):
+        eng.set_option("team", team)
+        fx, stats, sched = eng.comp_fcn(x, record=True)
+        out.append((eng.download(fx), sched, stats["nsweeps"]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    eng.set_option("min_sweeps", 1)
+    eng.set_option("lin_tol", 1.0e-3)
+    rep = []
+    for team in (0, 1):
+        eng.set_option("team", team)
+        fx, _, _ = eng.comp_fcn(x, replay=out[0][1])
+        rep.append(eng.download(fx))
+    assert np.array_equal(rep[0], rep[1])
+    with pytest.raises(Exception, match="team"):
+        eng.set_option("team", 2)
+
+
+def test_team_phosphorus_bitwise():
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    grid = Grid2d.default(30, 12)
+    eng = phosphorus_engine(grid)
+    rng = np.random.default_rng(2)
+    x0 = np.empty((3, 30, 12))
+    x0[0] = 2.0 + 0.1 * rng.standard_normal((30, 12))
+    x0[1] = 0.05 + 0.005 * rng.standard_normal((30, 12))
+    x0[2] = 0.01 + 0.001 * rng.standard_normal((30, 12))
+    res, _, counters = _year_variants(eng, eng.upload(x0))
+    assert np.isfinite(res).all() and counters["nsteps"] > 50
+    eng.close()
+
+
+@pytest.mark.parametrize("nz", [130, 416])
+def test_team_forced_file_bitwise(nz):
+    """kind 2 (forcing records interpolated in time, thresholded sink) at 3 and 7 levels per lane, a short year"""
+    from nk_ooc_amd.engine import ModuleEngine
+    from nk_ooc_amd.grid import Grid2d
+
+    ny = 11
+    rng = np.random.default_rng(nz)
+    times = np.array([-10.0, 40.0, 95.0, 200.0, 300.0]) * 86400.0
+    restore = 1.0 + 0.2 * rng.standard_normal((5, ny))
+    sms = 3.0e-8 * rng.standard_normal((5, nz, ny))
+    eng = ModuleEngine(Grid2d.default(nz, ny), tc=1, surf_rate=(24.0 / 86400.0,), module_kind=2,
+                       restore_series=(times, restore), sms_series=(times, sms), sink_thres=0.4,
+                       time_range=(0.0, 30.0 * 86400.0))
+    x = eng.upload(0.6 + 0.2 * rng.standard_normal((1, nz, ny)))
+    res, _, counters = _year_variants(eng, x)
+    assert np.isfinite(res).all() and counters["nsteps"] > 10
+    eng.close()
