@@ -166,18 +166,52 @@ class Workload:
 
 
 def roofline_of(eng, n):
-    """dominant kernel of the forward year, from the library's HIP-event windows on the context's own
-    stream (nk2d_profile_reset / nk2d_profile_read).  `achieved` uses the RAW window time per launch --
-    the event pair's own cost is NOT subtracted, so this is a lower bound of what the kernel does; the
-    value net of an empty pair's reading and the static rocprofv3 figure of the same command are printed
-    beside it, labelled."""
+    """dominant kernel of the forward year.  Host control: `achieved` = the algorithmic bytes of the kernel's launches
+    in the timed region / their duration, the duration of each launch shape measured live by a back-to-back replay
+    of 200 launches inside ONE HIP event pair on the context's stream (nk2d_profile_replay: no event cost to subtract,
+    the hand-over between launches included) and weighted with the shape counts of the timed region.  The library's
+    event windows over the timed region itself (one or two launches per window, so a quarter of each reading is the
+    event pair) and the static rocprofv3 figure of the same command are printed beside it, labelled."""
     prof = eng.profile_read()
     samples = max(prof["samples"], 1)
-    bytes_per_launch = prof["bytes"] / samples
+    win_bytes_per_launch = prof["bytes"] / samples
     net_us = max(prof["avg_us"], 1e-3)
     raw_us = net_us + prof["event_overhead_us"] * prof["windows"] / samples
-    achieved = bytes_per_launch / (raw_us * 1e-6) / 1e9
     persistent = getattr(eng, "device_ctl", 0) == 3
+    windows = {
+        "what": "HIP event pairs around the launches of single Newton iterations inside the timed region",
+        "avg_launch_us_event_cost_included": raw_us,
+        "avg_launch_us_net_of_empty_event_pair": net_us,
+        "event_pair_empty_us": prof["event_overhead_us"],
+        "event_windows": prof["windows"],
+        "event_samples": prof["samples"],
+        "algorithmic_bytes_per_launch": win_bytes_per_launch,
+        "frac_event_cost_included": win_bytes_per_launch / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "frac_net_of_empty_event_pair": win_bytes_per_launch / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+    }
+    if persistent:
+        bytes_per_launch, launch_us = win_bytes_per_launch, raw_us
+        timing = "HIP event pair on the context's stream around each whole-year launch"
+        shapes_out = None
+    else:
+        shapes = eng.profile_shapes()
+        names = ["stage + sweep + update", "stage + first sweep", "last sweep + update"]
+        shapes_out, tot_bytes, tot_us, tot_cnt = [], 0.0, 0.0, 0
+        for shape in range(3):
+            cnt = shapes["counts"][shape]
+            rep = eng.profile_replay(shape, 200)
+            shapes_out.append({"shape": names[shape], "launches_in_timed_region": cnt, "replay_us_per_launch": rep["avg_us"],
+                               "algorithmic_bytes_per_launch": rep["bytes"],
+                               "GBs": rep["bytes"] / (rep["avg_us"] * 1e-6) / 1e9})
+            tot_bytes += shapes["bytes"][shape]
+            tot_us += cnt * rep["avg_us"]
+            tot_cnt += cnt
+        tot_cnt = max(tot_cnt, 1)
+        bytes_per_launch, launch_us = tot_bytes / tot_cnt, max(tot_us / tot_cnt, 1e-3)
+        timing = ("per launch shape: 200 launches queued back to back inside ONE HIP event pair on the context's stream "
+                  "(hand-over between launches included, no event cost subtracted), weighted with the shape counts of "
+                  "the timed region")
+    achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
     out = {
         "bound": "hbm",
         "kernel": (f"k_year_persistent<{(eng.nz + 63) // 64}, 0> (the whole forward year in one launch: all phases and "
@@ -187,17 +221,14 @@ def roofline_of(eng, n):
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": None,
-        "avg_launch_us": raw_us,
-        "timing": ("HIP event pair on the context's stream around each whole-year launch" if persistent else
-                   "HIP event pairs on the context's stream around back-to-back launches, event cost included"),
-        "avg_launch_us_net_of_empty_event_pair": net_us,
-        "frac_net_of_empty_event_pair": bytes_per_launch / (net_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-        "event_pair_empty_us": prof["event_overhead_us"],
-        "event_windows": prof["windows"],
-        "event_samples": prof["samples"],
+        "avg_launch_us": launch_us,
+        "timing": timing,
         "launches": prof["launches"],
         "algorithmic_bytes_per_launch": bytes_per_launch,
+        "event_windows_over_timed_region": windows,
     }
+    if shapes_out:
+        out["launch_shapes"] = shapes_out
     pmc_fname = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{n}.json")
     if not os.path.exists(pmc_fname):
         pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")

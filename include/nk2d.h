@@ -218,6 +218,14 @@ int nk2d_profile_read(nk2d_ctx* ctx, double* avg_us, int64_t* samples, int64_t* 
 /* the same counters since the last nk2d_profile_reset over ALL launches of the dominant kernel (timed
    or not): their number and their algorithmic bytes -- for the end-to-end rate bytes / wall time */
 int nk2d_profile_totals(nk2d_ctx* ctx, int64_t* launches, double* bytes);
+/* the launches of the dominant kernel without the factorisation since the last nk2d_profile_reset, by shape
+   (0: stage + sweep + update, 1: stage + first sweep, 2: last sweep + update, 3: a middle sweep), and their
+   algorithmic bytes */
+int nk2d_profile_shapes(nk2d_ctx* ctx, int64_t* counts4, double* bytes4);
+/* n launches of shape 0, 1 or 2 of that kernel queued back to back inside ONE event pair, on the state the last
+   forward year left behind, their updates written to scratch: microseconds per launch (the hand-over between
+   consecutive launches included, no event cost to subtract) and the algorithmic bytes of one such launch */
+int nk2d_profile_replay(nk2d_ctx* ctx, int32_t shape, int32_t n, double* avg_us, double* bytes_per_launch);
 /* a HIP event pair on the context's own stream for the caller's measurements (bench.py times the
    preconditioner apply with it): nk2d_timer_begin records the first event, nk2d_timer_end records
    the second, waits for it and returns the elapsed milliseconds between the two */
@@ -280,6 +288,11 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    "min_sweeps" (1, default: a solve whose contraction bound meets lin_tol after ONE sweep runs the whole simplified
    Newton iteration as a single launch, its update written to a spare stage buffer; 2: at least two sweeps wherever
    columns couple, the round-1 rule -- also what the device-side controllers 1 and 2 always use),
+   "jac_stage" (0, 1 or 2, with "jac_fresh" 1 and host-side or persistent control: the Jacobian of a step attempt is
+   taken at the time of that stage of the attempt, t + c_i h, instead of the step start -- the simplified Newton
+   iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
+   the launch that computes the stage's mixing plane derives the Jacobian planes from it.  -1, the library default:
+   the step start, as SciPy.  Ignored by modules whose Jacobian reads the state),
    "team" (1: the Newton-iteration launches run with one workgroup of four waves per column -- stages, real system,
    complex system on waves of their own -- instead of one wave per column; same arguments, bit-identical results;
    -1, the default: chosen per context, on for at most 512 columns of at least 5 levels per lane, where all teams fit

@@ -124,6 +124,8 @@ SIGNATURES = {
     "nk2d_profile_reset": (_ci, [_vp, _i32]),
     "nk2d_profile_read": (_ci, [_vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p, c_int64_p]),
     "nk2d_profile_totals": (_ci, [_vp, c_int64_p, c_double_p]),
+    "nk2d_profile_shapes": (_ci, [_vp, c_int64_p, c_double_p]),
+    "nk2d_profile_replay": (_ci, [_vp, _i32, _i32, c_double_p, c_double_p]),
     "nk2d_timer_begin": (_ci, [_vp]),
     "nk2d_timer_end": (_ci, [_vp, c_double_p]),
     "nk2d_jvp": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, c_double_p, ctypes.POINTER(Stats)]),

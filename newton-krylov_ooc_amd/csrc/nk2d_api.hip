@@ -131,6 +131,11 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "jac_stage") {
+        if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: jac_stage must be -1, 0, 1 or 2");
+        c->jac_stage = (int)value;
+        return 0;
+    }
     if (key == "xcd_map") { c->xcd_map = value != 0.0; return 0; }
     if (key == "team") {   // -1: automatic (see nk2d_team_auto), 0 / 1: never / always
         if (value != 0.0 && value != 1.0 && value != -1.0) return nk2d_fail(c, "nk2d_set_option: team must be -1, 0 or 1");
@@ -209,12 +214,21 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     c->sweep_launches = 0;
     c->sweep_bytes = 0.0;
     c->fused_bytes_all = 0.0;
+    for (int i = 0; i < 4; ++i) { c->shape_cnt[i] = 0; c->shape_bytes[i] = 0.0; }
     return 0;
 }
 
 extern "C" int nk2d_profile_totals(nk2d_ctx* c, int64_t* launches, double* bytes) {
     if (launches) *launches = c->sweep_launches;
     if (bytes) *bytes = c->fused_bytes_all;
+    return 0;
+}
+
+extern "C" int nk2d_profile_shapes(nk2d_ctx* c, int64_t* counts4, double* bytes4) {
+    for (int i = 0; i < 4; ++i) {
+        if (counts4) counts4[i] = c->shape_cnt[i];
+        if (bytes4) bytes4[i] = c->shape_bytes[i];
+    }
     return 0;
 }
 
@@ -339,6 +353,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->min_sweeps = 1;
     c->team = nk2d_team_auto(c);
     c->xcd_map = 0;
+    c->jac_stage = -1;
     c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));

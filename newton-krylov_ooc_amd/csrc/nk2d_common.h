@@ -75,6 +75,7 @@ struct nk2d_ctx {
     // the old ones from Z in the same launch, then Z and ZN swap
     double* ZN /*3nv*/;
     int min_sweeps;    // least sweeps per solve where columns couple (option "min_sweeps": 1 default, 2 = round-1 rule)
+    int jac_stage;     // >= 0: Jacobian of a step attempt from the vertical mixing plane of this stage time (option "jac_stage"); -1: step start
     int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
     int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
     int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
@@ -169,6 +170,8 @@ struct nk2d_ctx {
     int64_t prof_cnt;
     int64_t sweep_launches;           // launches of the dominant kernel since the last nk2d_profile_reset
     double fused_bytes_all;           // algorithmic bytes of ALL those launches (timed or not)
+    int64_t shape_cnt[4];             // non-factorising launches by shape: stage+update, stage only, update only, neither
+    double shape_bytes[4];            // their algorithmic bytes
     double sweep_bytes;               // algorithmic bytes of the launches inside timed windows
     int64_t prof_windows;             // timed windows folded into prof_ms_sum (prof_cnt: their launches)
     std::vector<int> prof_win_launches;
@@ -509,8 +512,9 @@ int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part);
 int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part);
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv);
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2);
-int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2);
+                         double x0, double x1, double x2, int jac_stage = -1);
+int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
+                         int jac_stage = -1);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);

@@ -207,14 +207,14 @@ __device__ __forceinline__ double ramp2(double x, double x0, double x1, double y
 }
 
 // vertical mixing coefficient of ypos column j at the time whose seasonal fraction is `frac`
-template <int E, int MP = 0>
-__device__ __forceinline__ void vmix_col(const DevP& P, double bldmin, double vy0, double vy1, double hw, double frac,
-                                         double* __restrict__ out, int j, int lane) {
+template <int E>
+__device__ __forceinline__ void vmix_col_regs(const DevP& P, double bldmin, double vy0, double vy1, double hw, double frac,
+                                              int j, int lane, double (&kv)[E]) {
     const double bld = bldmin + (P.BLDMAX[j] - bldmin) * frac;
     const double x0 = bld - hw, x1 = bld + hw;
     const double y0 = vy0, y1 = vy1;
     const double slope = (y1 - y0) / (x1 - x0);
-    double zm0[E], zm1[E], dm[E], dmr[E], wb[E], kv[E];
+    double zm0[E], zm1[E], dm[E], dmr[E], wb[E];
     load_col<E>(P.ZM0, 0, lane, zm0);
     load_col<E>(P.ZM1, 0, lane, zm1);
     load_col<E>(P.DM, 0, lane, dm);
@@ -252,13 +252,21 @@ __device__ __forceinline__ void vmix_col(const DevP& P, double bldmin, double vy
         }
         kv[e] = val;
     }
+}
+template <int E, int MP = 0>
+__device__ __forceinline__ void vmix_col(const DevP& P, double bldmin, double vy0, double vy1, double hw, double frac,
+                                         double* __restrict__ out, int j, int lane) {
+    double kv[E];
+    vmix_col_regs<E>(P, bldmin, vy0, vy1, hw, frac, j, lane, kv);
     store_col<E, MP>(out, j, lane, kv);
 }
 
+// one (time, ypos column) task of a plane launch; kv: the vertical mixing column it computed, for callers that go on with it
 template <int E, int MP = 0>
-__device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int task, int lane) {
+__device__ __forceinline__ void vmix_body_kv(const DevP& P, const VmixArgs& A, int task, int lane, double (&kv)[E]) {
     const int ti = task / P.ny, j = task - ti * P.ny;
-    vmix_col<E, MP>(P, A.bldmin, A.y0, A.y1, A.hw, A.frac[ti], A.out[ti], j, lane);
+    vmix_col_regs<E>(P, A.bldmin, A.y0, A.y1, A.hw, A.frac[ti], j, lane, kv);
+    store_col<E, MP>(A.out[ti], j, lane, kv);
     // forcing fields of the same time (kind 2), linear in time between two records:
     // slope = (y_hi - y_lo) / (x_hi - x_lo), y = slope (x - x_lo) + y_lo  (scipy interp1d, utils.py:529-531)
     if (P.f_sms > 0) {
@@ -277,6 +285,12 @@ __device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int 
         const double slope = (hi - lo) / A.rden[ti];
         A.out[ti][2 * P.np + j] = slope * A.rdx[ti] + lo;
     }
+}
+
+template <int E, int MP = 0>
+__device__ __forceinline__ void vmix_body(const DevP& P, const VmixArgs& A, int task, int lane) {
+    double kv[E];
+    vmix_body_kv<E, MP>(P, A, task, lane, kv);
 }
 
 template <int E>
@@ -486,16 +500,33 @@ int nk2d_k_tend(nk2d_ctx* c, const double* y, const double* kv, double* f) {
 // Jacobian planes (advection.py:111-173, horiz_mix.py:100-142, vert_mix.py:140-182)
 // up = d tend[k]/d c[k-1], dn = .../d c[k+1], south = .../d c[j-1], north = .../d c[j+1]
 // ---------------------------------------------------------------------------------
+template <int E, int MP>
+__device__ __forceinline__ void jac_core(const DevP& P, const double (&kv)[E], const double* __restrict__ kvp,
+                                         double* __restrict__ JL, double* __restrict__ JU, double* __restrict__ JS,
+                                         double* __restrict__ JN, double* __restrict__ JC, const double* __restrict__ ylin,
+                                         double* __restrict__ UPR, int task, int lane);
+
 template <int E, int MP = 0>
 __device__ __forceinline__ void jac_body(const DevP& P, const double* __restrict__ kvp, double* __restrict__ JL,
                                          double* __restrict__ JU, double* __restrict__ JS, double* __restrict__ JN,
                                          double* __restrict__ JC, const double* __restrict__ ylin,
                                          double* __restrict__ UPR, int task, int lane) {
+    double kv[E];
+    load_col<E, MP>(kvp, task, lane, kv);
+    jac_core<E, MP>(P, kv, kvp, JL, JU, JS, JN, JC, ylin, UPR, task, lane);
+}
+
+// the same from a vertical mixing column held in registers (kvp: its bundle in memory, read only for the source plane of
+// a forced module with a thresholded sink)
+template <int E, int MP = 0>
+__device__ __forceinline__ void jac_core(const DevP& P, const double (&kv)[E], const double* __restrict__ kvp,
+                                         double* __restrict__ JL, double* __restrict__ JU, double* __restrict__ JS,
+                                         double* __restrict__ JN, double* __restrict__ JC, const double* __restrict__ ylin,
+                                         double* __restrict__ UPR, int task, int lane) {
     const int j = task;
     ColCoef<E> cf;
     load_coef<E>(P, j, lane, cf);
-    double kv[E], kvprev[E], up[E], dn[E], so[E], no[E], ce[E];
-    load_col<E, MP>(kvp, j, lane, kv);
+    double kvprev[E], up[E], dn[E], so[E], no[E], ce[E];
     shift_prev<E>(kv, kvprev, lane, 0.0);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1181,13 +1212,24 @@ __global__ void k_predict(int ncol, PredictArgs A) {
 
 // start of a step attempt in one launch: the vertical mixing planes at the three stage times
 // (first blocks) and the predicted stage values (remaining blocks) are independent of each other
+struct JacOut {
+    double *JL, *JU, *JS, *JN, *JC;
+    int stage;   // >= 0: the waves computing the plane of this stage time also derive the Jacobian planes from it
+};
+
 template <int E>
-__global__ void k_attempt_setup(DevP P, VmixArgs V, int nblk_vmix, PredictArgs A) {
+__global__ void k_attempt_setup(DevP P, VmixArgs V, int nblk_vmix, PredictArgs A, JacOut J) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     if ((int)blockIdx.x < nblk_vmix) {
         const int task = blockIdx.x * wpb + wave;
-        if (task < P.ny * 3) vmix_body<E>(P, V, task, lane);
+        if (task < P.ny * 3) {
+            double kv[E];
+            vmix_body_kv<E>(P, V, task, lane, kv);
+            const int ti = task / P.ny;
+            if (ti == J.stage)
+                jac_core<E, 0>(P, kv, V.out[ti], J.JL, J.JU, J.JS, J.JN, J.JC, nullptr, nullptr, task - ti * P.ny, lane);
+        }
     } else {
         const int task = (blockIdx.x - nblk_vmix) * wpb + wave;
         if (task < P.ncol) predict_body<E>(A, task, lane);
@@ -2045,6 +2087,7 @@ struct BoundaryArgs {
     double *ynew, *f;
     double *JL, *JU, *JS, *JN, *JC;
     int do_jac, nblk_vmix, nblk_jac;
+    int jac_stage;                     // >= 0: Jacobian from the new plane of this stage (by the wave that computes it); then do_jac = 0
 };
 
 template <int E, int KIND>
@@ -2054,7 +2097,15 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V
     int blk = blockIdx.x;
     if (blk < B.nblk_vmix) {
         const int task = blk * wpb + wave;
-        if (task < P.ny * 3) vmix_body<E>(P, V, task, lane);
+        if (task < P.ny * 3) {
+            double kv[E];
+            vmix_body_kv<E>(P, V, task, lane, kv);
+            // option "jac_stage": the Jacobian of the coming attempt from the plane of one of ITS stage times -- the wave
+            // that has just computed that column derives the Jacobian planes of the column from it
+            const int ti = task / P.ny;
+            if (ti == B.jac_stage)
+                jac_core<E, 0>(P, kv, V.out[ti], B.JL, B.JU, B.JS, B.JN, B.JC, nullptr, nullptr, task - ti * P.ny, lane);
+        }
         return;
     }
     blk -= B.nblk_vmix;
@@ -2074,7 +2125,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V
 // with stage times `times` (planes into out[0..2]) and dense-output abscissae x0..x2.  Buffers are taken in their
 // roles BEFORE the caller swaps them: y_new goes to YOLD, the predicted stage values to ZP.
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2) {
+                         double x0, double x1, double x2, int jac_stage) {
     VmixArgs V;
     for (int i = 0; i < 3; ++i) {
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
@@ -2087,6 +2138,8 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
     B.y = c->Y; B.z2 = c->Z + 2 * c->nv; B.kv_new = kv_new; B.ynew = c->YOLD; B.f = c->F;
     B.JL = c->JL; B.JU = c->JU; B.JS = c->JS; B.JN = c->JN; B.JC = c->JC;
     B.do_jac = do_jac ? 1 : 0;
+    B.jac_stage = jac_stage;
+    if (jac_stage >= 0 && do_jac) return nk2d_fail(c, "nk2d_r_step_boundary: Jacobian at t_new and at a stage time requested together");
     B.nblk_vmix = nk2d_grid(c->ny * 3);
     B.nblk_jac = do_jac ? nk2d_grid(c->ny) : 0;
     PredictArgs A;
@@ -2237,7 +2290,8 @@ int nk2d_r_predict(nk2d_ctx* c, double x0, double x1, double x2) {
     return 0;
 }
 // stage planes at times[0..2] into out[0..2] and the predicted Z, W in one launch
-int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2) {
+int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
+                         int jac_stage) {
     VmixArgs V;
     for (int i = 0; i < 3; ++i) {
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
@@ -2249,22 +2303,40 @@ int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, d
     PredictArgs A = predict_args(c, x0, x1, x2);
     DevP P = make_devp(c);
     const int nblk_vmix = nk2d_grid(c->ny * 3);
+    JacOut J = {c->JL, c->JU, c->JS, c->JN, c->JC, jac_stage};
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_attempt_setup<EE>, dim3(nblk_vmix + nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0,
-                                              c->stream, P, V, nblk_vmix, A));
+                                              c->stream, P, V, nblk_vmix, A, J));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
 }
-// one launch of the fused Newton iteration; src = ping-pong buffer with the previous
-// sweep's iterate, the new iterate goes to 1-src unless do_update consumes it
-int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
-                        double mci, int src, bool delta) {
-    FusedArgs A = {};
+// algorithmic (unique) 8-byte words of one launch of the fused Newton iteration, P = nz*ny cells, N = tc*P values:
+//   stage : read y, Z[3], W[3] (7N), kappa_v at 3 times + 4 static planes (7P),
+//           write the 3 right-hand sides (3N) unless the update consumes them
+//   sweep : Jacobian planes JL, JU (+JS, JN after the first sweep), pivot reciprocals
+//           (real N + complex 2N), PCR tables (3 * 14/E * N), right-hand sides (3N, unless
+//           just computed), previous iterate (3N, after the first sweep), new iterate (3N,
+//           unless the update consumes it)
+//   update: y (N, unless the stage read it), W read + write (6N), Z write (3N)
+static double fused_words(const nk2d_ctx* c, bool do_stage, bool first, bool do_update, bool delta, bool do_factor) {
+    const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
+    double words = 0.0;
+    if (do_stage) words += 7.0 * N + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * N);
+    const double fw = (c->factor_fp32 && !do_factor) ? 0.5 : 1.0;  // fp32 copies of the factorisation
+    words += (first ? 2.0 : 4.0) * Pc + fw * (3.0 * N + 3.0 * 14.0 / c->E * N);  // factor read, or written when computed here
+    if (do_factor) words += Pc;                                             // JC
+    if (!do_stage && !delta) words += 3.0 * N;
+    if (!first) words += 3.0 * N;
+    if (!do_update) words += 3.0 * N;
+    if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;
+    return words;
+}
+
+static void fill_fused_args(nk2d_ctx* c, FusedArgs& A, bool do_stage, bool first, bool do_update, double mreal,
+                            double mcr, double mci, int src, bool delta) {
+    A = {};
     A.st.y = c->Y; A.st.z = c->Z; A.st.w = c->W;
-    // stage and update in ONE launch (single-sweep solve): the update must not overwrite stage values the
-    // neighbouring columns are still reading -- it writes the spare buffer, the buffers swap after the launch
-    const bool swap_z = do_stage && do_update && c->single_swap;
-    A.st.zout = swap_z ? c->ZN : c->Z;
+    A.st.zout = c->Z;
     A.st.kv[0] = c->KV[0]; A.st.kv[1] = c->KV[1]; A.st.kv[2] = c->KV[2];
     A.st.br = c->BR; A.st.bcr = c->BCR; A.st.bci = c->BCI;
     A.st.nv = c->nv; A.st.mreal = mreal; A.st.mcr = mcr; A.st.mci = mci;
@@ -2273,45 +2345,14 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     A.sw.xr_old = c->XR[src]; A.sw.xcr_old = c->XCR[src]; A.sw.xci_old = c->XCI[src];
     A.sw.xr_new = c->XR[1 - src]; A.sw.xcr_new = c->XCR[1 - src]; A.sw.xci_new = c->XCI[1 - src];
     A.sw.first = first ? 1 : 0;
-    A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : c->PART;
+    A.sw.cre = c->lu_cre; A.sw.ccr = c->lu_ccr; A.sw.cci = c->lu_cci;
+    A.part = c->PART;
     A.do_stage = do_stage ? 1 : 0;
     A.do_update = do_update ? 1 : 0;
     A.delta = delta ? 1 : 0;
-    // pivots / PCR tables of a new (h, J): computed inside the first launch that uses them
-    bool do_factor = c->factor_pending != 0;
-    if (do_factor && !do_stage) {  // not expected: the first launch after an "LU" event evaluates the stages
-        NK2D_TRY(nk2d_k_factor(c, true, true, c->lu_cre, c->lu_ccr, c->lu_cci));
-        do_factor = false;
-    }
-    A.sw.cre = c->lu_cre; A.sw.ccr = c->lu_ccr; A.sw.cci = c->lu_cci;
-    c->factor_pending = 0;
-    DevP P = make_devp(c);
-    {
-        // algorithmic (unique) bytes of this launch, P = nz*ny cells, N = tc*P values:
-        //   stage : read y, Z[3], W[3] (7N), kappa_v at 3 times + 4 static planes (7P),
-        //           write the 3 right-hand sides (3N) unless the update consumes them
-        //   sweep : Jacobian planes JL, JU (+JS, JN after the first sweep), pivot reciprocals
-        //           (real N + complex 2N), PCR tables (3 * 14/E * N), right-hand sides (3N, unless
-        //           just computed), previous iterate (3N, after the first sweep), new iterate (3N,
-        //           unless the update consumes it)
-        //   update: y (N, unless the stage read it), W read + write (6N), Z write (3N)
-        const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
-        double words = 0.0;
-        if (do_stage) words += 7.0 * N + 7.0 * Pc + ((do_update || delta) ? 0.0 : 3.0 * N);
-        const double fw = (c->factor_fp32 && !do_factor) ? 0.5 : 1.0;  // fp32 copies of the factorisation
-        words += (first ? 2.0 : 4.0) * Pc + fw * (3.0 * N + 3.0 * 14.0 / c->E * N);  // factor read, or written when computed here
-        if (do_factor) words += Pc;                                             // JC
-        if (!do_stage && !delta) words += 3.0 * N;
-        if (!first) words += 3.0 * N;
-        if (!do_update) words += 3.0 * N;
-        if (do_update) words += (do_stage ? 0.0 : N) + 9.0 * N;
-        c->sweep_launches++;
-        c->fused_bytes_all += 8.0 * words;
-        if (c->win_open) {
-            c->win_launches++;
-            c->win_bytes += 8.0 * words;
-        }
-    }
+}
+
+static int launch_fused(nk2d_ctx* c, const DevP& P, const FusedArgs& A, bool do_factor, bool do_stage) {
     if (c->team) {    // one workgroup per column (k_newton_team)
         if (do_factor) {
             NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
@@ -2328,9 +2369,84 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
     }
     NK2D_CHECK(c, hipGetLastError());
+    return 0;
+}
+
+// one launch of the fused Newton iteration; src = ping-pong buffer with the previous
+// sweep's iterate, the new iterate goes to 1-src unless do_update consumes it
+int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, double mreal, double mcr,
+                        double mci, int src, bool delta) {
+    FusedArgs A;
+    fill_fused_args(c, A, do_stage, first, do_update, mreal, mcr, mci, src, delta);
+    // stage and update in ONE launch (single-sweep solve): the update must not overwrite stage values the
+    // neighbouring columns are still reading -- it writes the spare buffer, the buffers swap after the launch
+    const bool swap_z = do_stage && do_update && c->single_swap;
+    A.st.zout = swap_z ? c->ZN : c->Z;
+    A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : c->PART;
+    // pivots / PCR tables of a new (h, J): computed inside the first launch that uses them
+    bool do_factor = c->factor_pending != 0;
+    if (do_factor && !do_stage) {  // not expected: the first launch after an "LU" event evaluates the stages
+        NK2D_TRY(nk2d_k_factor(c, true, true, c->lu_cre, c->lu_ccr, c->lu_cci));
+        do_factor = false;
+    }
+    c->factor_pending = 0;
+    DevP P = make_devp(c);
+    {
+        const double words = fused_words(c, do_stage, first, do_update, delta, do_factor);
+        c->sweep_launches++;
+        c->fused_bytes_all += 8.0 * words;
+        if (!do_factor) {   // launch shapes of the kernel without the factorisation, for nk2d_profile_replay
+            const int shape = (do_stage && do_update) ? 0 : (do_stage ? 1 : (do_update ? 2 : 3));
+            c->shape_cnt[shape]++;
+            c->shape_bytes[shape] += 8.0 * words;
+        }
+        if (c->win_open) {
+            c->win_launches++;
+            c->win_bytes += 8.0 * words;
+        }
+    }
+    NK2D_TRY(launch_fused(c, P, A, do_factor, do_stage));
     if (swap_z) std::swap(c->Z, c->ZN);
     c->st.nlaunch++;
     c->st.nsweeps++;
+    return 0;
+}
+
+// Back-to-back replay of the dominant kernel for the roofline line of bench.py.  The timing windows above hold one
+// or two launches each (the host reads a norm after every Newton iteration), so the ~4.6 us an event pair costs is a
+// quarter of every reading.  Here n launches of ONE shape are queued with nothing between them inside ONE event
+// pair, on the state the last forward year left behind (stage values, W, planes, factorisation of its last step):
+//   shape 0: stage + sweep + update (the single-launch iteration of a one-sweep solve)
+//   shape 1: stage + first sweep (first launch of a two-sweep solve, delta form)
+//   shape 2: second sweep + update (its last launch)
+// The updates go to scratch (W -> a copy in ZP, Z -> ZN) so that every launch reads the same inputs.  avg_us includes
+// the hand-over between consecutive launches, which the per-kernel durations of rocprofv3 do not.
+int nk2d_profile_replay(nk2d_ctx* c, int shape, int n, double* avg_us, double* bytes_per_launch) {
+    if (shape < 0 || shape > 2 || n < 1) return nk2d_fail(c, "nk2d_profile_replay: shape must be 0..2 and n >= 1");
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (c->lu_cre == 0.0) return nk2d_fail(c, "nk2d_profile_replay: run a forward year first");
+    if (!c->timer_ready) {
+        NK2D_CHECK(c, hipEventCreate(&c->timer_ev[0]));
+        NK2D_CHECK(c, hipEventCreate(&c->timer_ev[1]));
+        c->timer_ready = 1;
+    }
+    const bool do_stage = shape != 2, do_update = shape != 1, first = shape != 2, delta = shape != 0;
+    NK2D_CHECK(c, hipMemcpyAsync(c->ZP, c->W, 3 * c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    FusedArgs A;
+    fill_fused_args(c, A, do_stage, first, do_update, c->lu_cre, c->lu_ccr, c->lu_cci, 0, delta);
+    A.st.w = c->ZP;
+    A.st.zout = c->ZN;
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    for (int i = 0; i < 3; ++i) NK2D_TRY(launch_fused(c, P, A, false, do_stage));   // warm-up
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[0], c->stream));
+    for (int i = 0; i < n; ++i) NK2D_TRY(launch_fused(c, P, A, false, do_stage));
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[1], c->stream));
+    NK2D_CHECK(c, hipEventSynchronize(c->timer_ev[1]));
+    float ms = 0.f;
+    NK2D_CHECK(c, hipEventElapsedTime(&ms, c->timer_ev[0], c->timer_ev[1]));
+    if (avg_us) *avg_us = 1000.0 * ms / n;
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * fused_words(c, do_stage, first, do_update, delta, false);
     return 0;
 }
 
@@ -2475,6 +2591,7 @@ struct YearArgs {
     double* PART;              // [2][ncol]: norm partials, the two halves alternate from one reduction to the next
     double t0, t1, h_abs0, max_step, newton_tol, n_total, growth_cap;
     int jac_fresh, f32;
+    int jac_stage;             // >= 0: Jacobian of an attempt from the plane of this stage time (option "jac_stage")
     double bld_t[4], bld_f[4], bldmin, vy0, vy1, hw;
     const int* m_tab;          // sweeps for the shift bucket k (host: nk2d_sweeps_for), n_tab entries
     int n_tab;
@@ -2636,6 +2753,21 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
         jac_body<E, 1>(P, kvp, const_cast<double*>(A.fac.JL), const_cast<double*>(A.fac.JU), const_cast<double*>(A.fac.JS), \
                        const_cast<double*>(A.fac.JN), const_cast<double*>(A.fac.JC), nullptr, nullptr, task, lane);
 
+    // one (stage time, ypos column) task of an attempt's planes; with option "jac_stage" the wave that computes the
+    // column of that stage derives the Jacobian planes of the column from it
+    const bool jac_at_stage = A.jac_stage >= 0;
+    const double rc_jac = (A.jac_stage == 0) ? RC0 : ((A.jac_stage == 1) ? RC1 : RC2);
+#define YEAR_PLANE(ti, fr, dst, j)                                                                                     \
+    {                                                                                                                   \
+        double kvc_[E];                                                                                                 \
+        vmix_col_regs<E>(P, A.bldmin, A.vy0, A.vy1, A.hw, fr, j, lane, kvc_);                                           \
+        store_col<E, 1>(dst, j, lane, kvc_);                                                                            \
+        if ((ti) == A.jac_stage)                                                                                        \
+            jac_core<E, 1>(P, kvc_, dst, const_cast<double*>(A.fac.JL), const_cast<double*>(A.fac.JU),                  \
+                           const_cast<double*>(A.fac.JS), const_cast<double*>(A.fac.JN), const_cast<double*>(A.fac.JC), \
+                           nullptr, nullptr, j, lane);                                                                  \
+    }
+
     while (t < A.t1) {
         const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
         double h_abs, h_abs_old = 0.0, err_old = 0.0;
@@ -2643,7 +2775,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
         if (h_abs_s > A.max_step) { h_abs = A.max_step; has_h_old = has_err_old = false; }
         else if (h_abs_s < min_step) { h_abs = min_step; has_h_old = has_err_old = false; }
         else { h_abs = h_abs_s; h_abs_old = h_abs_old_s; err_old = err_old_s; has_h_old = has_old_h; has_err_old = has_old_err; }
-        if (A.jac_fresh && !current_jac) {
+        if (A.jac_fresh && !current_jac && !jac_at_stage) {
             YEAR_JAC(YR_KV3)     // KV3 holds the plane at the current t
             YEAR_SYNC()
             t_jac = t; ++njev; current_jac = true; have_lu = false;
@@ -2671,8 +2803,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
                 const double f2 = uni_d(year_interp4(A.bld_t, A.bld_f, t + (h * RC2)));
                 for (int task = wave; task < 3 * P.ny; task += nwaves) {
                     const int ti = task / P.ny, j = task - ti * P.ny;
-                    vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2),
-                                   (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV2), j, lane);
+                    YEAR_PLANE(ti, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2), (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV2), j)
                 }
                 if (col_wave) {
                     if (have_dense) {
@@ -2695,6 +2826,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
                 }
                 YEAR_SYNC()
             }
+            if (jac_at_stage) { t_jac = t + (h * rc_jac); ++njev; current_jac = true; have_lu = false; }
             bool converged = false;
             while (!converged) {
                 if (!have_lu) {
@@ -2922,10 +3054,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
             const double f2 = uni_d(year_interp4(A.bld_t, A.bld_f, t_new + (h2 * RC2)));
             for (int task = wave; task < 3 * P.ny; task += nwaves) {
                 const int ti = task / P.ny, j = task - ti * P.ny;
-                vmix_col<E, 1>(P, A.bldmin, A.vy0, A.vy1, A.hw, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2),
-                               (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV3), j, lane);
+                YEAR_PLANE(ti, (ti == 0) ? f0 : ((ti == 1) ? f1 : f2), (ti == 0) ? A.KV[0] : ((ti == 1) ? A.KV[1] : YR_KV3), j)
             }
-            if (jac_due) { YEAR_JAC(YR_KV2) }      // the third stage plane is the plane at t_new
+            if (jac_due && !jac_at_stage) { YEAR_JAC(YR_KV2) }      // the third stage plane is the plane at t_new
             if (col_wave) {
                 commit_tend_body<E, KIND, 1>(P, YR_Y, YR_Z + 2 * nv, YR_KV2, YR_YOLD, A.F, wave, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's y_new is in memory before it reads it back
@@ -2944,7 +3075,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
             ++nsteps; ++nfev;
             YEAR_SYNC()
             pre_setup = true; pre_h = h2;
-            if (jac_due) {
+            if (jac_at_stage) {
+                current_jac = false;     // came with the planes; booked when the attempt starts
+            } else if (jac_due) {
                 t_jac = t; ++njev; current_jac = true;
                 if (!recompute_jac) have_lu = false;
             } else {
@@ -2987,6 +3120,7 @@ finish:
     }
 #undef YEAR_SYNC
 #undef YEAR_JAC
+#undef YEAR_PLANE
 #undef YR_Y
 #undef YR_YOLD
 #undef YR_Z
@@ -3043,7 +3177,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     A.fac.f32 = 0;
     A.PART = c->YR_PART;
     A.t0 = c->d.t0; A.t1 = c->d.t1; A.h_abs0 = h_abs0; A.max_step = max_step; A.newton_tol = newton_tol;
-    A.n_total = n_total; A.growth_cap = c->growth_cap; A.jac_fresh = c->jac_fresh;
+    A.n_total = n_total; A.growth_cap = c->growth_cap; A.jac_fresh = c->jac_fresh; A.jac_stage = c->jac_fresh ? c->jac_stage : -1;
     for (int i = 0; i < 4; ++i) { A.bld_t[i] = c->d.bld_tvals[i]; A.bld_f[i] = c->d.bld_fvals[i]; }
     A.bldmin = c->d.bldepth_min; A.vy0 = c->d.vmix_log_shallow; A.vy1 = c->d.vmix_log_deep; A.hw = c->d.vmix_half_width;
     A.m_tab = c->YR_MTAB; A.n_tab = (int)c->rho_tab.size(); A.rho_c0 = c->rho_c0; A.rho_dlog = c->rho_dlog;

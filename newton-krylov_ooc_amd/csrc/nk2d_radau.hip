@@ -47,6 +47,7 @@ struct Ctl {
     // the set-up of the next step's first attempt (stage planes, predicted stage values) and, where due, the Jacobian
     // at its start were already queued with the commit of the step before (nk2d_r_step_boundary): for this (t, h)
     bool pre_setup;
+    bool pre_jac;        // ... and so was the Jacobian of that attempt (option "jac_stage")
     double pre_t, pre_h;
 };
 
@@ -128,7 +129,7 @@ int predict(Ctl& s, double t, double h) {
 
 // stage planes + predicted stage values of a step attempt in one launch (needs the dense output
 // of a previous step; the very first step falls back to the two separate calls)
-int setup_attempt(Ctl& s, double t, double h) {
+int setup_attempt(Ctl& s, double t, double h, int jac_stage = -1) {
     nk2d_ctx* c = s.c;
     double times[3], x[3];
     for (int i = 0; i < 3; ++i) {
@@ -136,7 +137,7 @@ int setup_attempt(Ctl& s, double t, double h) {
         x[i] = ((t + h * RC[i]) - s.dense_t_old) / s.dense_h;
     }
     double* out[3] = {c->KV[0], c->KV[1], c->KV[2]};
-    return nk2d_r_attempt_setup(c, times, out, x[0], x[1], x[2]);
+    return nk2d_r_attempt_setup(c, times, out, x[0], x[1], x[2], jac_stage);
 }
 
 int stage_planes(Ctl& s, double t, double h) {
@@ -445,7 +446,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         if (s.h_abs > s.max_step) { h_abs = s.max_step; has_h_old = has_err_old = false; }
         else if (s.h_abs < min_step) { h_abs = min_step; has_h_old = has_err_old = false; }
         else { h_abs = s.h_abs; h_abs_old = s.h_abs_old; err_old = s.err_old; has_h_old = s.has_old_h; has_err_old = s.has_old_err; }
-        if (c->jac_fresh && !s.current_jac) {
+        const bool jac_needs_state0 = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
+        const bool jac_at_stage = c->jac_stage >= 0 && c->jac_fresh && s.device_ctl == 0 && !jac_needs_state0;
+        if (c->jac_fresh && !s.current_jac && !jac_at_stage) {
             // evaluating J costs two small launches here (SciPy pays a Python double loop and two
             // SuperLU factorisations, hence its reuse heuristics): never start a step on a stale J
             // (normally done by the step boundary launch of the step before)
@@ -469,16 +472,27 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             h = t_new - t;
             h_abs = std::fabs(h);
             // host control: planes and prediction of the first try in one launch
-            bool predicted = false;
+            bool predicted = false, jac_done = false;
             if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
                 predicted = true;            // queued with the commit of the step before
+                jac_done = s.pre_jac;
             } else if (s.device_ctl == 0 && s.have_dense) {
-                NK2D_TRY(setup_attempt(s, t, h));
+                NK2D_TRY(setup_attempt(s, t, h, jac_at_stage ? c->jac_stage : -1));
                 predicted = true;
+                jac_done = jac_at_stage;
             } else {
                 NK2D_TRY(stage_planes(s, t, h));
             }
             s.pre_setup = false;
+            if (jac_at_stage) {
+                // option "jac_stage": the Jacobian of this attempt from the vertical mixing plane of one of ITS stage
+                // times instead of the step start (normally derived by the launch that computed the plane)
+                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[c->jac_stage], nullptr));
+                s.t_jac = t + (h * RC[c->jac_stage]);
+                c->st.njev++;
+                s.current_jac = true;
+                s.have_lu = false;
+            }
             bool converged = false;
             double err_sum = 0.0;
             int buf = 0;
@@ -593,7 +607,8 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // planes: the third stage plane of this step IS the plane at t_new; the new stage planes go to the two
             // stage buffers nobody needs any more and to the buffer of the plane at the old t
             double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
-            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due && !jac_needs_state, times, out, x[0], x[1], x[2]));
+            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due && !jac_needs_state && !jac_at_stage, times, out, x[0], x[1], x[2],
+                                          jac_at_stage ? c->jac_stage : -1));
             std::swap(c->KV[3], c->KV[2]);
             std::swap(c->Y, c->YOLD);
             std::swap(c->Z, c->ZP);
@@ -603,8 +618,10 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             s.t = t_new;
             c->st.nsteps++;
             c->st.nfev++;
-            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2;
-            if (jac_due) {
+            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2; s.pre_jac = jac_at_stage;
+            if (jac_at_stage) {
+                s.current_jac = false;   // evaluated inside the next attempt
+            } else if (jac_due) {
                 // a Jacobian that reads the state (phosphorus, forced with a sink threshold) needs y_new complete:
                 // its own launch, after the boundary
                 if (jac_needs_state) NK2D_TRY(refresh_jac(s, t_new, true));
@@ -648,7 +665,11 @@ int run_replay(Ctl& s, const double* sched, int64_t n) {
         const int n_iter = (int)r[3];
         if (t != s.t) return nk2d_fail(c, "nk2d_comp_fcn: replay schedule does not start where the state is", -5);
         if (t_jac != s.t_jac) {
-            if (t_jac != t) return nk2d_fail(c, "nk2d_comp_fcn: replay schedule refreshes the Jacobian off a step start", -5);
+            // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
+            // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
+            const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
+            if (t_jac != t && needs_state)
+                return nk2d_fail(c, "nk2d_comp_fcn: replay schedule refreshes the Jacobian off a step start", -5);
             NK2D_TRY(refresh_jac(s, t_jac, false));
             c->st.njev++;
             have = false;
@@ -687,6 +708,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     const bool persistent = c->device_ctl == 3 && !replay && c->hist_n == 0 && !c->norm_hook && c->kind == 0;
     s.device_ctl = (c->device_ctl == 3) ? 0 : c->device_ctl;
     s.pre_setup = false;
+    s.pre_jac = false;
     s.pre_t = s.pre_h = 0.0;
     // per-column partials go to pinned host memory while the host takes the decisions; the flag is
     // dropped on every way out of this function

@@ -22,6 +22,16 @@ DEFAULT_LIN_TOL = 3.0e-2
 # SuperLU factorisations): same ODE, same error control, ~15 % fewer simplified-Newton iterations
 # (DESIGN.md section 3).  0 (or NK2D_JAC_FRESH=0 in the environment) follows SciPy decision for decision.
 DEFAULT_JAC_FRESH = 1
+# Stage whose time the Jacobian of a step attempt is taken at (nk2d_set_option "jac_stage"): 1 = t + 0.645 h, the
+# second Radau node, instead of the step start (-1, SciPy).  The vertical mixing coefficient changes over a step;
+# the simplified Newton iteration and the filter of the error estimate both work with ONE Jacobian for the three
+# stages, and the one near the middle of the stage times (0.155, 0.645, 1) h is at most 0.49 h away from any of them
+# instead of a whole h: at 416^2 a forward year takes 2617 steps and 10.9 k Newton iterations instead of 3568 and
+# 17.5 k (0.46 s against 0.67 s), the result 0.06 of the CI tolerance away from the one with the Jacobian at the step
+# start (tools/probe_jac_stage.py).  The plane of that time is computed for the stage anyway --
+# the launch that computes it derives the Jacobian planes from it.  Modules whose Jacobian reads the state
+# (phosphorus, a thresholded sink) keep the step start.  NK2D_JAC_STAGE in the environment overrides.
+DEFAULT_JAC_STAGE = 1
 # largest growth factor of the step size after a step whose simplified Newton iteration failed at first and was
 # repeated with half the step size (nk2d_set_option "growth_cap"): 1.0 is the rule of Hairer & Wanner's RADAU5
 # (no growth), which SciPy's Radau dropped -- it tries up to 10 h again and fails on a third of its attempts here.
@@ -151,6 +161,7 @@ class ModuleEngine:
             self.set_option("device_ctl", 3)
         self.set_option("jac_fresh", float(os.environ.get("NK2D_JAC_FRESH", DEFAULT_JAC_FRESH)))
         self.set_option("growth_cap", float(os.environ.get("NK2D_GROWTH_CAP", DEFAULT_GROWTH_CAP)))
+        self.set_option("jac_stage", float(os.environ.get("NK2D_JAC_STAGE", DEFAULT_JAC_STAGE)))
 
     def close(self):
         if self._ctx is not None:
@@ -284,6 +295,21 @@ class ModuleEngine:
         launches, nbytes = ctypes.c_int64(), ctypes.c_double()
         self._chk(self._lib.nk2d_profile_totals(self._ctx, ctypes.byref(launches), ctypes.byref(nbytes)))
         return {"launches": launches.value, "bytes": nbytes.value}
+
+    def profile_shapes(self):
+        """non-factorising launches of the dominant kernel since profile_reset by shape (stage + sweep + update,
+        stage + first sweep, last sweep + update, middle sweep): counts and algorithmic bytes"""
+        counts = (ctypes.c_int64 * 4)()
+        nbytes = (ctypes.c_double * 4)()
+        self._chk(self._lib.nk2d_profile_shapes(self._ctx, counts, nbytes))
+        return {"counts": list(counts), "bytes": list(nbytes)}
+
+    def profile_replay(self, shape, n=200):
+        """n back-to-back launches of one shape of the dominant kernel inside one event pair (state of the last
+        forward year, updates to scratch): microseconds per launch and algorithmic bytes per launch"""
+        avg, nbytes = ctypes.c_double(), ctypes.c_double()
+        self._chk(self._lib.nk2d_profile_replay(self._ctx, int(shape), int(n), ctypes.byref(avg), ctypes.byref(nbytes)))
+        return {"avg_us": avg.value, "bytes": nbytes.value}
 
     def timer_begin(self):
         """first event of a HIP event pair on the context's own stream"""

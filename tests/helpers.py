@@ -21,15 +21,17 @@ def rel_err(a, b):
 def free_years(eng, x, **kw):
     """one free-running forward year with SciPy's controller decision for decision (Jacobian reuse of
     radau.py:509-517, no memory of Newton failures: the mode whose counters are comparable with solve_ivp's)
-    and one in the engine's default mode (Jacobian re-evaluated at every step start, RADAU5's no-growth rule
+    and one in the engine's default mode (Jacobian re-evaluated for every step attempt, at its second stage time
     after a Newton failure): ((fx, stats, sched), (fx, stats, sched))"""
-    from nk_ooc_amd.engine import DEFAULT_GROWTH_CAP, DEFAULT_JAC_FRESH
+    from nk_ooc_amd.engine import DEFAULT_GROWTH_CAP, DEFAULT_JAC_FRESH, DEFAULT_JAC_STAGE
 
     eng.set_option("jac_fresh", 0)
     eng.set_option("growth_cap", 0)
+    eng.set_option("jac_stage", -1)
     try:
         faithful = eng.comp_fcn(x, **kw)
     finally:
         eng.set_option("jac_fresh", DEFAULT_JAC_FRESH)
         eng.set_option("growth_cap", DEFAULT_GROWTH_CAP)
+        eng.set_option("jac_stage", DEFAULT_JAC_STAGE)
     return faithful, eng.comp_fcn(x, **kw)

@@ -95,10 +95,19 @@ def test_replay_schedule_is_validated():
     bad[0, 0] = 10.0                       # does not start where the state is
     with pytest.raises(Nk2dError, match="replay schedule"):
         eng.comp_fcn(x, replay=bad)
-    bad = sched.copy()
+    # a Jacobian that is a function of time alone may be scheduled at any time (the engines' default takes it at the
+    # second stage time of every attempt); one that reads the state only where the state is -- at a step start
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    ph = phosphorus_engine(Grid2d.default(20, 6))
+    y0 = np.stack([np.full((20, 6), 2.0), np.full((20, 6), 0.05), np.full((20, 6), 0.01)])
+    _, _, sched_ph = ph.comp_fcn(ph.upload(y0), record=True)
+    bad = sched_ph.copy()
     bad[5, 4] = bad[5, 0] + 1.0            # Jacobian refreshed off a step start
     with pytest.raises(Nk2dError, match="replay schedule"):
-        eng.comp_fcn(x, replay=bad)
+        ph.comp_fcn(ph.upload(y0), replay=bad)
+    ph.close()
     with pytest.raises(Nk2dError, match="record buffer"):
         eng.comp_fcn(x, record=True, record_cap=8)
     # the context is usable afterwards and reproduces the recorded run (to SciPy's Newton tolerance: the replay

@@ -109,3 +109,29 @@ def test_team_forced_file_bitwise(nz):
     res, _, counters = _year_variants(eng, x)
     assert np.isfinite(res).all() and counters["nsteps"] > 10
     eng.close()
+
+
+def test_profile_replay_and_shapes():
+    """measurement plumbing of bench.py: launch-shape tallies of a year and the back-to-back replay of each shape;
+    the replay writes to scratch only -- the next year is bit-identical to the one before it"""
+    eng = make_engine(26, 26)
+    model, _ = oracle_iage(26, 26)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2).copy())
+    eng.set_option("device_ctl", 0)
+    with pytest.raises(Exception, match="forward year"):
+        eng.profile_replay(0, 4)
+    eng.profile_reset(0)
+    fx, stats, _ = eng.comp_fcn(x)
+    first = eng.download(fx)
+    shapes = eng.profile_shapes()
+    totals = eng.profile_totals()
+    assert sum(shapes["counts"]) + stats["nlu"] // 2 >= totals["launches"] - stats["nlu"]   # the rest factorise
+    assert sum(shapes["counts"]) > 0 and all(b >= 0.0 for b in shapes["bytes"])
+    for shape in range(3):
+        rep = eng.profile_replay(shape, 20)
+        assert 0.5 < rep["avg_us"] < 500.0 and rep["bytes"] > 0.0
+    with pytest.raises(Exception, match="shape"):
+        eng.profile_replay(3, 4)
+    fx2, _, _ = eng.comp_fcn(x)
+    assert np.array_equal(eng.download(fx2), first)
