@@ -107,7 +107,7 @@ def cpu_baseline(grid_n, gpu_attempts_per_year, budget_s):
     how = (f"one full forward year in {res['wall_s']:.1f} s" if res["full_year"] else
            f"first {res['attempts']} Radau step attempts in {res['wall_s']:.1f} s "
            f"({res['wall_s'] / max(res['attempts'], 1):.2f} s each), scaled to the {gpu_attempts_per_year} "
-           f"attempts the GPU run needed per forward year")
+           f"attempts a forward year takes under SciPy's decisions (counted by a GPU year in that mode)")
     return {
         "value": 1.0 / sec,
         "unit": "JVPs/s",
@@ -177,7 +177,9 @@ def roofline_of(eng, n):
     win_bytes_per_launch = prof["bytes"] / samples
     net_us = max(prof["avg_us"], 1e-3)
     raw_us = net_us + prof["event_overhead_us"] * prof["windows"] / samples
-    persistent = getattr(eng, "device_ctl", 0) == 3
+    # the years of the timed region are frozen years (host-launched replays of the base year's steps) unless
+    # NK2D_JVP_FROZEN=0 leaves them to the engine's own mode, which may be the persistent kernel
+    persistent = getattr(eng, "device_ctl", 0) == 3 and os.environ.get("NK2D_JVP_FROZEN", "1") == "0"
     windows = {
         "what": "HIP event pairs around the launches of single Newton iterations inside the timed region",
         "avg_launch_us_event_cost_included": raw_us,
@@ -291,10 +293,14 @@ def run_ladder(device_ordinal, device, args):
             row = {"grid": n, "jvps_per_s": args.ladder_steps / elapsed,
                    "ms_per_jvp": 1000.0 * elapsed / args.ladder_steps,
                    "forward_year_s": st["seconds"], "nsteps": st["nsteps"], "nlaunch": st["nlaunch"],
+                   "base_year_free_running_s": wl.fwd_stats["seconds"],
                    "roofline_frac": roof["frac"], "avg_launch_us": roof["avg_launch_us"],
                    "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]}
             if args.cpu_baseline_seconds > 0:
-                attempts = st["nsteps"] + st["nrejected"]
+                wl.eng.set_option("jac_fresh", 0)       # attempts of a year under SciPy's decisions, as the oracle takes them
+                _, st_f, _ = wl.eng.comp_fcn(wl.iterate.tracer_modules[0].vec)
+                wl.eng.set_option("jac_fresh", integrator_mode()["jac_fresh"])
+                attempts = st_f["nsteps"] + st_f["nrejected"]
                 cpu = cpu_oracle_year(n, cpu_full.get(n, 12.0), attempts)
                 if "seconds_per_year" in cpu:
                     row["cpu_oracle"] = {"seconds_per_year": cpu["seconds_per_year"], "full_year": cpu["full_year"],
@@ -331,10 +337,14 @@ def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, allreduces_
             comm.allreduce_scalar(1.0)
         latency = (time.perf_counter() - t0) / 200
         scale = (n / float(args.grid)) ** 0.5 if args.grid else 1.0       # steps grow like sqrt(n) on this ladder
-        expected = 2.0 * (allreduces_hint * scale * latency + one_gpu_ms / 1000.0)
+        # untimed: F(x), a coupled year (one all-reduce per Newton iteration and error estimate); timed: one Krylov
+        # iteration whose perturbed year repeats the steps of that year and exchanges nothing
+        expected = allreduces_hint * scale * latency + 3.0 * one_gpu_ms / 1000.0
         verdict = torch.tensor([expected], dtype=torch.float64)
-        result = {"layout": "ONE iage module, tracer per rank on ranks 0 and 1 (block-diagonal Jacobian); every "
-                            "Radau norm and every Krylov inner product is an all-reduce(SUM) of 1 .. (j+1) nreg doubles",
+        result = {"layout": "ONE iage module, tracer per rank on ranks 0 and 1 (block-diagonal Jacobian); the year that gives "
+                            "F(x) all-reduces every Radau norm (untimed), the perturbed years of the Krylov iterations repeat "
+                            "its accepted steps and exchange nothing; every Krylov inner product is an all-reduce(SUM) of "
+                            "1 .. (j+1) nreg doubles",
                   "backend": backend, "grid": [n, n], "allreduce_latency_us": 1.0e6 * latency,
                   "expected_seconds": expected, "one_gpu_ms_per_jvp": one_gpu_ms}
         if expected > args.shard_budget:
@@ -344,13 +354,16 @@ def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, allreduces_
             eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(grid.depth.delta, grid.ypos.delta))
             col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
             x = eng.upload(np.broadcast_to(col[:, None], (1, n, n)).copy())
+            calls_base = comm.calls
             fx, _, _ = eng.comp_fcn(x)                      # F(x): a coupled year, untimed
+            sched = eng.last_schedule()
+            result["allreduces_of_the_coupled_year"] = comm.calls - calls_base
             eng.precond_setup()
             eng.sync()
             calls0 = comm.calls
             tdist.barrier(group=group)
             t0 = time.perf_counter()
-            _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 1)
+            _, info = nkdist.sharded_gmres(eng, comm, x, fx, 0.0, 0, 1, sched=sched)
             eng.sync()
             tdist.barrier(group=group)
             elapsed = time.perf_counter() - t0
@@ -441,6 +454,7 @@ def main():
         out = None
         if rank == 0:
             total_jvps = args.steps * world
+            year_keys = ("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps", "nlaunch", "seconds")
             totals = eng.profile_totals()
             roof = roofline_of(eng, n)
             out = {
@@ -477,18 +491,35 @@ def main():
                     "achieved_GBs_per_gpu": totals["bytes"] / elapsed / 1e9,
                     "frac_of_hbm_peak": totals["bytes"] / elapsed / 1e9 / HBM_PEAK_GBS,
                 },
-                "forward_year": {k: jvp_stats[k] for k in
-                                 ("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps",
-                                  "nlaunch", "seconds")},
+                "jvp": {
+                    "mode": ("frozen controller (internal numerical differentiation): the perturbed year of every product "
+                             "repeats the accepted steps, Newton iteration counts, Jacobian times and factorisations of "
+                             "the free-running year that produced F(x), checked afterwards against SciPy's Newton "
+                             "convergence test; NK2D_JVP_FROZEN=0 gives two free-running years as the reference has them"
+                             if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else "free-running perturbed years"),
+                    "perturbed_year": {k: jvp_stats[k] for k in year_keys},
+                    "base_year_free_running": {k: wl.fwd_stats[k] for k in year_keys},
+                    "frozen_years_rejected": eng.frozen_fallbacks(),
+                },
                 "setup_seconds": {"total": wl.setup_s, "precond_factorisation": wl.precond_setup_s},
             }
             if world == 1:
                 out["roofline_precond"] = precond_roofline(eng)
         one_gpu_ms = 1000.0 * elapsed / args.steps
+        wl_base_stats = dict(wl.fwd_stats)
+        faithful_attempts = None
+        if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:
+            # the CPU baseline restates the reference's integrator (SciPy's decisions): what one of ITS years needs is
+            # counted by a year of this engine in that mode (counters within 10 % of solve_ivp's, tests/test_gpu_comp_fcn.py)
+            eng.set_option("jac_fresh", 0)
+            _, st_f, _ = eng.comp_fcn(wl.iterate.tracer_modules[0].vec)
+            eng.set_option("jac_fresh", integrator_mode()["jac_fresh"])
+            faithful_attempts = st_f["nsteps"] + st_f["nrejected"]
         wl.close()
         wl = None
         if world >= 2 and not args.no_shard:
-            hint = jvp_stats["nnewton"] + 2 * (jvp_stats["nsteps"] + jvp_stats["nrejected"]) + 10
+            base = wl_base_stats
+            hint = base["nnewton"] + 2 * (base["nsteps"] + base["nrejected"]) + 10
             shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
             if rank == 0:
                 out["shard_e2"] = shard
@@ -501,8 +532,7 @@ def main():
                                       "avg_launch_us": out["roofline"]["avg_launch_us"],
                                       "algorithmic_bytes_per_launch": out["roofline"]["algorithmic_bytes_per_launch"]})
             if world == 1 and args.cpu_baseline_seconds > 0:
-                attempts = jvp_stats["nsteps"] + jvp_stats["nrejected"]
-                out["cpu_baseline"] = cpu_baseline(n, attempts, args.cpu_baseline_seconds)
+                out["cpu_baseline"] = cpu_baseline(n, faithful_attempts, args.cpu_baseline_seconds)
                 out["cpu_baseline"]["host_cpus"] = os.cpu_count()
                 if "ladder" in out:
                     out["ladder"][-1]["cpu_oracle"] = {
@@ -517,9 +547,11 @@ def main():
 
 def integrator_mode():
     """the controller mode of the forward years in this run (engine defaults, overridable from the environment)"""
-    from nk_ooc_amd.engine import DEFAULT_JAC_FRESH, DEFAULT_LIN_TOL
+    from nk_ooc_amd.engine import DEFAULT_JAC_FRESH, DEFAULT_JAC_STAGE, DEFAULT_LIN_TOL
 
     return {"jac_fresh": int(float(os.environ.get("NK2D_JAC_FRESH", DEFAULT_JAC_FRESH))),
+            "jac_stage": int(float(os.environ.get("NK2D_JAC_STAGE", DEFAULT_JAC_STAGE))),
+            "jvp_frozen": os.environ.get("NK2D_JVP_FROZEN", "1") != "0",
             "lin_tol": float(os.environ.get("NK2D_LIN_TOL", DEFAULT_LIN_TOL)), "rtol": 1.0e-6, "atol": 1.0e-6}
 
 

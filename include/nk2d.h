@@ -169,6 +169,29 @@ int nk2d_shifted_solve(nk2d_ctx* ctx, double t_jac, double h, double mu_re, doub
 int nk2d_comp_fcn(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats,
                   const double* replay, int64_t replay_n,
                   double* record, int64_t record_cap, int64_t* record_n);
+/* The finite-difference product of the reference, (F(x + sigma v) - F(x)) / sigma with sigma = 1e-4 |x|
+   (model_state_base.py:492-527), differences two years of an ADAPTIVE integrator: wherever the two controllers
+   decide differently (a rejected step, another Newton iteration) the difference of their discretisation errors,
+   divided by sigma, lands in the product -- measured here at 5 % ... 90 % of |w| for the first Krylov direction, in
+   every controller mode including SciPy's own (tools/probe_jvp_noise.py).  Internal numerical differentiation removes
+   it: the perturbed year repeats the accepted steps, Newton iteration counts, Jacobian times and factorisations of
+   the year that produced F(x), which makes w the derivative of ONE discrete map.
+   nk2d_comp_fcn_frozen: forward year on a schedule recorded by nk2d_comp_fcn on this context under the same options,
+   with the recorded year's own inner tolerance, nothing decided and nothing read back (for the recorded x itself it
+   reproduces the recorded year bit for bit).
+   nk2d_set_frozen_schedule: the schedule the perturbed years of nk2d_jvp / nk2d_gmres_solve repeat from now on
+   (copied; sched_n = 0 returns them to free-running years). */
+int nk2d_comp_fcn_frozen(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* sched, int64_t sched_n);
+int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n);
+/* A frozen year checks afterwards, for every step, SciPy's Newton convergence test on the last recorded iteration
+   (with a slack of 30) -- one device reduction per step, folded into the step-boundary launch, one read-back per year.
+   A state for which the recorded counts are not enough makes nk2d_comp_fcn_frozen return -7; nk2d_jvp then runs a
+   free-running year instead.  n: how often that has happened on this context. */
+int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
+/* accepted steps of the most recent free-running year of this context (whichever entry point ran it: nk2d_comp_fcn,
+   nk2d_comp_fcn_hist, the perturbed year of a free-running nk2d_jvp): n rows of NK2D_SCHED_WIDTH doubles; out may be
+   NULL to ask for n only */
+int nk2d_last_schedule(nk2d_ctx* ctx, double* out, int64_t cap, int64_t* n);
 
 /* the same forward year with dense output: the solution at the n_eval increasing times t_eval
    (within [t0, t1]) is written to host_hist [n_eval][tc][nz][ny], evaluated from each step's

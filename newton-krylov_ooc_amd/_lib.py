@@ -110,6 +110,10 @@ SIGNATURES = {
     "nk2d_shifted_solve": (_ci, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, c_int32_p]),
     "nk2d_comp_fcn": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), c_double_p, _i64,
                             c_double_p, _i64, c_int64_p]),
+    "nk2d_comp_fcn_frozen": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), c_double_p, _i64]),
+    "nk2d_set_frozen_schedule": (_ci, [_vp, c_double_p, _i64]),
+    "nk2d_last_schedule": (_ci, [_vp, c_double_p, _i64, c_int64_p]),
+    "nk2d_frozen_fallbacks": (_ci, [_vp, c_int64_p]),
     "nk2d_comp_fcn_hist": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), _i32, c_double_p, c_double_p]),
     "nk2d_precond_setup": (_ci, [_vp]),
     "nk2d_precond_setup_states": (_ci, [_vp, ctypes.POINTER(_vp)]),

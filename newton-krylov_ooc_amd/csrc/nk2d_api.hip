@@ -380,6 +380,9 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->TMP, c->nv));
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
+    NK2D_TRY(dev_alloc(c, &c->PART2, (size_t)c->ncol));
+    NK2D_TRY(dev_alloc(c, &c->STEP_NORM, (size_t)2 * NK2D_OWN_REC_CAP));
+    c->frozen_fallbacks = 0;
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
     NK2D_TRY(dev_alloc(c, &c->DCTL, (size_t)8));
     NK2D_TRY(dev_alloc(c, &c->ICTL, (size_t)8));
@@ -512,7 +515,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
-                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->RED, c->STAGE, c->RCOEF,
+                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->RED, c->STAGE, c->RCOEF,
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN,
                       c->SMSREC, c->RESTREC};
     for (double* b : bufs)
@@ -773,6 +776,37 @@ extern "C" int nk2d_comp_fcn(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* s
     NK2D_CHECK(c, hipSetDevice(c->dev));
     if (record_n) *record_n = 0;
     return nk2d_radau_year(c, x, fx, stats, replay, replay_n, record, record_cap, record_n);
+}
+
+// forward year on a schedule this library recorded itself (nk2d_comp_fcn with `record`) under the same options: the
+// steps, Newton iteration counts, Jacobian times and factorisations of the recorded year with its own inner tolerance
+// and no decision taken -- for x itself the recorded year again, bit for bit; for x + sigma v the same discrete map
+extern "C" int nk2d_comp_fcn_frozen(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* sched,
+                                    int64_t sched_n) {
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    if (!sched || sched_n < 1) return nk2d_fail(c, "nk2d_comp_fcn_frozen: empty schedule");
+    return nk2d_radau_year(c, x, fx, stats, sched, sched_n, nullptr, 0, nullptr, true);
+}
+
+extern "C" int nk2d_frozen_fallbacks(nk2d_ctx* c, int64_t* n) {
+    if (n) *n = c->frozen_fallbacks;
+    return 0;
+}
+
+extern "C" int nk2d_last_schedule(nk2d_ctx* c, double* out, int64_t cap, int64_t* n) {
+    const int64_t rows = (int64_t)(c->last_sched.size() / NK2D_SCHED_WIDTH);
+    if (n) *n = rows;
+    if (out) {
+        if (cap < rows) return nk2d_fail(c, "nk2d_last_schedule: buffer too small", -4);
+        std::memcpy(out, c->last_sched.data(), sizeof(double) * c->last_sched.size());
+    }
+    return 0;
+}
+
+extern "C" int nk2d_set_frozen_schedule(nk2d_ctx* c, const double* sched, int64_t sched_n) {
+    if (sched_n < 0 || (sched_n > 0 && !sched)) return nk2d_fail(c, "nk2d_set_frozen_schedule: bad arguments");
+    c->frozen_sched.assign(sched, sched + (size_t)sched_n * NK2D_SCHED_WIDTH);
+    return 0;
 }
 
 // samples of the solution at t_eval (scipy ivp.py:707-723: every t_eval <= t not yet emitted is

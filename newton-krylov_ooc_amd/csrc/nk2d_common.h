@@ -28,6 +28,7 @@
 #define NK2D_WAVES_PER_BLOCK 4
 #define NK2D_BLOCK (NK2D_WAVE * NK2D_WAVES_PER_BLOCK)
 #define NK2D_MAX_E 8
+#define NK2D_OWN_REC_CAP 65536   /* rows of the context's own schedule record */
 
 struct nk2d_ctx {
     nk2d_desc d;
@@ -75,6 +76,9 @@ struct nk2d_ctx {
     // the old ones from Z in the same launch, then Z and ZN swap
     double* ZN /*3nv*/;
     int min_sweeps;    // least sweeps per solve where columns couple (option "min_sweeps": 1 default, 2 = round-1 rule)
+    std::vector<double> last_sched;     // accepted steps of the most recent free-running year (nk2d_last_schedule)
+    std::vector<double> own_rec;        // its record buffer when the caller gave none
+    std::vector<double> frozen_sched;   // accepted steps the perturbed years of nk2d_jvp repeat (nk2d_set_frozen_schedule)
     int jac_stage;     // >= 0: Jacobian of a step attempt from the vertical mixing plane of this stage time (option "jac_stage"); -1: step start
     int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
     int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
@@ -104,6 +108,9 @@ struct nk2d_ctx {
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
+    double* PART2;   // second buffer [ncol]: a replayed year keeps the partials of the last two Newton iterations of a step
+    double* STEP_NORM;  // [2 * NK2D_OWN_REC_CAP] per step of a frozen year: sum((dW/scale)^2) of its last and last-but-one iteration
+    int64_t frozen_fallbacks;   // frozen years rejected by the a-posteriori Newton check (nk2d_frozen_fallbacks)
     double* RED;     // reduced scalars (device)
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
@@ -512,7 +519,9 @@ int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part);
 int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part);
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv);
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2, int jac_stage = -1);
+                         double x0, double x1, double x2, int jac_stage = -1, bool with_tend = true,
+                         const double* part_last = nullptr, const double* part_prev = nullptr, double* norm_out = nullptr);
+int nk2d_r_step_norms(nk2d_ctx* c, const double* part_last, const double* part_prev, double* out);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 int nk2d_prof_window_begin(nk2d_ctx* c);
@@ -542,6 +551,6 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
 // nk2d_radau.hip
 int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first);
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,
-                    int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n);
+                    int64_t replay_n, double* record, int64_t record_cap, int64_t* record_n, bool replay_own = false);
 // nk2d_precond.hip
 void nk2d_precond_free(nk2d_ctx* c);

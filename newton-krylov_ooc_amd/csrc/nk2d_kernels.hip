@@ -2088,6 +2088,12 @@ struct BoundaryArgs {
     double *JL, *JU, *JS, *JN, *JC;
     int do_jac, nblk_vmix, nblk_jac;
     int jac_stage;                     // >= 0: Jacobian from the new plane of this stage (by the wave that computes it); then do_jac = 0
+    int with_tend;                     // 0: y_new only (step replay: no error estimate will ask for f(t_new, y_new))
+    // frozen year: one more workgroup adds up the norm partials the last two Newton iterations of the step left behind
+    // (part_prev null: the step had one iteration) into norm_out[0], norm_out[1]
+    const double *part_last, *part_prev;
+    double* norm_out;
+    int npart;
 };
 
 template <int E, int KIND>
@@ -2115,17 +2121,50 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V
         return;
     }
     blk -= B.nblk_jac;
+    if (B.norm_out != nullptr && blk == (P.ncol + wpb - 1) / wpb) {
+        __shared__ double sh[NK2D_BLOCK];
+        const double s_last = block_sum(B.part_last, B.npart, sh);
+        __syncthreads();
+        const double s_prev = (B.part_prev != nullptr) ? block_sum(B.part_prev, B.npart, sh) : -1.0;
+        if (threadIdx.x == 0) { B.norm_out[0] = s_last; B.norm_out[1] = s_prev; }
+        return;
+    }
     const int task = blk * wpb + wave;
     if (task >= P.ncol) return;
-    commit_tend_body<E, KIND, 0>(P, B.y, B.z2, B.kv_new, B.ynew, B.f, task, lane);
+    if (B.with_tend) {
+        commit_tend_body<E, KIND, 0>(P, B.y, B.z2, B.kv_new, B.ynew, B.f, task, lane);
+    } else {
+        double c[E], t0[E];
+        load_col<E>(B.y, task, lane, c);
+        load_col<E>(B.z2, task, lane, t0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
+        store_col<E>(B.ynew, task, lane, c);
+    }
     predict_body<E>(A, task, lane);
+}
+
+__global__ void k_step_norms(const double* __restrict__ part_last, const double* __restrict__ part_prev, int n,
+                             double* __restrict__ out) {
+    __shared__ double sh[NK2D_BLOCK];
+    const double s_last = block_sum(part_last, n, sh);
+    __syncthreads();
+    const double s_prev = (part_prev != nullptr) ? block_sum(part_prev, n, sh) : -1.0;
+    if (threadIdx.x == 0) { out[0] = s_last; out[1] = s_prev; }
+}
+int nk2d_r_step_norms(nk2d_ctx* c, const double* part_last, const double* part_prev, double* out) {
+    hipLaunchKernelGGL(k_step_norms, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, part_last, part_prev, c->ncol, out);
+    NK2D_CHECK(c, hipGetLastError());
+    c->st.nlaunch++;
+    return 0;
 }
 
 // commit of the step just taken + (optionally) the Jacobian at t_new + set-up of the attempt that starts at t_new
 // with stage times `times` (planes into out[0..2]) and dense-output abscissae x0..x2.  Buffers are taken in their
 // roles BEFORE the caller swaps them: y_new goes to YOLD, the predicted stage values to ZP.
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2, int jac_stage) {
+                         double x0, double x1, double x2, int jac_stage, bool with_tend, const double* part_last,
+                         const double* part_prev, double* norm_out) {
     VmixArgs V;
     for (int i = 0; i < 3; ++i) {
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
@@ -2139,6 +2178,8 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
     B.JL = c->JL; B.JU = c->JU; B.JS = c->JS; B.JN = c->JN; B.JC = c->JC;
     B.do_jac = do_jac ? 1 : 0;
     B.jac_stage = jac_stage;
+    B.with_tend = with_tend ? 1 : 0;
+    B.part_last = part_last; B.part_prev = part_prev; B.norm_out = norm_out; B.npart = c->ncol;
     if (jac_stage >= 0 && do_jac) return nk2d_fail(c, "nk2d_r_step_boundary: Jacobian at t_new and at a stage time requested together");
     B.nblk_vmix = nk2d_grid(c->ny * 3);
     B.nblk_jac = do_jac ? nk2d_grid(c->ny) : 0;
@@ -2148,7 +2189,7 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
     A.x0 = x0; A.x1 = x1; A.x2 = x2;
     DevP P = make_devp(c);
     P.guard = nullptr;
-    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol)),
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol) + (norm_out ? 1 : 0)),
                                                          dim3(NK2D_BLOCK), 0, c->stream, P, V, B, A));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
@@ -2382,7 +2423,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     // neighbouring columns are still reading -- it writes the spare buffer, the buffers swap after the launch
     const bool swap_z = do_stage && do_update && c->single_swap;
     A.st.zout = swap_z ? c->ZN : c->Z;
-    A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : c->PART;
+    A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : (c->part_cur ? c->part_cur : c->PART);
     // pivots / PCR tables of a new (h, J): computed inside the first launch that uses them
     bool do_factor = c->factor_pending != 0;
     if (do_factor && !do_stage) {  // not expected: the first launch after an "LU" event evaluates the stages

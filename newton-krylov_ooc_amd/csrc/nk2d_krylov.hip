@@ -209,7 +209,18 @@ extern "C" int nk2d_jvp(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_vec v, nk2d_v
     if (!fp) NK2D_TRY(tmp.add(&fp));
     // perturb_ms = self + sigma * direction (:515)
     NK2D_TRY(nk2d_axpby(c, xp, one.data(), x, sigma.data(), v));
-    NK2D_TRY(nk2d_radau_year(c, xp, fp, stats, nullptr, 0, nullptr, 0, nullptr));
+    // the perturbed year: free-running, or -- with a schedule installed (nk2d_set_frozen_schedule: the accepted steps
+    // of the year that produced fx) -- on exactly those steps, so that w is the derivative of ONE discrete map
+    // instead of the difference of two maps whose adaptive controllers took different decisions
+    int rc = -7;
+    if (!c->frozen_sched.empty()) {
+        rc = nk2d_radau_year(c, xp, fp, stats, c->frozen_sched.data(),
+                             (int64_t)(c->frozen_sched.size() / NK2D_SCHED_WIDTH), nullptr, 0, nullptr, true);
+        // -7: the recorded iteration counts do not converge for the perturbed state -- a free-running year instead
+        // (counted, nk2d_frozen_fallbacks); not with a norm hook, where every shard would have to fall back together
+        if (rc != 0 && (rc != -7 || c->norm_hook)) return rc;
+    }
+    if (rc == -7) NK2D_TRY(nk2d_radau_year(c, xp, fp, stats, nullptr, 0, nullptr, 0, nullptr));
     // (perturb_fcn - fcn) / sigma (:523)
     NK2D_TRY(nk2d_diff_scale(c, w, fp, fx, rsig.data()));
     if (sigma_out) std::memcpy(sigma_out, sigma.data(), sizeof(double) * nreg);

@@ -23,6 +23,8 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -162,14 +164,18 @@ int newton_iteration(Ctl& s, double mreal, double mcr, double mci) {
 }
 
 // Replay: exactly n_iters simplified-Newton iterations, no tests, nothing read back.
+// The norm partials of iteration k go to PART (k even) / PART2 (k odd): a frozen year checks afterwards that the
+// recorded iteration counts were enough for ITS state (run_replay).
 int newton_fixed(Ctl& s, double h, int n_iters) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
     for (int k = 0; k < n_iters; ++k) {
+        c->part_cur = (k & 1) ? c->PART2 : c->PART;
         NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
         c->st.nfev += 3;
         c->st.nnewton++;
     }
+    c->part_cur = nullptr;
     return 0;
 }
 
@@ -655,30 +661,136 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
     return 0;
 }
 
-int run_replay(Ctl& s, const double* sched, int64_t n) {
+// Step replay: the accepted steps of a recorded year (SciPy's, for the 1e-10 parity checks; this library's own, for
+// the finite-difference products with a frozen controller) with no decisions and nothing read back -- the whole year
+// is queued without a host round trip.  With host-side launches (device_ctl 0) the year runs on the launches of the
+// free-running loop: step boundary (commit + planes + predicted stage values + Jacobian of the next row) and fused
+// Newton iterations; a row whose Jacobian time is a stage time of its own attempt takes the Jacobian from that
+// stage's plane, as the free run with option "jac_stage" does.
+int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
     nk2d_ctx* c = s.c;
+    if (check_newton && n > NK2D_OWN_REC_CAP) return nk2d_fail(c, "nk2d_comp_fcn_frozen: schedule too long", -4);
     double h_lu_cur = 0.0;
     bool have = false;
+    const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
+    const bool fast = s.device_ctl == 0 && c->hist_n == 0;
+    // stage of the attempt (t, h) whose time is t_jac, or -1
+    auto stage_of = [&](double t, double h, double t_jac) {
+        if (needs_state || !fast) return -1;
+        for (int k = 0; k < 3; ++k)
+            if (t_jac == t + (h * RC[k])) return k;
+        return -1;
+    };
+    int pre_jstage = -1;       // stage whose Jacobian the boundary launch of the row before derived for this row
     for (int64_t i = 0; i < n; ++i) {
         const double* r = sched + i * NK2D_SCHED_WIDTH;
         const double t = r[0], t_new = r[1], h = r[2], t_jac = r[4], h_lu = r[5];
         const int n_iter = (int)r[3];
         if (t != s.t) return nk2d_fail(c, "nk2d_comp_fcn: replay schedule does not start where the state is", -5);
+        // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
+        // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
+        if (t_jac != s.t_jac && t_jac != t && needs_state)
+            return nk2d_fail(c, "nk2d_comp_fcn: replay schedule refreshes the Jacobian off a step start", -5);
+        const int jstage = (t_jac != s.t_jac) ? stage_of(t, h, t_jac) : -1;
+        bool predicted = false, jac_done = false;
+        if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
+            predicted = true;
+            jac_done = jstage >= 0 && pre_jstage == jstage;
+        } else if (fast && s.have_dense) {
+            NK2D_TRY(setup_attempt(s, t, h, jstage));
+            predicted = true;
+            jac_done = jstage >= 0;
+        } else {
+            NK2D_TRY(stage_planes(s, t, h));
+        }
+        s.pre_setup = false;
+        pre_jstage = -1;
         if (t_jac != s.t_jac) {
-            // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
-            // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
-            const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
-            if (t_jac != t && needs_state)
-                return nk2d_fail(c, "nk2d_comp_fcn: replay schedule refreshes the Jacobian off a step start", -5);
-            NK2D_TRY(refresh_jac(s, t_jac, false));
+            if (jstage >= 0) {
+                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[jstage], nullptr));
+                s.t_jac = t_jac;
+            } else {
+                NK2D_TRY(refresh_jac(s, t_jac, false));
+            }
             c->st.njev++;
             have = false;
         }
         if (!have || h_lu != h_lu_cur) { NK2D_TRY(set_lu(s, h_lu)); h_lu_cur = h_lu; have = true; }
-        NK2D_TRY(stage_planes(s, t, h));
-        NK2D_TRY(predict(s, t, h));
+        if (!predicted) NK2D_TRY(predict(s, t, h));
         NK2D_TRY(newton_fixed(s, h, n_iter));
-        NK2D_TRY(commit_step(s, t, t_new));
+        // where the partials of the last two iterations are, for the a-posteriori check of a frozen year
+        const double* part_last = (check_newton && n_iter >= 1) ? (((n_iter - 1) & 1) ? c->PART2 : c->PART) : nullptr;
+        const double* part_prev = (check_newton && n_iter >= 2) ? (((n_iter - 2) & 1) ? c->PART2 : c->PART) : nullptr;
+        double* norm_out = part_last ? c->STEP_NORM + 2 * i : nullptr;
+        // boundary: with a next row that starts where this one ends, its planes, predicted stage values and (where its
+        // Jacobian time is the step start or one of its stage times) its Jacobian come with the commit
+        const double* r2 = (i + 1 < n) ? r + NK2D_SCHED_WIDTH : nullptr;
+        if (fast && r2 && t + h == t_new && r2[0] == t_new && r2[2] > 0.0 && std::isfinite(r2[2])) {
+            const double h2 = r2[2], t_jac2 = r2[4];
+            const bool jac_new = t_jac2 != s.t_jac;
+            const int jstage2 = jac_new ? stage_of(t_new, h2, t_jac2) : -1;
+            const bool jac_at_tnew = jac_new && jstage2 < 0 && t_jac2 == t_new && !needs_state;
+            double times[3], x[3];
+            for (int k = 0; k < 3; ++k) {
+                times[k] = t_new + (h2 * RC[k]);
+                x[k] = ((t_new + h2 * RC[k]) - t) / (t_new - t);
+            }
+            double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
+            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_at_tnew, times, out, x[0], x[1], x[2], jstage2, false,
+                                          part_last, part_prev, norm_out));
+            std::swap(c->KV[3], c->KV[2]);
+            std::swap(c->Y, c->YOLD);
+            std::swap(c->Z, c->ZP);
+            s.have_dense = true;
+            s.dense_t_old = t;
+            s.dense_h = t_new - t;
+            s.t = t_new;
+            c->st.nsteps++;
+            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2;
+            pre_jstage = jstage2;
+            if (jac_at_tnew) {
+                s.t_jac = t_new;
+                c->st.njev++;
+                have = false;
+            }
+        } else {
+            if (norm_out) NK2D_TRY(nk2d_r_step_norms(c, part_last, part_prev, norm_out));
+            NK2D_TRY(commit_step(s, t, t_new));
+        }
+    }
+    if (check_newton && n > 0) {
+        // SciPy's convergence test (radau.py:120-129) on what the LAST recorded iteration of every step left, with
+        // slack: the perturbed state of a finite-difference product converges like the state the schedule was
+        // recorded for, give or take; a state that does not (the recorded year converged at once on a special
+        // structure, say) must not be integrated with its iteration counts
+        std::vector<double> sums((size_t)2 * n);
+        NK2D_CHECK(c, hipMemcpyAsync(sums.data(), c->STEP_NORM, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        const double slack = 30.0;
+        // a sharded module (norm hook) checks its own tracers against their own count: nothing is exchanged, and if
+        // every shard passes so does the module
+        const bool hooked = c->norm_hook != nullptr;
+        const double n_unknowns = hooked ? (double)c->tc * c->nz * c->ny : s.n_total;
+        for (int64_t i = 0; i < n; ++i) {
+            if ((int)sched[i * NK2D_SCHED_WIDTH + 3] < 1) continue;
+            const double s_last = sums[2 * i], s_prev = sums[2 * i + 1];
+            const double n_last = rms_from_sum(s_last, 3.0 * n_unknowns);
+            bool ok = n_last == n_last;
+            if (ok && n_last != 0.0) {
+                if (s_prev >= 0.0) {
+                    const double n_prev = rms_from_sum(s_prev, 3.0 * n_unknowns);
+                    const double rate = (n_prev > 0.0) ? n_last / n_prev : 0.0;
+                    ok = rate < 1.0 && rate / (1.0 - rate) * n_last < slack * s.newton_tol;
+                } else {
+                    ok = n_last < slack * s.newton_tol;   // one iteration: the recorded year's first correction vanished
+                }
+            }
+            if (!ok) {
+                c->frozen_fallbacks++;
+                return nk2d_fail(c, "nk2d_comp_fcn_frozen: the recorded Newton iteration counts do not converge for this state "
+                                    "(step " + std::to_string(i) + " of " + std::to_string(n) + ")", -7);
+            }
+        }
     }
     return 0;
 }
@@ -686,9 +798,23 @@ int run_replay(Ctl& s, const double* sched, int64_t n) {
 }  // namespace
 
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay, int64_t replay_n,
-                    double* record, int64_t record_cap, int64_t* record_n) {
+                    double* record, int64_t record_cap, int64_t* record_n, bool replay_own) {
     const auto wall0 = std::chrono::steady_clock::now();
     c->st = nk2d_stats();
+    // every free-running year leaves its accepted steps behind (nk2d_last_schedule): recorded into the caller's
+    // buffer, or into the context's own
+    int64_t own_n = 0;
+    if (!replay) {
+        c->last_sched.clear();
+        if (!record) {
+            c->own_rec.resize((size_t)NK2D_OWN_REC_CAP * NK2D_SCHED_WIDTH);
+            record = c->own_rec.data();
+            record_cap = NK2D_OWN_REC_CAP;
+            record_n = &own_n;
+        } else if (!record_n) {
+            record_n = &own_n;
+        }
+    }
     Ctl s;
     s.c = c;
     s.t = c->d.t0;
@@ -732,7 +858,9 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         double saved;
         ~LinTolGuard() { c->d.lin_tol = saved; }
     } lin_tol_guard{c, c->d.lin_tol};
-    if (replay) c->d.lin_tol = std::min(c->d.lin_tol, 1.0e-3);
+    // (a schedule this library recorded itself under the same inner tolerance -- the frozen-controller year of a
+    // finite-difference product -- repeats the recorded year's own solves: replay_own)
+    if (replay && !replay_own) c->d.lin_tol = std::min(c->d.lin_tol, 1.0e-3);
     NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
     if (s.t1 > s.t) {
         // f = fun(t0, y0);  J = jac(t0, y0)
@@ -750,7 +878,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
             stepped = rc == 0;      // 1: the grid does not fit the chip at once -- host control below
         }
         if (stepped) {}
-        else if (replay) NK2D_TRY(run_replay(s, replay, replay_n));
+        else if (replay) NK2D_TRY(run_replay(s, replay, replay_n, replay_own));
         else NK2D_TRY(run_free(s, record, record_cap, record_n));
         NK2D_TRY(nk2d_r_final(c, (const double*)x, (double*)fx));
     } else {
@@ -758,6 +886,8 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     }
     NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     NK2D_TRY(nk2d_profile_collect(c));
+    if (!replay && record && record_n && *record_n <= record_cap)
+        c->last_sched.assign(record, record + (size_t)(*record_n) * NK2D_SCHED_WIDTH);
     c->st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = c->st;
     return 0;

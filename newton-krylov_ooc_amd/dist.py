@@ -157,11 +157,14 @@ class ShardedVectorSpace:
         return h_tot
 
 
-def sharded_gmres(eng, comm, x, fx, rel_tol, min_iter, max_iter):
+def sharded_gmres(eng, comm, x, fx, rel_tol, min_iter, max_iter, sched=None):
     """KrylovSolver.solve (nk_ooc/krylov_solver.py:85-165) for the local tracers of a sharded module:
     the same loop as nk2d_gmres_solve with every reduction all-reduced over the shards and CGS-2
     instead of sequential MGS.  The preconditioner of iage is block diagonal over its tracers
-    (iage.py:66-93): each shard applies its own block.  Returns (increment, info)."""
+    (iage.py:66-93): each shard applies its own block.  `sched`: the accepted steps of the (coupled) year that
+    produced fx, `eng.last_schedule()` -- identical on every shard, the controller saw module-wide norms; the
+    perturbed years then repeat those steps (internal numerical differentiation) and need NO exchange at all: the
+    only collectives left per Krylov iteration are its five reductions.  Returns (increment, info)."""
     from .krylov_solver import least_squares_coeffs
 
     vs = ShardedVectorSpace(eng, comm)
@@ -176,7 +179,21 @@ def sharded_gmres(eng, comm, x, fx, rel_tol, min_iter, max_iter):
         sigma = 1.0e-4 * vs.norm(x)
         sigma = np.where(sigma == 0.0, 1.0, sigma)
         perturbed = eng.axpby(1.0, x, sigma, basis[j])
-        fpert, _, _ = eng.comp_fcn(perturbed)
+        fpert = None
+        if sched is not None and len(sched) > 0:
+            from .engine import Nk2dFrozenMismatch
+
+            bad = 0.0
+            try:
+                fpert, _ = eng.comp_fcn_frozen(perturbed, sched)
+            except Nk2dFrozenMismatch:
+                bad = 1.0
+            # a shard whose frozen year was rejected (recorded Newton counts not enough for its perturbed state) needs
+            # a coupled free-running year -- which every shard must then run: one flag per product
+            if comm.allreduce_scalar(bad) > 0.0:
+                fpert = None
+        if fpert is None:
+            fpert, _, _ = eng.comp_fcn(perturbed)
         w = eng.precond_apply(eng.diff_scale(fpert, fx, 1.0 / sigma))
         prods.append(w.copy())
         grown = np.zeros((1, j + 2, j + 1, eng.nreg))

@@ -51,6 +51,10 @@ class Nk2dError(RuntimeError):
     pass
 
 
+class Nk2dFrozenMismatch(Nk2dError):
+    """a frozen year (comp_fcn_frozen) whose recorded Newton iteration counts do not converge for the state given"""
+
+
 def _dp(arr):
     return arr.ctypes.data_as(_lib.c_double_p)
 
@@ -175,6 +179,8 @@ class ModuleEngine:
             pass
 
     def _chk(self, rc):
+        if rc == -7:
+            raise Nk2dFrozenMismatch(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
         if rc != 0:
             raise Nk2dError(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
 
@@ -274,6 +280,40 @@ class ModuleEngine:
         sched = rec[: recn.value].copy() if record else None
         return out, stats.as_dict(), sched
 
+    def comp_fcn_frozen(self, x, sched, out=None):
+        """forward year on the accepted steps `sched` recorded by comp_fcn(..., record=True) on this engine under
+        the same options: no decisions, nothing read back, the recorded year's own inner tolerance.  Returns
+        (fx, stats dict)."""
+        out = self.new_vec() if out is None else out
+        stats = _lib.Stats()
+        sched = np.ascontiguousarray(sched, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+        self._chk(self._lib.nk2d_comp_fcn_frozen(self._ctx, x.ptr, out.ptr, ctypes.byref(stats), _dp(sched),
+                                                 sched.shape[0]))
+        return out, stats.as_dict()
+
+    def last_schedule(self):
+        """accepted steps of the most recent free-running year of this engine, [n, SCHED_WIDTH]"""
+        n = ctypes.c_int64(0)
+        self._chk(self._lib.nk2d_last_schedule(self._ctx, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, _lib.SCHED_WIDTH))
+        if n.value:
+            self._chk(self._lib.nk2d_last_schedule(self._ctx, _dp(out), n.value, ctypes.byref(n)))
+        return out
+
+    def frozen_fallbacks(self):
+        """how many frozen years of this engine were rejected by their Newton check so far"""
+        n = ctypes.c_int64(0)
+        self._chk(self._lib.nk2d_frozen_fallbacks(self._ctx, ctypes.byref(n)))
+        return n.value
+
+    def set_frozen_schedule(self, sched):
+        """the schedule the perturbed years of jvp / gmres_solve repeat from now on (None: free-running years)"""
+        if sched is None:
+            self._chk(self._lib.nk2d_set_frozen_schedule(self._ctx, None, 0))
+            return
+        sched = np.ascontiguousarray(sched, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+        self._chk(self._lib.nk2d_set_frozen_schedule(self._ctx, _dp(sched), sched.shape[0]))
+
     # ---- sampled timing of the dominant kernel ----------------------------------------
     def profile_reset(self, every_n):
         self._chk(self._lib.nk2d_profile_reset(self._ctx, int(every_n)))
@@ -322,18 +362,26 @@ class ModuleEngine:
         return ms.value
 
     # ---- the Krylov loop on the device (C entry points of SURVEY.md section 8(b)) -----------------
-    def jvp(self, x, fx, v, out=None, perturb_fcn=None):
+    def jvp(self, x, fx, v, out=None, perturb_fcn=None, sched=None):
         """finite-difference Jacobian-vector product in one call (model_state_base.py:492-527):
-        returns (w, sigma [nreg], stats of the perturbed year)"""
+        returns (w, sigma [nreg], stats of the perturbed year).  sched: the accepted steps of the year that
+        produced fx -- the perturbed year repeats them (otherwise whatever set_frozen_schedule installed, or a
+        free-running year)"""
         out = self.new_vec() if out is None else out
         sigma = np.empty(self.nreg)
         stats = _lib.Stats()
-        self._chk(self._lib.nk2d_jvp(self._ctx, x.ptr, fx.ptr, v.ptr, out.ptr,
-                                     perturb_fcn.ptr if perturb_fcn is not None else None,
-                                     _dp(sigma), ctypes.byref(stats)))
+        if sched is not None:
+            self.set_frozen_schedule(sched)
+        try:
+            self._chk(self._lib.nk2d_jvp(self._ctx, x.ptr, fx.ptr, v.ptr, out.ptr,
+                                         perturb_fcn.ptr if perturb_fcn is not None else None,
+                                         _dp(sigma), ctypes.byref(stats)))
+        finally:
+            if sched is not None:
+                self.set_frozen_schedule(None)
         return out, sigma, stats.as_dict()
 
-    def gmres_solve(self, x, fx, rel_tol, min_iter, max_iter, out=None):
+    def gmres_solve(self, x, fx, rel_tol, min_iter, max_iter, out=None, sched=None):
         """KrylovSolver.solve for this one module, all on the device (krylov_solver.py:85-165).  Returns
         (increment, dict(beta [nreg], h_mat [iters+1, iters, nreg], resid_norm [iters, nreg],
         coeff [iters, nreg], iters))"""
@@ -345,9 +393,15 @@ class ModuleEngine:
         iters = ctypes.c_int32()
         if not self._precond_ready and self.module_kind != 1:
             self.precond_setup()
-        self._chk(self._lib.nk2d_gmres_solve(self._ctx, x.ptr, fx.ptr, float(rel_tol), int(min_iter),
-                                             int(max_iter), out.ptr, _dp(beta), _dp(h_mat), _dp(resid),
-                                             _dp(coeff), ctypes.byref(iters)))
+        if sched is not None:
+            self.set_frozen_schedule(sched)
+        try:
+            self._chk(self._lib.nk2d_gmres_solve(self._ctx, x.ptr, fx.ptr, float(rel_tol), int(min_iter),
+                                                 int(max_iter), out.ptr, _dp(beta), _dp(h_mat), _dp(resid),
+                                                 _dp(coeff), ctypes.byref(iters)))
+        finally:
+            if sched is not None:
+                self.set_frozen_schedule(None)
         k = iters.value
         return out, {"beta": beta, "h_mat": h_mat[: k + 1, :k].copy(), "resid_norm": resid[:k].copy(),
                      "coeff": coeff[:k].copy(), "iters": k}

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import hist as hist_mod
 from . import ncio
-from .engine import PHOSPHORUS_PARAM_NAMES, forced_engine, iage_engine, phosphorus_engine
+from .engine import PHOSPHORUS_PARAM_NAMES, Nk2dFrozenMismatch, forced_engine, iage_engine, phosphorus_engine
 from .limiter import scalef_for_bound
 from .grid import Grid2d, SpatialAxis
 
@@ -42,6 +42,11 @@ def _strtobool(val):
 
 def _class_name(obj):
     return f"{obj.__module__}.{type(obj).__name__}"
+
+
+# side file of a comp_fcn result: the accepted Radau steps of the year that produced it, per tracer module (what the
+# perturbed years of the finite-difference products around that result repeat); not part of the reference's file set
+SCHED_SUFFIX = ".sched.npz"
 
 
 class TracerModuleState:
@@ -193,6 +198,7 @@ class ModelState:
     _engines = None
     _grid = None
     _resident = {}
+    _sched_by_name = {}     # fcn file -> {module name: accepted Radau steps of the year that produced it}
     RESIDENT_MAX = 256      # device snapshots kept by name; the oldest are dropped beyond this, with or
                             # without the files on disk (write_files=False: a dropped name cannot be re-opened)
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
@@ -208,6 +214,7 @@ class ModelState:
         cls._engines = None
         cls._grid = None
         cls._resident = {}
+        cls._sched_by_name = {}
         cls._hist_end = {}
         cls._precond_state = {}
         cls.model_config_obj = None
@@ -251,6 +258,13 @@ class ModelState:
                 self.tracer_modules[ind] = tms
             return
         cached = self._resident.get(os.path.abspath(fname)) if isinstance(fname, str) else None
+        # the accepted steps of the forward year that produced this file, if it is the result of one (comp_fcn):
+        # remembered by name in this process, and kept next to the file for a resumed run
+        if isinstance(fname, str):
+            self._sched = self._sched_by_name.get(os.path.abspath(fname))
+            if self._sched is None and os.path.exists(fname + SCHED_SUFFIX):
+                with np.load(fname + SCHED_SUFFIX) as data:
+                    self._sched = {key: data[key] for key in data.files}
         for ind, name in enumerate(names):
             module_def = cfg.tracer_module_defs[name]
             eng = self._engines[name]
@@ -435,18 +449,28 @@ class ModelState:
         return self._inplace(other, lambda a, b: a.__itruediv__(b))
 
     # ---- the function whose root is sought ------------------------------------------------------------
-    def comp_fcn(self, res_fname, solver_state, hist_fname=None):
+    def comp_fcn(self, res_fname, solver_state, hist_fname=None, frozen=None):
         """one forward model year per tracer module on its GPU: F(x) = y(T) - x
-        (py_driver_2d/model_state.py:67-139)"""
+        (py_driver_2d/model_state.py:67-139).  The result carries the accepted Radau steps of every module's year
+        (`_sched`); `frozen`: such schedules of another year, {module name: schedule} -- this year then repeats
+        those steps instead of choosing its own (the perturbed year of a finite-difference product,
+        comp_jacobian_fcn_state_prod)."""
         logger = logging.getLogger(__name__)
         fcn_complete_step = f"comp_fcn complete for {res_fname}"
         if solver_state is not None and solver_state.step_logged(fcn_complete_step):
             logger.debug('"%s" logged, returning result', fcn_complete_step)
             return type(self)(res_fname)
-        mods, stats, hists = [], [], []
+        mods, stats, hists, scheds = [], [], [], {}
         t_eval = np.linspace(self.time_range[0], self.time_range[1], 61)
 
         def forward_year(tms):
+            if frozen is not None and hist_fname is None and len(frozen.get(tms.name, ())) > 0:
+                try:
+                    fx, st = tms.eng.comp_fcn_frozen(tms.vec, frozen[tms.name])
+                    return fx, st, None
+                except Nk2dFrozenMismatch as msg:
+                    # the recorded Newton iteration counts are not enough for this state: a free-running year
+                    logger.warning("%s: %s -- free-running year instead", tms.name, msg)
             if hist_fname is None:
                 return tms.eng.comp_fcn(tms.vec)
             return tms.eng.comp_fcn_hist(tms.vec, t_eval)
@@ -478,11 +502,22 @@ class ModelState:
                 hists.append((tracers, hist))
             mods.append(tms._like(fx))
             stats.append(st)
+            if frozen is None:
+                scheds[tms.name] = tms.eng.last_schedule()
         if hist_fname is not None and self.write_files:
             hist_mod.write_hist_file(hist_fname, self._grid, t_eval, hists,
                                      self.tracer_modules[0].eng.vmix_coeff)
         type(self).last_stats = stats
         res_ms = self._new(mods)
+        res_ms._sched = scheds if frozen is None else None
+        if res_fname is not None and res_ms._sched:
+            by_name = type(self)._sched_by_name
+            by_name.pop(os.path.abspath(res_fname), None)
+            by_name[os.path.abspath(res_fname)] = res_ms._sched
+            while len(by_name) > self.RESIDENT_MAX:
+                by_name.pop(next(iter(by_name)))
+            if self.write_files:
+                np.savez(res_fname + SCHED_SUFFIX[:-4], **res_ms._sched)
         # zero_extra_tracers: no shadow tracers in the py_driver_2d modules handled here;
         # apply_region_mask is fused into the kernel that forms y(T) - x
         caller = f"{_class_name(self)}.comp_fcn_postprocess called from {_class_name(self)}.comp_fcn"
@@ -636,7 +671,13 @@ class ModelState:
         perturb_ms = self + sigma * direction
         perturb_fcn_fname = os.path.join(
             solver_state.get_workdir(), f"perturb_fcn_{os.path.basename(res_fname)}")
-        perturb_fcn = perturb_ms.comp_fcn(perturb_fcn_fname, solver_state)
+        # Internal numerical differentiation: the perturbed year repeats the accepted steps of the year that produced
+        # `fcn` (carried by it when it was computed in this process), so that the quotient below differentiates ONE
+        # discrete map.  Two free-running years take different controller decisions here and there, and the
+        # difference of their discretisation errors over sigma is 5 ... 90 % of the product (DESIGN.md section 3c,
+        # tools/probe_jvp_noise.py).  NK2D_JVP_FROZEN=0, or an `fcn` read back from a file, gives free-running years.
+        frozen = getattr(fcn, "_sched", None) if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else None
+        perturb_fcn = perturb_ms.comp_fcn(perturb_fcn_fname, solver_state, frozen=frozen or None)
         caller = f"{_class_name(self)}.comp_jacobian_fcn_state_prod"
         res = ((perturb_fcn - fcn) / sigma).dump(res_fname, caller)
         solver_state.log_step(fcn_complete_step)

@@ -67,7 +67,11 @@ def test_gmres_entry_point_against_krylov_solver(tmp_path, nz, ny, vv, kh):
     state = solver._solver_state
     beta, h_mat = state.get_value_saved_state("beta"), state.get_value_saved_state("h_mat")
     eng = iterate.tracer_modules[0].eng
-    got, info = eng.gmres_solve(iterate.tracer_modules[0].vec, fcn.tracer_modules[0].vec, 1.0e-30, 0, iters)
+    # the perturbed years repeat the accepted steps of the year that produced fcn, there (ModelState carries them with
+    # fcn) and here (handed to the C entry point)
+    sched = fcn._sched["iage"]
+    assert len(sched) > 50
+    got, info = eng.gmres_solve(iterate.tracer_modules[0].vec, fcn.tracer_modules[0].vec, 1.0e-30, 0, iters, sched=sched)
     assert info["iters"] == iters == solver.get_iteration()
     # same kernels in the same order up to the least-squares solve: the Krylov space is identical
     assert np.array_equal(info["beta"], beta[0])
@@ -78,7 +82,7 @@ def test_gmres_entry_point_against_krylov_solver(tmp_path, nz, ny, vv, kh):
 
     assert np.allclose(info["coeff"], least_squares_coeffs(beta, h_mat)[0], rtol=1e-10, atol=1e-14)
     # stopping rule: with a loose tolerance and min_iter the loop stops where the reference's would
-    _, early = eng.gmres_solve(iterate.tracer_modules[0].vec, fcn.tracer_modules[0].vec, 0.9, 2, iters)
+    _, early = eng.gmres_solve(iterate.tracer_modules[0].vec, fcn.tracer_modules[0].vec, 0.9, 2, iters, sched=sched)
     want = next(k + 1 for k in range(iters)
                 if k + 1 >= 2 and (info["resid_norm"][k] < 0.9 * info["beta"]).all())
     assert early["iters"] == want
@@ -244,3 +248,61 @@ def test_plugin_backend_on_the_device():
     assert np.array_equal(backend.precond_apply(tm, v), eng.download(eng.precond_apply(eng.upload(v))))
     with pytest.raises(NotImplementedError):
         backend.engine(types.SimpleNamespace(name="phosphorus"))
+
+
+def test_frozen_year_reproduces_the_recorded_year_and_checks_newton():
+    """internal numerical differentiation (nk2d_comp_fcn_frozen / nk2d_set_frozen_schedule): on the recorded state a
+    frozen year IS the recorded year, bit for bit, in the engines' default mode and with SciPy's decisions; the product
+    (F(x + sigma v) - F(x)) / sigma through frozen years is far closer to the product of years integrated 10^4 times
+    tighter than through free-running ones; a state the recorded Newton counts do not converge for is refused (-7)
+    and nk2d_jvp falls back to a free-running year"""
+    from nk_ooc_amd.engine import Nk2dFrozenMismatch, iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    n = 26
+    grid = Grid2d.default(n, n)
+    eng = iage_engine(grid)
+    tight = iage_engine(grid, rtol=1.0e-10, atol=1.0e-10, lin_tol=1.0e-10)
+    tight.set_option("jac_fresh", 0)
+    rng = np.random.default_rng(3)
+    col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2) + 0.01 * rng.standard_normal((2, n, n)))
+    xh = eng.download(x)
+    v = np.cumsum(np.cumsum(rng.standard_normal(xh.shape), axis=1), axis=2)
+    v /= np.sqrt(np.sum(v * v))
+    xt = tight.upload(xh)
+    fxt, _, _ = tight.comp_fcn(xt)
+    w_ref = tight.download(tight.jvp(xt, fxt, tight.upload(v))[0])
+    for ctl, fresh in ((0, 1), (3, 1), (0, 0)):
+        eng.set_option("device_ctl", ctl)
+        eng.set_option("jac_fresh", fresh)
+        fx, st, sched = eng.comp_fcn(x, record=True)
+        assert np.array_equal(eng.last_schedule(), sched) and len(sched) == st["nsteps"]
+        fx2, st2 = eng.comp_fcn_frozen(x, sched)
+        assert np.array_equal(eng.download(fx2), eng.download(fx)), (ctl, fresh)
+        # (the free run also counts the iterations of its rejected and failed attempts)
+        assert st2["nsteps"] == st["nsteps"] and st2["nnewton"] == int(sched[:, 3].sum()) <= st["nnewton"]
+        assert st2["nrejected"] == 0
+        w_frozen = eng.download(eng.jvp(x, fx, eng.upload(v), sched=sched)[0])
+        err_frozen = rel_err(w_frozen, w_ref)
+        assert err_frozen < 2.0e-3, (ctl, fresh, err_frozen)
+    assert eng.frozen_fallbacks() == 0
+    # the recorded counts of a year that converged at once (a uniform state under pure decay: no transport at all)
+    # are not enough for a perturbed state with structure
+    eng.set_option("device_ctl", 0)
+    eng.set_option("jac_fresh", 1)
+    flat = eng.upload(np.zeros((2, n, n)))
+    f_flat, _, s_flat = eng.comp_fcn(flat, record=True)
+    bumpy = eng.upload(50.0 * rng.standard_normal((2, n, n)))
+    try:
+        eng.comp_fcn_frozen(bumpy, s_flat)
+        refused = False
+    except Nk2dFrozenMismatch:
+        refused = True
+    if refused:
+        assert eng.frozen_fallbacks() == 1
+        # nk2d_jvp: same situation, falls back to a free-running perturbed year and still returns a product
+        w, _, stp = eng.jvp(flat, f_flat, bumpy, sched=s_flat)
+        assert np.isfinite(eng.download(w)).all()
+    eng.close()
+    tight.close()

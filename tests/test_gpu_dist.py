@@ -52,7 +52,10 @@ def _check_two_rank_line(stdout, backend, check_shard=True):
         assert shard["backend"] == backend and shard["allreduce_latency_us"] > 0.0
         if "skipped" not in shard:
             assert shard["ms_per_jvp"] > 0.0
-            assert shard["allreduces_per_jvp"] > 100            # every Radau norm is a collective
+            # every Radau norm of the coupled year that gives F(x) is a collective; the perturbed year of the Krylov
+            # iteration repeats its steps and exchanges nothing -- what is left are the iteration's own reductions
+            assert shard["allreduces_of_the_coupled_year"] > 100
+            assert shard["allreduces_per_jvp"] < 20
     else:
         assert "shard_e2" not in out
     return out

@@ -99,9 +99,16 @@ def test_two_module_krylov(tmp_path, monkeypatch):
         assert np.allclose(fcn.tracer_modules[i].get_tracer_vals_all().reshape(-1), f[i], rtol=1e-3, atol=1e-6)
     _, trace = krylov.krylov_solve(mods, x, f, rel_tol=1e-9, max_iter=2)
     assert rel_err(beta, trace["beta"]) < 1e-4
-    # Hessenberg entries are finite differences of two free-running forward years (integrator
-    # tolerance 1e-6 over sigma = 1e-4 |x|): noise of a few per cent of the largest entry
-    assert rel_err(h_mat, trace["h_mat"][-1]) < 5e-2
+    # The oracle's Hessenberg entries are finite differences of two free-running forward years (integrator
+    # tolerance 1e-6 over sigma = 1e-4 |x|): noise of a few per cent of the largest entry.  Here the perturbed years
+    # repeat the steps of the base year (no such noise).  For the forced module -- one decaying tracer, exact
+    # preconditioner -- the first Krylov vector then already solves the system: h[1, 0] is a breakdown (~1e-9 of
+    # h[0, 0]) and the second column, divided by it, means nothing on either side.
+    want = trace["h_mat"][-1]
+    assert rel_err(h_mat[0], want[0]) < 5e-2
+    assert abs(h_mat[1, 0, 0, 0] - want[1, 0, 0, 0]) < 5e-2 * abs(want[1, 0, 0, 0])
+    if abs(h_mat[1, 1, 0, 0]) > 1.0e-4 * abs(h_mat[1, 0, 0, 0]):
+        assert rel_err(h_mat[1], want[1]) < 5e-2
     # the saved-state file holds both modules' tracers
     from nk_ooc_amd import ncio
 

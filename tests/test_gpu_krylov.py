@@ -105,7 +105,6 @@ def _setup_run(tmp_path, nz, ny, extra_modelinfo=None, extra_solverinfo=None):
 
 
 def test_krylov_column_regions_vs_reference_baselines(tmp_path, monkeypatch):
-    monkeypatch.setenv("NK2D_JAC_STAGE", "-1")   # TEMP: revisited with the frozen-schedule products
     """the ci_py_driver_2d_iage_column_regions case end to end on the GPU, compared with the
     reference's committed files at the tolerances of its CI script"""
     import json

@@ -23,7 +23,6 @@ def _read_state(fname):
 
 
 def test_newton_column_regions(tmp_path, monkeypatch):
-    monkeypatch.setenv("NK2D_JAC_STAGE", "-1")   # TEMP: revisited with the frozen-schedule products
     from nk_ooc_amd import ncio, nk_driver
     from nk_ooc_amd.model_state import ModelState
     from nk_ooc_amd.setup_solver import make_config, setup
@@ -136,10 +135,10 @@ def test_newton_resume_after_interruption(tmp_path, stop_at):
             return nk_driver.run(cfg), cfg
         original = ModelState.comp_fcn
 
-        def guarded(self, res_fname, solver_state, hist_fname=None):
+        def guarded(self, res_fname, solver_state, hist_fname=None, **kw):
             if stop_at in os.path.basename(res_fname):
                 raise Interrupt(res_fname)
-            return original(self, res_fname, solver_state, hist_fname)
+            return original(self, res_fname, solver_state, hist_fname, **kw)
 
         ModelState.comp_fcn = guarded
         try:

@@ -242,10 +242,10 @@ def test_phosphorus_newton_resume(tmp_path):
             return nk_driver.run(cfg)
         original = ModelState.comp_fcn
 
-        def guarded(self, res_fname, solver_state, hist_fname=None):
+        def guarded(self, res_fname, solver_state, hist_fname=None, **kw):
             if "perturb_fcn_w_raw_01" in os.path.basename(res_fname):
                 raise Interrupt(res_fname)
-            return original(self, res_fname, solver_state, hist_fname)
+            return original(self, res_fname, solver_state, hist_fname, **kw)
 
         ModelState.comp_fcn = guarded
         try:

@@ -53,5 +53,20 @@ for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104"])]:
             same = st["nsteps"] == stp["nsteps"] and st["nrejected"] == stp["nrejected"]
             print(f"    {name:32s}: |w - w_ref| / |w_ref| = {err:.3e}, d<v,w>/<v,w> = {dq:+.3e}; steps {st['nsteps']} / {stp['nsteps']}, "
                   f"rejected {st['nrejected']} / {stp['nrejected']}{'' if same else '  (sequences differ in length)'}", flush=True)
+        # frozen controller: the perturbed year repeats the accepted steps of the year that produced F(x)
+        for name, fresh, stage in MODES[:1] + MODES[3:4]:
+            eng.set_option("jac_fresh", fresh)
+            eng.set_option("jac_stage", stage)
+            fx, st, sched = eng.comp_fcn(x, record=True)
+            fx2, st2 = eng.comp_fcn_frozen(x, sched)
+            same = np.array_equal(eng.download(fx2), eng.download(fx))
+            eng.set_frozen_schedule(sched)
+            w, _, stp = eng.jvp(x, fx, eng.upload(v))
+            eng.set_frozen_schedule(None)
+            w = eng.download(w)
+            err = np.sqrt(np.sum((w - w_ref) ** 2) / np.sum(w_ref ** 2))
+            dq = (np.sum(v * w) - q_ref) / abs(q_ref)
+            print(f"    FROZEN, {name:24s}: |w - w_ref| / |w_ref| = {err:.3e}, d<v,w>/<v,w> = {dq:+.3e}; free year {st['seconds']:.4f} s, "
+                  f"frozen year {stp['seconds']:.4f} s ({stp['nlaunch']} launches); frozen year of x itself bit-identical: {same}", flush=True)
     eng.close()
     tight.close()
