@@ -58,12 +58,29 @@ class HipBackend:
             self.engines[name] = eng
         return self.engines[name]
 
-    def forward_year(self, tracer_module, y0, t_eval):
-        """what solve_ivp returned to the reference: times and the solution at them, shape (N, len(t_eval))"""
+    def last_schedules(self):
+        """accepted Radau steps of the most recent free-running year of every module: what the plugin's ModelState
+        attaches to a comp_fcn result, for the products around it"""
+        return {name: eng.last_schedule() for name, eng in self.engines.items()}
+
+    def forward_year(self, tracer_module, y0, t_eval, frozen=None):
+        """what solve_ivp returned to the reference: times and the solution at them, shape (N, len(t_eval)).
+        frozen: {module name: schedule} of the year whose steps this one repeats (the perturbed year of a
+        finite-difference product); a state the recorded Newton counts do not converge for gets a free-running year"""
+        from nk_ooc_amd.engine import Nk2dFrozenMismatch
+
         eng = self.engine(tracer_module)
         x = eng.upload(np.asarray(y0).reshape(eng.shape))
         if len(t_eval) == 2:
-            fx, _, _ = eng.comp_fcn(x)
+            fx = None
+            sched = (frozen or {}).get(tracer_module.name)
+            if sched is not None and len(sched) > 0:
+                try:
+                    fx, _ = eng.comp_fcn_frozen(x, sched)
+                except Nk2dFrozenMismatch:
+                    fx = None
+            if fx is None:
+                fx, _, _ = eng.comp_fcn(x)
             y_end = np.asarray(y0).reshape(-1) + eng.download(fx).reshape(-1)
             return np.asarray(t_eval), np.stack([np.asarray(y0).reshape(-1), y_end], axis=1)
         _, _, hist = eng.comp_fcn_hist(x, np.asarray(t_eval))

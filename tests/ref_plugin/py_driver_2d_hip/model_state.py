@@ -9,6 +9,9 @@ from nk_ooc.py_driver_2d import model_state as ref_model_state
 from . import _backend
 
 
+_FROZEN = None     # {module name: schedule} while a finite-difference product computes its perturbed year
+
+
 @contextlib.contextmanager
 def _forward_year_from(backend):
     """while active, `integrate.solve_ivp(...)` inside nk_ooc/py_driver_2d/model_state.py:102-114 returns the
@@ -18,7 +21,10 @@ def _forward_year_from(backend):
     def solve_ivp(fun, t_span, y0, method, t_eval, **kwargs):
         if method != "Radau":
             raise NotImplementedError(f"py_driver_2d_hip: integrator {method}")
-        times, vals = backend.forward_year(fun.__self__, y0, t_eval)
+        if _FROZEN and len(t_eval) == 2:
+            times, vals = backend.forward_year(fun.__self__, y0, t_eval, frozen=_FROZEN)
+        else:
+            times, vals = backend.forward_year(fun.__self__, y0, t_eval)
         return types.SimpleNamespace(t=times, y=vals, success=True)
 
     saved = ref_model_state.integrate
@@ -40,5 +46,21 @@ class ModelState(ref_model_state.ModelState):
         _backend.bind(type(self))
 
     def comp_fcn(self, res_fname, solver_state, hist_fname=None):
-        with _forward_year_from(_backend.backend()):
-            return super().comp_fcn(res_fname, solver_state, hist_fname)
+        backend = _backend.backend()
+        with _forward_year_from(backend):
+            res = super().comp_fcn(res_fname, solver_state, hist_fname)
+        # the accepted Radau steps of the years just run travel with the result (in this process): the products around
+        # it repeat them.  A backend without recorded steps (the CPU stand-in of the test harness) has none.
+        if not _FROZEN and hasattr(backend, "last_schedules"):
+            res._nk2d_sched = backend.last_schedules()
+        return res
+
+    def comp_jacobian_fcn_state_prod(self, fcn, direction, res_fname, solver_state):
+        """the reference's finite-difference product (model_state_base.py:492-527), its perturbed year on the steps of
+        the year that produced `fcn` (internal numerical differentiation; this repository's DESIGN.md section 3c)"""
+        global _FROZEN
+        _FROZEN = getattr(fcn, "_nk2d_sched", None)
+        try:
+            return super().comp_jacobian_fcn_state_prod(fcn, direction, res_fname, solver_state)
+        finally:
+            _FROZEN = None

@@ -238,6 +238,12 @@ def test_plugin_backend_on_the_device():
     t, y = backend.forward_year(tm, y0.reshape(-1), np.array([0.0, year]))
     assert y.shape == (y0.size, 2) and np.array_equal(y[:, 0], y0.reshape(-1))
     assert np.array_equal(y[:, 1], y0.reshape(-1) + want.reshape(-1))         # what `sol.y[:, -1]` is read from
+    # the steps of that year, as the plugin's ModelState attaches them to the result; a year frozen on them is the
+    # year again, and the perturbed year of a product around it takes no decisions of its own
+    scheds = backend.last_schedules()
+    assert set(scheds) == {"iage"} and len(scheds["iage"]) > 100
+    _, y_frozen = backend.forward_year(tm, y0.reshape(-1), np.array([0.0, year]), frozen=scheds)
+    assert np.array_equal(y_frozen, y)
     t_eval = np.linspace(0.0, year, 61)
     t, y = backend.forward_year(tm, y0.reshape(-1), t_eval)
     assert y.shape == (y0.size, 61) and np.array_equal(t, t_eval)
