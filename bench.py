@@ -227,8 +227,9 @@ def roofline_of(eng, n):
         "timing": timing,
         "launches": prof["launches"],
         "algorithmic_bytes_per_launch": bytes_per_launch,
-        "event_windows_over_timed_region": windows,
     }
+    if prof["windows"] > 0:     # none in a region of frozen years: nothing there waits for a norm
+        out["event_windows_over_timed_region"] = windows
     if shapes_out:
         out["launch_shapes"] = shapes_out
     pmc_fname = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{n}.json")

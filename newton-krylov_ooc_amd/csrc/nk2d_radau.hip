@@ -757,6 +757,11 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             if (norm_out) NK2D_TRY(nk2d_r_step_norms(c, part_last, part_prev, norm_out));
             NK2D_TRY(commit_step(s, t, t_new));
         }
+        // nothing is read back during a replay: bound the depth of the launch queue (a year is 10^4 launches; the
+        // counter-collecting profiler of this ROCm falls over behind a few thousand unsynchronised dispatches, as it
+        // did behind the preconditioner's elimination) -- the host is far ahead at that point
+        // and a drain every 64 steps costs forty hand-overs a year
+        if ((i & 63) == 63) NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     }
     if (check_newton && n > 0) {
         // SciPy's convergence test (radau.py:120-129) on what the LAST recorded iteration of every step left, with

@@ -13,4 +13,5 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python tools/probe_persistent_sizes.py > $R/persistent_sizes.log 2>&1; echo "sizes rc=$?" >> $R/persistent_sizes.log
 timeout -k 10 200 python tools/probe_team.py 416 --tc1 > $R/team_tc1.log 2>&1
 timeout -k 10 200 python tools/probe_team.py 416 > $R/team_tc2.log 2>&1
+timeout -k 10 300 python tools/probe_jvp_noise.py 52 > $R/jvp_noise_52.log 2>&1
 ls -la $R; du -sh $GRAFT_REPO_ROOT/gpurun_out
