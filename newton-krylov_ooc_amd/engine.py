@@ -40,9 +40,10 @@ DEFAULT_JAC_STAGE = 1
 DEFAULT_GROWTH_CAP = 0.0
 # Whole forward year in ONE persistent kernel (nk2d_set_option "device_ctl" 3: grid barriers between the phases,
 # SciPy's controller on the device) for grids of at most this many depth levels.  Measured against the host-controlled
-# loop of the same build (tools/probe_persistent_sizes.py, profiles/r02_persistent_sizes.log): 1.25x at 26^2, 1.21x at
-# 52^2, 1.08x at 104^2, 0.98x at 208^2, 0.92x at 416^2.  Same phase functions, same decisions;
-# history sampling, sharded modules and the state dependent modules keep the host-controlled loop.
+# loop of the same build (tools/probe_persistent_sizes.py, profiles/r02_persistent_sizes.log): 1.41x at 26^2, 1.26x at
+# 52^2, 1.13x at 104^2, 1.08x at 208^2, 0.97x at 416^2.  Same phase functions, same algorithm;
+# history sampling, sharded modules and the state dependent modules keep the host-controlled loop.  This concerns the
+# free-running years (F(x) itself); the perturbed years of the products are frozen years under host launches (section 3c).
 # NK2D_DEVICE_CTL in the environment overrides (0 = host control everywhere).
 PERSISTENT_MAX_NZ = 128
 
