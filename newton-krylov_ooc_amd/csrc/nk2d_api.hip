@@ -131,6 +131,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
     if (key == "jac_stage") {
         if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: jac_stage must be -1, 0, 1 or 2");
         c->jac_stage = (int)value;
@@ -343,6 +344,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->YLIN = nullptr;
     c->ylin_set = 0;
     for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->KV[i], c->kv_len));
+    for (int i = 0; i < 3; ++i) NK2D_TRY(dev_alloc(c, &c->KVN[i], c->kv_len));
+    for (int i = 0; i < 5; ++i) NK2D_TRY(dev_alloc(c, &c->JB[i], c->np));
     NK2D_TRY(dev_alloc(c, &c->Y, c->nv));
     NK2D_TRY(dev_alloc(c, &c->YOLD, c->nv));
     NK2D_TRY(dev_alloc(c, &c->F, c->nv));
@@ -354,6 +357,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->team = nk2d_team_auto(c);
     c->xcd_map = 0;
     c->jac_stage = -1;
+    c->final_fuse = 1;
     c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));
@@ -383,6 +387,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->PART2, (size_t)c->ncol));
     NK2D_TRY(dev_alloc(c, &c->STEP_NORM, (size_t)2 * NK2D_OWN_REC_CAP));
     c->frozen_fallbacks = 0;
+    c->STEP_PART = nullptr;
+    c->step_part_rows = 0;
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
     NK2D_TRY(dev_alloc(c, &c->DCTL, (size_t)8));
     NK2D_TRY(dev_alloc(c, &c->ICTL, (size_t)8));
@@ -513,9 +519,10 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     nk2d_precond_free(c);
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
-                      c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->Y,
+                      c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->KVN[0], c->KVN[1], c->KVN[2], c->JB[0], c->JB[1],
+                      c->JB[2], c->JB[3], c->JB[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
-                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->RED, c->STAGE, c->RCOEF,
+                      c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->STEP_PART, c->RED, c->STAGE, c->RCOEF,
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN,
                       c->SMSREC, c->RESTREC};
     for (double* b : bufs)

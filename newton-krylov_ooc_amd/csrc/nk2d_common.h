@@ -69,6 +69,10 @@ struct nk2d_ctx {
     int ylin_set;
     // vertical mixing planes: 3 stage times, current t, scratch
     double* KV[5];
+    // second sets: the launch that ends a frozen step writes the next attempt's stage planes and Jacobian planes while
+    // its own stage and sweep parts still read the current ones (nk2d_r_newton_final)
+    double* KVN[3];
+    double* JB[5];
     // Radau work vectors (nv each unless noted)
     double *Y, *YOLD, *F, *Z /*3nv*/, *ZP /*3nv*/, *W /*3nv*/;
     // third stage buffer: a simplified-Newton iteration whose solve needs ONE sweep runs as a single launch
@@ -79,6 +83,7 @@ struct nk2d_ctx {
     std::vector<double> last_sched;     // accepted steps of the most recent free-running year (nk2d_last_schedule)
     std::vector<double> own_rec;        // its record buffer when the caller gave none
     std::vector<double> frozen_sched;   // accepted steps the perturbed years of nk2d_jvp repeat (nk2d_set_frozen_schedule)
+    int final_fuse;    // 1: a frozen step ends in the launch of its last Newton iteration (option "final_fuse", for A/B runs)
     int jac_stage;     // >= 0: Jacobian of a step attempt from the vertical mixing plane of this stage time (option "jac_stage"); -1: step start
     int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
     int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
@@ -108,7 +113,9 @@ struct nk2d_ctx {
     int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
-    double* PART2;   // second buffer [ncol]: a replayed year keeps the partials of the last two Newton iterations of a step
+    double* PART2;   // second buffer [ncol]
+    double* STEP_PART;      // frozen year: norm partials of the last two Newton iterations of every step, rows of ncol
+    size_t step_part_rows;  // rows allocated
     double* STEP_NORM;  // [2 * NK2D_OWN_REC_CAP] per step of a frozen year: sum((dW/scale)^2) of its last and last-but-one iteration
     int64_t frozen_fallbacks;   // frozen years rejected by the a-posteriori Newton check (nk2d_frozen_fallbacks)
     double* RED;     // reduced scalars (device)
@@ -519,9 +526,10 @@ int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part);
 int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part);
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv);
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2, int jac_stage = -1, bool with_tend = true,
-                         const double* part_last = nullptr, const double* part_prev = nullptr, double* norm_out = nullptr);
-int nk2d_r_step_norms(nk2d_ctx* c, const double* part_last, const double* part_prev, double* out);
+                         double x0, double x1, double x2, int jac_stage = -1, bool with_tend = true);
+int nk2d_r_rows_sum(nk2d_ctx* c, const double* rows, int64_t nrows, double* out);
+int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
+                        const double* times, double x0, double x1, double x2, int jac_stage);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 int nk2d_prof_window_begin(nk2d_ctx* c);

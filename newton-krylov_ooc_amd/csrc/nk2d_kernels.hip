@@ -1259,6 +1259,19 @@ struct StageArgs {
 // With m sweeps per solve a Newton iteration is m launches (stage fused into the first,
 // update into the last) instead of m + 2.
 // ---------------------------------------------------------------------------------
+// The launch that ends the last Newton iteration of a FROZEN step (a replayed year knows it is the last) also ends the
+// step: y_new = y + Z_2, the predicted stage values of the next attempt and W = TI Z_0 from the collocation polynomial of
+// this step -- all of it the column's own data, already in the registers of the update -- and, in workgroups behind
+// the column workgroups, the next attempt's mixing planes with the Jacobian planes derived from one of them.  A
+// step boundary launch of its own disappears (2 600 of 12 000 launches of a 416^2 year).  The planes go to a second set
+// of buffers: this launch's own stage and sweep parts still read the current ones.
+struct FinalArgs {
+    double* ynew;           // y + Z_2 (the buffer that becomes Y)
+    double* znext;          // predicted stage values of the next attempt, 3 nv (never the Z the stage part reads)
+    double x0, x1, x2;      // dense-output abscissae of the next attempt's stage times
+    int nblk_cols;          // workgroups of the columns; the plane workgroups follow
+};
+
 struct FusedArgs {
     StageArgs st;
     SweepArgs sw;
@@ -1272,8 +1285,9 @@ struct FusedArgs {
 // STAGE = 0: instantiation for launches without the stage part.  For the phosphorus module the
 // full kernel needs more registers than two waves per SIMD leave while its 3 ny columns are more
 // waves than the chip has SIMDs; the stage-less instantiation fits and runs in one round.
-template <int E, int KIND, int FACTOR, int STAGE, int MP = 0>
-__device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane) {
+template <int E, int KIND, int FACTOR, int STAGE, int MP = 0, int FINAL = 0>
+__device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane,
+                                                  const FinalArgs* fin = nullptr) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
@@ -1482,6 +1496,43 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
     acc = wave_sum(acc);
     if (lane == 0) st_mp<MP>(A.part + task, acc);
     double* wout = const_cast<double*>(A.st.w);
+    if constexpr (FINAL) {
+        // end of a frozen step (FinalArgs): the operations of commit_tend_body (y_new) and predict_body, on registers
+        double z0[E], z1[E], z2[E], yn[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            z0[e] = (cT[0][0] * w0[e] + cT[0][1] * w1[e]) + cT[0][2] * w2[e];
+            z1[e] = (cT[1][0] * w0[e] + cT[1][1] * w1[e]) + cT[1][2] * w2[e];
+            z2[e] = (cT[2][0] * w0[e] + cT[2][1] * w1[e]) + cT[2][2] * w2[e];
+            yn[e] = yy[e] + z2[e];
+        }
+        store_col<E>(fin->ynew, task, lane, yn);
+        const double xs[3] = {fin->x0, fin->x1, fin->x2};
+        double o[3][E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            double q[3];
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double p1 = xs[i], p2 = p1 * xs[i], p3 = p2 * xs[i];
+                double v = (q[0] * p1 + q[1] * p2) + q[2] * p3;
+                v = v + yy[e];
+                o[i][e] = v - yn[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store_col<E>(fin->znext + i * A.st.nv, task, lane, o[i]);
+        double wv[E];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
+            store_col<E>(wout + r * A.st.nv, task, lane, wv);
+        }
+        return;
+    }
     double* zout = A.st.zout;
     store_col<E>(wout, task, lane, w0);
     store_col<E>(wout + A.st.nv, task, lane, w1);
@@ -1500,6 +1551,26 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     GUARD_RETURN(P.guard)
     TASK_PROLOGUE_XCD(P.ncol)
     newton_fused_body<E, KIND, FACTOR, STAGE, 0>(P, A, task, lane);
+}
+
+// the launch that ends a frozen step (FinalArgs): column workgroups first, then the workgroups of the next attempt's planes
+template <int E, int KIND, int FACTOR, int STAGE>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if ((int)blockIdx.x < Fin.nblk_cols) {
+        const int task = blockIdx.x * wpb + wave;
+        if (task < P.ncol) newton_fused_body<E, KIND, FACTOR, STAGE, 0, 1>(P, A, task, lane, &Fin);
+        return;
+    }
+    const int task = (blockIdx.x - Fin.nblk_cols) * wpb + wave;
+    if (task < P.ny * 3) {
+        double kv[E];
+        vmix_body_kv<E>(P, V, task, lane, kv);
+        const int ti = task / P.ny;
+        if (ti == J.stage)
+            jac_core<E, 0>(P, kv, V.out[ti], J.JL, J.JU, J.JS, J.JN, J.JC, nullptr, nullptr, task - ti * P.ny, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2089,11 +2160,6 @@ struct BoundaryArgs {
     int do_jac, nblk_vmix, nblk_jac;
     int jac_stage;                     // >= 0: Jacobian from the new plane of this stage (by the wave that computes it); then do_jac = 0
     int with_tend;                     // 0: y_new only (step replay: no error estimate will ask for f(t_new, y_new))
-    // frozen year: one more workgroup adds up the norm partials the last two Newton iterations of the step left behind
-    // (part_prev null: the step had one iteration) into norm_out[0], norm_out[1]
-    const double *part_last, *part_prev;
-    double* norm_out;
-    int npart;
 };
 
 template <int E, int KIND>
@@ -2121,14 +2187,6 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V
         return;
     }
     blk -= B.nblk_jac;
-    if (B.norm_out != nullptr && blk == (P.ncol + wpb - 1) / wpb) {
-        __shared__ double sh[NK2D_BLOCK];
-        const double s_last = block_sum(B.part_last, B.npart, sh);
-        __syncthreads();
-        const double s_prev = (B.part_prev != nullptr) ? block_sum(B.part_prev, B.npart, sh) : -1.0;
-        if (threadIdx.x == 0) { B.norm_out[0] = s_last; B.norm_out[1] = s_prev; }
-        return;
-    }
     const int task = blk * wpb + wave;
     if (task >= P.ncol) return;
     if (B.with_tend) {
@@ -2144,16 +2202,15 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_step_boundary(DevP P, VmixArgs V
     predict_body<E>(A, task, lane);
 }
 
-__global__ void k_step_norms(const double* __restrict__ part_last, const double* __restrict__ part_prev, int n,
-                             double* __restrict__ out) {
+// sums of rows of per-column partials: out[r] = sum_i rows[r * n + i] in the association of k_reduce (a frozen year keeps
+// the norm partials of the last two Newton iterations of every step and checks them after the year, nk2d_radau.hip)
+__global__ void k_rows_sum(const double* __restrict__ rows, int n, double* __restrict__ out) {
     __shared__ double sh[NK2D_BLOCK];
-    const double s_last = block_sum(part_last, n, sh);
-    __syncthreads();
-    const double s_prev = (part_prev != nullptr) ? block_sum(part_prev, n, sh) : -1.0;
-    if (threadIdx.x == 0) { out[0] = s_last; out[1] = s_prev; }
+    const double v = block_sum(rows + (size_t)blockIdx.x * n, n, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
-int nk2d_r_step_norms(nk2d_ctx* c, const double* part_last, const double* part_prev, double* out) {
-    hipLaunchKernelGGL(k_step_norms, dim3(1), dim3(NK2D_BLOCK), 0, c->stream, part_last, part_prev, c->ncol, out);
+int nk2d_r_rows_sum(nk2d_ctx* c, const double* rows, int64_t nrows, double* out) {
+    hipLaunchKernelGGL(k_rows_sum, dim3((unsigned)nrows), dim3(NK2D_BLOCK), 0, c->stream, rows, c->ncol, out);
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
@@ -2163,8 +2220,7 @@ int nk2d_r_step_norms(nk2d_ctx* c, const double* part_last, const double* part_p
 // with stage times `times` (planes into out[0..2]) and dense-output abscissae x0..x2.  Buffers are taken in their
 // roles BEFORE the caller swaps them: y_new goes to YOLD, the predicted stage values to ZP.
 int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const double* times, double* const* out,
-                         double x0, double x1, double x2, int jac_stage, bool with_tend, const double* part_last,
-                         const double* part_prev, double* norm_out) {
+                         double x0, double x1, double x2, int jac_stage, bool with_tend) {
     VmixArgs V;
     for (int i = 0; i < 3; ++i) {
         nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
@@ -2179,7 +2235,6 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
     B.do_jac = do_jac ? 1 : 0;
     B.jac_stage = jac_stage;
     B.with_tend = with_tend ? 1 : 0;
-    B.part_last = part_last; B.part_prev = part_prev; B.norm_out = norm_out; B.npart = c->ncol;
     if (jac_stage >= 0 && do_jac) return nk2d_fail(c, "nk2d_r_step_boundary: Jacobian at t_new and at a stage time requested together");
     B.nblk_vmix = nk2d_grid(c->ny * 3);
     B.nblk_jac = do_jac ? nk2d_grid(c->ny) : 0;
@@ -2189,7 +2244,7 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
     A.x0 = x0; A.x1 = x1; A.x2 = x2;
     DevP P = make_devp(c);
     P.guard = nullptr;
-    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol) + (norm_out ? 1 : 0)),
+    NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol)),
                                                          dim3(NK2D_BLOCK), 0, c->stream, P, V, B, A));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
@@ -2448,6 +2503,73 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     }
     NK2D_TRY(launch_fused(c, P, A, do_factor, do_stage));
     if (swap_z) std::swap(c->Z, c->ZN);
+    c->st.nlaunch++;
+    c->st.nsweeps++;
+    return 0;
+}
+
+// the launch that ends the last Newton iteration of a frozen step AND the step (k_newton_final): next attempt with stage
+// times `times`, dense-output abscissae x0..x2, Jacobian from the plane of stage jac_stage (-1: none due).  Buffers
+// are swapped into their new roles here: Y <-> YOLD, Z <-> ZN (when this launch also evaluated the stages), the stage
+// planes and -- when derived -- the Jacobian planes with their second sets.
+int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
+                        const double* times, double x0, double x1, double x2, int jac_stage) {
+    if (c->kind == 1) return nk2d_fail(c, "nk2d_r_newton_final: not for modules whose Jacobian reads the state");
+    FusedArgs A;
+    fill_fused_args(c, A, do_stage, first, true, mreal, mcr, mci, src, delta);
+    A.part = c->part_cur ? c->part_cur : c->PART;
+    bool do_factor = c->factor_pending != 0;
+    if (do_factor && !do_stage) {
+        NK2D_TRY(nk2d_k_factor(c, true, true, c->lu_cre, c->lu_ccr, c->lu_cci));
+        do_factor = false;
+    }
+    c->factor_pending = 0;
+    FinalArgs Fin;
+    Fin.ynew = c->YOLD;
+    Fin.znext = do_stage ? c->ZN : c->Z;
+    Fin.x0 = x0; Fin.x1 = x1; Fin.x2 = x2;
+    Fin.nblk_cols = nk2d_grid(c->ncol);
+    VmixArgs V;
+    for (int i = 0; i < 3; ++i) {
+        nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[i], &V.frac[i]);
+        V.out[i] = c->KVN[i];
+    }
+    V.frac[3] = 0.0; V.out[3] = nullptr;
+    vmix_forcing_args(c, 3, times, V);
+    V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
+    V.hw = c->d.vmix_half_width;
+    JacOut J = {c->JB[0], c->JB[1], c->JB[2], c->JB[3], c->JB[4], jac_stage};
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    {
+        const double words = fused_words(c, do_stage, first, true, delta, do_factor);
+        c->sweep_launches++;
+        c->fused_bytes_all += 8.0 * words;
+        if (!do_factor) {
+            const int shape = do_stage ? 0 : 2;
+            c->shape_cnt[shape]++;
+            c->shape_bytes[shape] += 8.0 * words;
+        }
+    }
+    const dim3 grid(Fin.nblk_cols + nk2d_grid(c->ny * 3));
+#define NK2D_FINAL_LAUNCH(KK)                                                                                              \
+    if (do_factor) {                                                                                                       \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 1, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+    } else if (do_stage) {                                                                                                 \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+    } else {                                                                                                               \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+    }
+    if (c->kind == 2) { NK2D_FINAL_LAUNCH(2) } else { NK2D_FINAL_LAUNCH(0) }
+#undef NK2D_FINAL_LAUNCH
+    NK2D_CHECK(c, hipGetLastError());
+    std::swap(c->Y, c->YOLD);
+    if (do_stage) std::swap(c->Z, c->ZN);
+    for (int i = 0; i < 3; ++i) std::swap(c->KV[i], c->KVN[i]);
+    if (jac_stage >= 0) {
+        std::swap(c->JL, c->JB[0]); std::swap(c->JU, c->JB[1]); std::swap(c->JS, c->JB[2]);
+        std::swap(c->JN, c->JB[3]); std::swap(c->JC, c->JB[4]);
+    }
     c->st.nlaunch++;
     c->st.nsweeps++;
     return 0;
@@ -3267,6 +3389,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         NK2D_CHECK(c, hipMemcpy(record, c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * ncopy, hipMemcpyDeviceToHost));
     }
     if (record_n) *record_n = nrec;
-    if (record && nrec > record_cap) return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
+    if (record && nrec > record_cap && record != c->own_rec.data())
+        return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
     return 0;
 }

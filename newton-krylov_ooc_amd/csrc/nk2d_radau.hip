@@ -164,13 +164,13 @@ int newton_iteration(Ctl& s, double mreal, double mcr, double mci) {
 }
 
 // Replay: exactly n_iters simplified-Newton iterations, no tests, nothing read back.
-// The norm partials of iteration k go to PART (k even) / PART2 (k odd): a frozen year checks afterwards that the
-// recorded iteration counts were enough for ITS state (run_replay).
-int newton_fixed(Ctl& s, double h, int n_iters) {
+// Iterations k0 .. k1-1 of the n_total a step has.  row_last / row_prev (a frozen year): where the norm partials of the
+// step's last and last-but-one iteration go, for the check after the year (run_replay); the others go to PART.
+int newton_fixed(Ctl& s, double h, int k0, int k1, int n_total, double* row_last = nullptr, double* row_prev = nullptr) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
-    for (int k = 0; k < n_iters; ++k) {
-        c->part_cur = (k & 1) ? c->PART2 : c->PART;
+    for (int k = k0; k < k1; ++k) {
+        c->part_cur = (row_last && k == n_total - 1) ? row_last : ((row_prev && k == n_total - 2) ? row_prev : nullptr);
         NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
         c->st.nfev += 3;
         c->st.nnewton++;
@@ -657,7 +657,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         s.h_abs = h_abs_next;
     }
     if (record_n) *record_n = nrec;
-    if (record && nrec > record_cap) return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
+    // (the context's own record buffer is a convenience: a year longer than it simply leaves no schedule behind)
+    if (record && nrec > record_cap && record != c->own_rec.data())
+        return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
     return 0;
 }
 
@@ -670,6 +672,15 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
 int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
     nk2d_ctx* c = s.c;
     if (check_newton && n > NK2D_OWN_REC_CAP) return nk2d_fail(c, "nk2d_comp_fcn_frozen: schedule too long", -4);
+    if (check_newton && c->step_part_rows < (size_t)(2 * n)) {
+        // norm partials of the last two Newton iterations of every step, one row of ncol each
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->STEP_PART) NK2D_CHECK(c, hipFree(c->STEP_PART));
+        c->STEP_PART = nullptr;
+        c->step_part_rows = 0;
+        NK2D_CHECK(c, hipMalloc((void**)&c->STEP_PART, sizeof(double) * (size_t)(2 * n) * c->ncol));
+        c->step_part_rows = (size_t)(2 * n);
+    }
     double h_lu_cur = 0.0;
     bool have = false;
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
@@ -717,30 +728,56 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         }
         if (!have || h_lu != h_lu_cur) { NK2D_TRY(set_lu(s, h_lu)); h_lu_cur = h_lu; have = true; }
         if (!predicted) NK2D_TRY(predict(s, t, h));
-        NK2D_TRY(newton_fixed(s, h, n_iter));
-        // where the partials of the last two iterations are, for the a-posteriori check of a frozen year
-        const double* part_last = (check_newton && n_iter >= 1) ? (((n_iter - 1) & 1) ? c->PART2 : c->PART) : nullptr;
-        const double* part_prev = (check_newton && n_iter >= 2) ? (((n_iter - 2) & 1) ? c->PART2 : c->PART) : nullptr;
-        double* norm_out = part_last ? c->STEP_NORM + 2 * i : nullptr;
-        // boundary: with a next row that starts where this one ends, its planes, predicted stage values and (where its
-        // Jacobian time is the step start or one of its stage times) its Jacobian come with the commit
+        double* row_last = check_newton ? c->STEP_PART + (size_t)(2 * i) * c->ncol : nullptr;
+        double* row_prev = check_newton ? c->STEP_PART + (size_t)(2 * i + 1) * c->ncol : nullptr;
+        // With a next row that starts where this one ends, its planes, predicted stage values and (where its Jacobian
+        // time is the step start or one of its stage times) its Jacobian are computed before this step is left:
         const double* r2 = (i + 1 < n) ? r + NK2D_SCHED_WIDTH : nullptr;
-        if (fast && r2 && t + h == t_new && r2[0] == t_new && r2[2] > 0.0 && std::isfinite(r2[2])) {
-            const double h2 = r2[2], t_jac2 = r2[4];
+        const bool chained = fast && r2 && t + h == t_new && r2[0] == t_new && r2[2] > 0.0 && std::isfinite(r2[2]);
+        double h2 = 0.0, times[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+        int jstage2 = -1;
+        bool jac_at_tnew = false;
+        if (chained) {
+            h2 = r2[2];
+            const double t_jac2 = r2[4];
             const bool jac_new = t_jac2 != s.t_jac;
-            const int jstage2 = jac_new ? stage_of(t_new, h2, t_jac2) : -1;
-            const bool jac_at_tnew = jac_new && jstage2 < 0 && t_jac2 == t_new && !needs_state;
-            double times[3], x[3];
+            jstage2 = jac_new ? stage_of(t_new, h2, t_jac2) : -1;
+            jac_at_tnew = jac_new && jstage2 < 0 && t_jac2 == t_new && !needs_state;
             for (int k = 0; k < 3; ++k) {
                 times[k] = t_new + (h2 * RC[k]);
                 x[k] = ((t_new + h2 * RC[k]) - t) / (t_new - t);
             }
-            double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
-            NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_at_tnew, times, out, x[0], x[1], x[2], jstage2, false,
-                                          part_last, part_prev, norm_out));
-            std::swap(c->KV[3], c->KV[2]);
-            std::swap(c->Y, c->YOLD);
-            std::swap(c->Z, c->ZP);
+        }
+        // ... in the launch that ends the last Newton iteration (nk2d_r_newton_final) where the Jacobian does not read
+        // the state and no Jacobian at t_new is due; otherwise in a step boundary launch of its own
+        const bool final_fused = chained && !needs_state && !jac_at_tnew && n_iter >= 1 && c->final_fuse;
+        if (final_fused) {
+            NK2D_TRY(newton_fixed(s, h, 0, n_iter - 1, n_iter, row_last, row_prev));
+            const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
+            const int m = std::max(s.m_real, s.m_cplx);
+            int src = 0;
+            c->part_cur = nullptr;
+            for (int it = 0; it + 1 < m; ++it) {
+                NK2D_TRY(nk2d_r_newton_fused(c, it == 0, it == 0, false, mreal, mcr, mci, src, m == 2));
+                src = 1 - src;
+            }
+            c->part_cur = row_last;
+            NK2D_TRY(nk2d_r_newton_final(c, m == 1, m == 1, mreal, mcr, mci, (m - 1) & 1, m == 2, times, x[0], x[1], x[2], jstage2));
+            c->part_cur = nullptr;
+            c->st.nsolve += 2;
+            c->st.nfev += 3;
+            c->st.nnewton++;
+        } else {
+            NK2D_TRY(newton_fixed(s, h, 0, n_iter, n_iter, row_last, row_prev));
+        }
+        if (chained) {
+            if (!final_fused) {
+                double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
+                NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_at_tnew, times, out, x[0], x[1], x[2], jstage2, false));
+                std::swap(c->KV[3], c->KV[2]);
+                std::swap(c->Y, c->YOLD);
+                std::swap(c->Z, c->ZP);
+            }
             s.have_dense = true;
             s.dense_t_old = t;
             s.dense_h = t_new - t;
@@ -754,7 +791,6 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
                 have = false;
             }
         } else {
-            if (norm_out) NK2D_TRY(nk2d_r_step_norms(c, part_last, part_prev, norm_out));
             NK2D_TRY(commit_step(s, t, t_new));
         }
         // nothing is read back during a replay: bound the depth of the launch queue (a year is 10^4 launches; the
@@ -769,6 +805,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         // recorded for, give or take; a state that does not (the recorded year converged at once on a special
         // structure, say) must not be integrated with its iteration counts
         std::vector<double> sums((size_t)2 * n);
+        NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART, 2 * n, c->STEP_NORM));
         NK2D_CHECK(c, hipMemcpyAsync(sums.data(), c->STEP_NORM, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
         const double slack = 30.0;
@@ -778,7 +815,8 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         const double n_unknowns = hooked ? (double)c->tc * c->nz * c->ny : s.n_total;
         for (int64_t i = 0; i < n; ++i) {
             if ((int)sched[i * NK2D_SCHED_WIDTH + 3] < 1) continue;
-            const double s_last = sums[2 * i], s_prev = sums[2 * i + 1];
+            const double s_last = sums[2 * i];
+            const double s_prev = ((int)sched[i * NK2D_SCHED_WIDTH + 3] >= 2) ? sums[2 * i + 1] : -1.0;
             const double n_last = rms_from_sum(s_last, 3.0 * n_unknowns);
             bool ok = n_last == n_last;
             if (ok && n_last != 0.0) {
