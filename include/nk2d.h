@@ -184,7 +184,7 @@ int nk2d_comp_fcn(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats,
 int nk2d_comp_fcn_frozen(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* sched, int64_t sched_n);
 int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n);
 /* A frozen year checks afterwards, for every step, SciPy's Newton convergence test on the last recorded iteration
-   (with a slack of 30) -- one device reduction per step, folded into the step-boundary launch, one read-back per year.
+   (with a slack of 30) -- the norm partials of those iterations are kept, one reduction launch and one read-back per year.
    A state for which the recorded counts are not enough makes nk2d_comp_fcn_frozen return -7; nk2d_jvp then runs a
    free-running year instead.  n: how often that has happened on this context. */
 int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
@@ -311,6 +311,8 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    "min_sweeps" (1, default: a solve whose contraction bound meets lin_tol after ONE sweep runs the whole simplified
    Newton iteration as a single launch, its update written to a spare stage buffer; 2: at least two sweeps wherever
    columns couple, the round-1 rule -- also what the device-side controllers 1 and 2 always use),
+   "final_fuse" (1, default: a step of a frozen year, nk2d_comp_fcn_frozen, ends in the launch of its last Newton
+   iteration; 0: in a step boundary launch of its own, for A/B runs),
    "jac_stage" (0, 1 or 2, with "jac_fresh" 1 and host-side or persistent control: the Jacobian of a step attempt is
    taken at the time of that stage of the attempt, t + c_i h, instead of the step start -- the simplified Newton
    iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
