@@ -312,3 +312,41 @@ def test_frozen_year_reproduces_the_recorded_year_and_checks_newton():
         assert np.isfinite(eng.download(w)).all()
     eng.close()
     tight.close()
+
+
+def test_gmres_residuals_are_true_with_frozen_products():
+    """what GMRES reports after j iterations is the TRUE preconditioned residual of its iterate -- measured with the
+    derivative of the map integrated 10^4 times tighter -- when the products run on frozen years
+    (tools/probe_gmres_quality.py: with free-running products the solver reports 1e-6 where it has 2e-4)"""
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    n, k = 26, 4
+    grid = Grid2d.default(n, n)
+    eng = iage_engine(grid)
+    tight = iage_engine(grid, rtol=1.0e-10, atol=1.0e-10, lin_tol=1.0e-10)
+    tight.set_option("jac_fresh", 0)
+    weight = np.outer(grid.depth.delta, grid.ypos.delta)
+    for e in (eng, tight):
+        e.set_region(np.ones((n, n), dtype=np.int32), weight)
+    col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
+    x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    xt = tight.upload(eng.download(x))
+    fxt, _, sched_t = tight.comp_fcn(xt, record=True)
+    eng.precond_setup()
+    tight.precond_setup()
+    inc, info = eng.gmres_solve(x, fx, 0.0, 0, k, sched=sched)
+    reported = info["resid_norm"][:, 0] / info["beta"][0]
+    assert reported[-1] < 1.0e-3 * reported[0]
+    inc_t = tight.upload(eng.download(inc))
+    nrm = np.sqrt(tight.dot(inc_t, inc_t)[0])
+    w, _, _ = tight.jvp(xt, fxt, tight.scale(inc_t, 1.0 / nrm), sched=sched_t)
+    r = tight.axpby(1.0, fxt, nrm, w)
+    pr, p0 = tight.precond_apply(r), tight.precond_apply(fxt)
+    true = float(np.sqrt(tight.dot(pr, pr)[0] / tight.dot(p0, p0)[0]))
+    assert abs(true - reported[-1]) < 0.05 * reported[-1], (true, reported)
+    assert eng.frozen_fallbacks() == 0
+    eng.close()
+    tight.close()
