@@ -15,8 +15,8 @@ from nk_ooc_amd.setup_solver import make_config, setup  # noqa: E402
 BASE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_baselines",
                     "ci_py_driver_2d_iage_column_regions")
 want, _ = ncio.read_file(os.path.join(BASE, "hist_0000.nc"))
-for fresh, cap in ((0, 0), (1, 0), (0, 1), (1, 1)):
-    os.environ["NK2D_JAC_FRESH"], os.environ["NK2D_GROWTH_CAP"] = str(fresh), str(cap)
+for fresh, stage, cap in ((0, -1, 0), (1, -1, 0), (1, 1, 0), (1, 2, 0), (1, 1, 1), (1, 1, 2), (1, 1, 3), (0, -1, 1)):
+    os.environ["NK2D_JAC_FRESH"], os.environ["NK2D_JAC_STAGE"], os.environ["NK2D_GROWTH_CAP"] = str(fresh), str(stage), str(cap)
     work = tempfile.mkdtemp()
     cfg = make_config(work, 20, 3, extra_modelinfo={"max_abs_vvel": "0.0", "horiz_mix_coeff": "0.0"})
     ModelState.reset_class()
@@ -26,5 +26,6 @@ for fresh, cap in ((0, 0), (1, 0), (0, 1), (1, 1)):
     worst = {name: float(np.max(np.abs(got[name] - ref) / (1.0e-6 + 1.0e-3 * np.abs(ref)))) for name, ref in want.items()
              if got[name].dtype.kind == "f"}
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
-    print(f"jac_fresh={fresh} growth_cap={cap}: steps {ModelState.last_stats[0]['nsteps']}, worst deviation / tolerance:",
+    st = ModelState.last_stats[0]
+    print(f"jac_fresh={fresh} jac_stage={stage} growth_cap={cap}: Newton {st['nnewton']}, rejected {st['nrejected']}, steps {ModelState.last_stats[0]['nsteps']}, worst deviation / tolerance:",
           ", ".join(f"{k} {v:.2f}" for k, v in top), flush=True)
