@@ -2543,13 +2543,10 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     P.guard = nullptr;
     {
         const double words = fused_words(c, do_stage, first, true, delta, do_factor);
+        // counted with the path's launches and bytes (end-to-end figures); not in the shape tallies of
+        // k_newton_fused<E, KIND, 0, 1>: this is a kernel of its own, with the planes' work in it
         c->sweep_launches++;
         c->fused_bytes_all += 8.0 * words;
-        if (!do_factor) {
-            const int shape = do_stage ? 0 : 2;
-            c->shape_cnt[shape]++;
-            c->shape_bytes[shape] += 8.0 * words;
-        }
     }
     const dim3 grid(Fin.nblk_cols + nk2d_grid(c->ny * 3));
 #define NK2D_FINAL_LAUNCH(KK)                                                                                              \
