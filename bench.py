@@ -314,10 +314,10 @@ def run_ladder(device_ordinal, device, args):
 
 
 def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, allreduces_hint):
-    """SURVEY.md section 8(e) level 2, measured: ONE iage module, its two tracers on ranks 0 and 1.  One Krylov
-    iteration (perturbed forward year with every Radau norm all-reduced, preconditioner, CGS-2 with fused
-    multi-dots, residual) is timed after the all-reduce latency itself; when latency x expected count exceeds
-    --shard-budget seconds the leg is skipped and says so."""
+    """SURVEY.md section 8(e) level 2, measured: ONE iage module, its two tracers on ranks 0 and 1.  Untimed: the
+    all-reduce latency itself and the coupled year that gives F(x) (every Radau norm all-reduced; when latency x expected
+    count exceeds --shard-budget seconds the leg is skipped and says so).  Timed: one Krylov iteration -- perturbed
+    year frozen on the coupled year's steps (no exchange), preconditioner, CGS-2 with fused multi-dots, residual."""
     import numpy as np
     import torch
     import torch.distributed as tdist

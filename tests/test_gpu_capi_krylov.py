@@ -350,3 +350,39 @@ def test_gmres_residuals_are_true_with_frozen_products():
     assert eng.frozen_fallbacks() == 0
     eng.close()
     tight.close()
+
+
+@pytest.mark.parametrize("kind", ["phosphorus", "forced_file", "forced_file_threshold"])
+def test_frozen_year_other_module_kinds(kind):
+    """a year frozen on its own recorded steps is the recorded year, bit for bit, for the modules whose Jacobian reads
+    the state (phosphorus, a thresholded sink: Jacobian at the step start, step boundary launches of their own) and for a
+    forced module with forcing files (planes carry the forcing bundle; steps end in their last Newton launch)"""
+    from nk_ooc_amd.engine import ModuleEngine, phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    rng = np.random.default_rng(8)
+    if kind == "phosphorus":
+        eng = phosphorus_engine(Grid2d.default(30, 12))
+        x0 = np.stack([2.0 + 0.1 * rng.standard_normal((30, 12)), 0.05 + 0.005 * rng.standard_normal((30, 12)),
+                       0.01 + 0.001 * rng.standard_normal((30, 12))])
+    else:
+        nz, ny = 130, 11
+        times = np.array([-10.0, 40.0, 95.0, 200.0, 300.0]) * 86400.0
+        restore = 1.0 + 0.2 * rng.standard_normal((5, ny))
+        sms = 3.0e-8 * rng.standard_normal((5, nz, ny))
+        extra = {"sink_thres": 0.4} if kind == "forced_file_threshold" else {}
+        eng = ModuleEngine(Grid2d.default(nz, ny), tc=1, surf_rate=(24.0 / 86400.0,), module_kind=2,
+                           restore_series=(times, restore), sms_series=(times, sms),
+                           time_range=(0.0, 40.0 * 86400.0), **extra)
+        x0 = 0.6 + 0.2 * rng.standard_normal((1, nz, ny))
+    x = eng.upload(x0)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    assert len(sched) == st["nsteps"] > 10
+    fx2, st2 = eng.comp_fcn_frozen(x, sched)
+    assert np.array_equal(eng.download(fx2), eng.download(fx))
+    assert st2["nnewton"] == int(sched[:, 3].sum()) and st2["nlaunch"] < st["nlaunch"]
+    # and a slightly different state passes the Newton check of the frozen year
+    xp = eng.upload(x0 * (1.0 + 1.0e-5 * rng.standard_normal(x0.shape)))
+    fx3, _ = eng.comp_fcn_frozen(xp, sched)
+    assert np.isfinite(eng.download(fx3)).all() and eng.frozen_fallbacks() == 0
+    eng.close()
