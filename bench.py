@@ -506,6 +506,18 @@ def main():
             }
             if world == 1:
                 out["roofline_precond"] = precond_roofline(eng)
+                # the same Krylov iterations as ONE C call with every vector in HBM and no file trail (nk2d_gmres_solve),
+                # for what the checkpoint trail and the Python mirror cost in the timed region above
+                x_vec, f_vec = wl.iterate.tracer_modules[0].vec, wl.fcn.tracer_modules[0].vec
+                sched = (wl.fcn._sched or {}).get("iage") if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else None
+                eng.gmres_solve(x_vec, f_vec, 0.0, 0, 1, sched=sched)
+                eng.sync()
+                t_g = time.perf_counter()
+                eng.gmres_solve(x_vec, f_vec, 0.0, 0, args.steps, sched=sched)
+                eng.sync()
+                t_g = time.perf_counter() - t_g
+                out["gmres_solve_in_hbm"] = {"what": "nk2d_gmres_solve: the same Krylov iterations in one C call, no files",
+                                             "jvps_per_s": args.steps / t_g, "ms_per_jvp": 1000.0 * t_g / args.steps}
         one_gpu_ms = 1000.0 * elapsed / args.steps
         wl_base_stats = dict(wl.fwd_stats)
         faithful_attempts = None
