@@ -518,6 +518,20 @@ def main():
                 t_g = time.perf_counter() - t_g
                 out["gmres_solve_in_hbm"] = {"what": "nk2d_gmres_solve: the same Krylov iterations in one C call, no files",
                                              "jvps_per_s": args.steps / t_g, "ms_per_jvp": 1000.0 * t_g / args.steps}
+                if os.environ.get("NK2D_JVP_FROZEN", "1") != "0":
+                    # the reference's own product, two free-running years, through the same solver: what `value` would
+                    # be without the frozen controller (measured, two Krylov iterations)
+                    os.environ["NK2D_JVP_FROZEN"] = "0"
+                    try:
+                        eng.sync()
+                        t_f = time.perf_counter()
+                        wl.krylov(2, "krylov_free", device)
+                        eng.sync()
+                        t_f = time.perf_counter() - t_f
+                    finally:
+                        os.environ["NK2D_JVP_FROZEN"] = "1"
+                    out["jvp"]["free_running_products"] = {"jvps_per_s": 2.0 / t_f, "ms_per_jvp": 1000.0 * t_f / 2.0,
+                                                           "krylov_iterations": 2}
         one_gpu_ms = 1000.0 * elapsed / args.steps
         wl_base_stats = dict(wl.fwd_stats)
         faithful_attempts = None

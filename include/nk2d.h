@@ -318,10 +318,10 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
    the launch that computes the stage's mixing plane derives the Jacobian planes from it.  -1, the library default:
    the step start, as SciPy.  Ignored by modules whose Jacobian reads the state),
-   "team" (1: the Newton-iteration launches run with one workgroup of four waves per column -- stages, real system,
-   complex system on waves of their own -- instead of one wave per column; same arguments, bit-identical results;
-   -1, the default: chosen per context, on for at most 512 columns of at least 5 levels per lane, where all teams fit
-   the chip at once), "xcd_map" (1: workgroup -> column mapping that gives every XCD a contiguous range of columns;
+   "team" (launch shape of the Newton-iteration launches: 0 one wave per column; 1 one workgroup of four waves per
+   column -- the three stages and the complex system on waves of their own; 2 a pair of waves per column -- stages and
+   real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
+   context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto), "xcd_map" (1: workgroup -> column mapping that gives every XCD a contiguous range of columns;
    0 default -- no measurable gain at 416 x 416), "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs),
    "sweep_wpb" */
 int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);

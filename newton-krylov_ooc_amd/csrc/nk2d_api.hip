@@ -139,7 +139,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "xcd_map") { c->xcd_map = value != 0.0; return 0; }
     if (key == "team") {   // -1: automatic (see nk2d_team_auto), 0 / 1: never / always
-        if (value != 0.0 && value != 1.0 && value != -1.0) return nk2d_fail(c, "nk2d_set_option: team must be -1, 0 or 1");
+        if (value != 0.0 && value != 1.0 && value != 2.0 && value != -1.0) return nk2d_fail(c, "nk2d_set_option: team must be -1, 0, 1 or 2");
         c->team = (value < 0.0) ? nk2d_team_auto(c) : (int)value;
         return 0;
     }

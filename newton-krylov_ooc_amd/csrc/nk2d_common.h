@@ -215,12 +215,19 @@ static inline int nk2d_fail(nk2d_ctx* c, const std::string& msg, int code = -2) 
     return code;
 }
 
-// Whether the Newton-iteration launches run as column teams (k_newton_team: a workgroup of four waves per column) by
-// default.  A team wave holds at most 256 VGPRs, so the chip's 1024 SIMDs take 2048 of them at once: with more than
-// 512 columns the workgroups run in two rounds and the team loses against one wave per column (iage 416^2, 832 columns:
-// 22.5 against 16.4 us per launch); with up to 512 columns of at least five levels per lane it wins (one-tracer module
-// at 416^2: 12.4 against 14.2 us per launch, year 0.60 against 0.66 s); below that the launch floor decides either way.
-static inline int nk2d_team_auto(const nk2d_ctx* c) { return (c->ncol <= 512 && c->E >= 5) ? 1 : 0; }
+// Launch shape of the Newton-iteration launches by default: 0 one wave per column (k_newton_fused), 1 a team of four waves
+// (k_newton_team), 2 a pair of waves (k_newton_pair).  All three give bit-identical results.  A team or pair wave holds
+// at most 256 VGPRs, so the chip's 1024 SIMDs take 2048 of them at once; beyond that the workgroups run in rounds and
+// the split loses (iage 416^2, 832 columns: 22.5 us per launch with teams, frozen year 0.225 s with pairs, against
+// 16.4 us / 0.198 s with one wave per column).  Where everything is resident it wins, the more the smaller the grid --
+// frozen year of iage, one wave / team / pair per column: 26^2 18.6 / 15.9 / 16.0 ms, 52^2 30.0 / 25.7 / 26.0 ms,
+// 104^2 54.1 / 48.1 / 46.4 ms, 208^2 97.9 / 98.3 / 93.7 ms; one-tracer module at 416^2 (416 columns of 7 levels per
+// lane): year 0.66 -> 0.60 s with teams (profiles/r02_team*.log).
+static inline int nk2d_team_auto(const nk2d_ctx* c) {
+    if (c->ncol <= 128) return 1;
+    if (c->ncol <= 512) return (c->E >= 5) ? 1 : 2;
+    return 0;
+}
 
 // grid of a kernel with TASK_PROLOGUE_XCD: tasks_per_block tasks per workgroup, rounded up to a multiple of the 8 XCDs
 static inline int nk2d_grid_xcd(int ntasks, int tasks_per_block) {

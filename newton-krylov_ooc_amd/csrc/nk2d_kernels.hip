@@ -1590,11 +1590,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A
 // of barriers on either branch.  The arithmetic of every value is the one of newton_fused_body, operation
 // for operation, so either kernel can run any launch of a year.
 // ---------------------------------------------------------------------------------
-template <int E>
+template <int E, int WR>      // WR: rows of W kept in LDS (3 for four-wave teams, 0 for pairs: 40 KB, four workgroups per CU)
 struct TeamLds {
     double F[3][E * 64];   // stage tendencies; later the squared scaled increments
     double D[3][E * 64];   // dW of the real system, real and imaginary part of the complex one
-    double W[3][E * 64];   // W before the update (stage launches)
+    double W[WR > 0 ? WR : 1][WR > 0 ? E * 64 : 1];   // W before the update (stage launches of four-wave teams)
     double a[E * 64], c[E * 64], inv[E * 64];   // real system: off-diagonals, pivot reciprocals (FACTOR: the diagonal)
     double tab[NK2D_TAB * 64];
 };
@@ -1610,19 +1610,20 @@ __device__ __forceinline__ void lds_get(const double* s, int lane, double (&v)[E
     for (int e = 0; e < E; ++e) v[e] = s[e * 64 + lane];
 }
 
-template <int E, int KIND, int FACTOR, int STAGE>
-__global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs A) {
-    GUARD_RETURN(P.guard)
-    __shared__ TeamLds<E> S;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int task = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // see TASK_PROLOGUE_XCD
-    if (task >= P.ncol) return;
+// NW = 4: waves 0..2 take a stage each, wave 3 the complex system.  NW = 2 (a "pair"): wave 0 takes the three stages
+// one after the other, wave 1 the complex system -- for modules with more columns than four-wave teams fit the chip
+// at once (iage 416^2: 832 columns = 1 664 pair waves of <= 256 VGPRs, one round).  FIN (pairs only): the launch also
+// ends a frozen step (FinalArgs; the plane workgroups follow the nblk_cols column workgroups, as in k_newton_final).
+template <int E, int KIND, int FACTOR, int STAGE, int NW, int FIN>
+__device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs& A, TeamLds<E, (NW == 4 ? 3 : 0)>& S, int task, int w, int lane,
+                                                 const FinalArgs* fin) {
+    constexpr int CW = NW - 1;      // the complex wave
+    constexpr int NS = NW - 1;      // stage waves
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     const bool stage = STAGE && A.do_stage;
 
-    if (w == 3) {
+    if (w == CW) {
         // =========================== complex system; supplier of the real one ===========================
         double a[E], cc[E];
         {
@@ -1648,7 +1649,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
                 load_col<E>(A.sw.fr_inv, task, lane, rinv);
                 load_tab<E>(A.sw.fr_tab, task, lane, rtab);
             }
-            load_col<E>(A.st.w, task, lane, w0);
+            if constexpr (NW == 4) load_col<E>(A.st.w, task, lane, w0);
             lds_put<E>(S.a, lane, a);
             lds_put<E>(S.c, lane, cc);
             lds_put<E>(S.inv, lane, rinv);
@@ -1656,7 +1657,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
 #pragma unroll
                 for (int i = 0; i < NK2D_TAB; ++i) S.tab[i * 64 + lane] = rtab[i];
             }
-            lds_put<E>(S.W[0], lane, w0);
+            if constexpr (NW == 4) lds_put<E>(S.W[0], lane, w0);
         }
         if constexpr (FACTOR) {
             line_diag<E, KIND, 0>(P, A.sw.JC, tr, j, lane, A.sw.ccr, dre);
@@ -1683,8 +1684,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
             double w1[E], w2[E];
             load_col<E>(A.st.w + A.st.nv, task, lane, w1);
             load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
-            lds_put<E>(S.W[1], lane, w1);
-            lds_put<E>(S.W[2], lane, w2);
+            if constexpr (NW == 4) {
+                lds_put<E>(S.W[1], lane, w1);
+                lds_put<E>(S.W[2], lane, w2);
+            }
             __syncthreads();   // barrier 1: stage tendencies are in LDS
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1786,44 +1789,53 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
         return;
     }
 
-    // =========================== waves 0..2: stages, real system (wave 0), update ===========================
+    // =========================== stage waves: stages, real system (wave 0), update ===========================
     double yy[E];
+    double wpre[E];      // pairs: W_0 of the real right-hand side, fetched before the stages
+    if constexpr (NW == 2) {
+        if (stage) load_col<E>(A.st.w, task, lane, wpre);
+    }
     if (STAGE && A.do_stage) {
-        const int i = w;
-        const double* __restrict__ zi = A.st.z + (size_t)i * A.st.nv;
-        const double* __restrict__ kvi = (i == 0) ? A.st.kv[0] : ((i == 1) ? A.st.kv[1] : A.st.kv[2]);
         ColCoef<E> cf;
         load_coef<E>(P, j, lane, cf);
-        double ys[E], yn[E], c[E], cs[E], cn[E], kv[E], f[E];
+        double ys[E], yn[E];
         load_col<E>(A.st.y, task, lane, yy);
         load_col<E>(A.st.y, cs_col, lane, ys);
         load_col<E>(A.st.y, cn_col, lane, yn);
-        load_col<E>(zi, task, lane, c);
-        load_col<E>(zi, cs_col, lane, cs);
-        load_col<E>(zi, cn_col, lane, cn);
-        load_col<E>(kvi, j, lane, kv);
+        for (int i = w; i < 3; i += NS) {
+            const double* __restrict__ zi = A.st.z + (size_t)i * A.st.nv;
+            const double* __restrict__ kvi = (i == 0) ? A.st.kv[0] : ((i == 1) ? A.st.kv[1] : A.st.kv[2]);
+            double c[E], cs[E], cn[E], kv[E], f[E];
+            load_col<E>(zi, task, lane, c);
+            load_col<E>(zi, cs_col, lane, cs);
+            load_col<E>(zi, cn_col, lane, cn);
+            load_col<E>(kvi, j, lane, kv);
 #pragma unroll
-        for (int e = 0; e < E; ++e) { c[e] = yy[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
-        tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
-        if constexpr (KIND == 2) forced_sources<E>(P, kvi, j, lane, c, f);
-        if constexpr (KIND == 1) {
-            double u1[E], u2[E], v1[E], v2[E];
-            phos_load_others<E>(P, tr, j, lane, A.st.y, u1, u2);
-            phos_load_others<E>(P, tr, j, lane, zi, v1, v2);
-            phos_add<E>(u1, u2, v1, v2);
-            phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, f);
+            for (int e = 0; e < E; ++e) { c[e] = yy[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
+            tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
+            if constexpr (KIND == 2) forced_sources<E>(P, kvi, j, lane, c, f);
+            if constexpr (KIND == 1) {
+                double u1[E], u2[E], v1[E], v2[E];
+                phos_load_others<E>(P, tr, j, lane, A.st.y, u1, u2);
+                phos_load_others<E>(P, tr, j, lane, zi, v1, v2);
+                phos_add<E>(u1, u2, v1, v2);
+                phos_sources<E>(P, tr, j, lane, c, u1, u2, cf.dzr, f);
+            }
+            lds_put<E>(S.F[i], lane, f);
         }
-        lds_put<E>(S.F[i], lane, f);
         __syncthreads();   // barrier 1
     }
     double w0[E], w1[E], w2[E];
     if (A.do_update) {
-        if (stage) {
-            lds_get<E>(S.W[0], lane, w0);
-            lds_get<E>(S.W[1], lane, w1);
-            lds_get<E>(S.W[2], lane, w2);
-        } else {
-            load_col<E>(A.st.y, task, lane, yy);
+        if constexpr (NW == 4) {
+            if (stage) {
+                lds_get<E>(S.W[0], lane, w0);
+                lds_get<E>(S.W[1], lane, w1);
+                lds_get<E>(S.W[2], lane, w2);
+            }
+        }
+        if (NW == 2 || !stage) {
+            if (!stage) load_col<E>(A.st.y, task, lane, yy);
             load_col<E>(A.st.w, task, lane, w0);
             load_col<E>(A.st.w + A.st.nv, task, lane, w1);
             load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
@@ -1840,7 +1852,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
                 for (int i = 0; i < NK2D_TAB; ++i) rtab[i] = S.tab[i * 64 + lane];
             }
             double wr0[E];
-            lds_get<E>(S.W[0], lane, wr0);
+            if constexpr (NW == 4) {
+                lds_get<E>(S.W[0], lane, wr0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) wr0[e] = wpre[e];
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 double s = 0.0;
@@ -1912,26 +1929,114 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
     if (!A.do_update) return;
     __syncthreads();   // barrier 2
     {
-        const int r = w;
-        double q[E], zz[E], wr[E];
+        double d0[E], d1[E], d2[E];
+        lds_get<E>(S.D[0], lane, d0);
+        lds_get<E>(S.D[1], lane, d1);
+        lds_get<E>(S.D[2], lane, d2);
+        // squared scaled increments of this wave's components (before the update below changes nothing they read)
+        for (int r = w; r < 3; r += NS) {
+            double q[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double sc = P.atol + fabs(yy[e]) * P.rtol;
+                const double dr = (r == 0) ? d0[e] : ((r == 1) ? d1[e] : d2[e]);
+                const double dq = dr / sc;
+                q[e] = dq * dq;
+            }
+            lds_put<E>(S.F[r], lane, q);
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const double d0 = S.D[0][e * 64 + lane], d1 = S.D[1][e * 64 + lane], d2 = S.D[2][e * 64 + lane];
-            const double sc = P.atol + fabs(yy[e]) * P.rtol;
-            const double dr = (r == 0) ? d0 : ((r == 1) ? d1 : d2);
-            const double dq = dr / sc;
-            q[e] = dq * dq;
-            w0[e] = w0[e] + d0;
-            w1[e] = w1[e] + d1;
-            w2[e] = w2[e] + d2;
-            wr[e] = (r == 0) ? w0[e] : ((r == 1) ? w1[e] : w2[e]);
-            zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+            w0[e] = w0[e] + d0[e];
+            w1[e] = w1[e] + d1[e];
+            w2[e] = w2[e] + d2[e];
         }
-        lds_put<E>(S.F[r], lane, q);
-        store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wr);
-        store_col<E>(A.st.zout + (size_t)r * A.st.nv, task, lane, zz);
+        if constexpr (FIN) {
+            // end of a frozen step, as in newton_fused_body<..., FINAL>: commit, prediction of the next attempt
+            double z0[E], z1[E], z2[E], yn[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                z0[e] = (cT[0][0] * w0[e] + cT[0][1] * w1[e]) + cT[0][2] * w2[e];
+                z1[e] = (cT[1][0] * w0[e] + cT[1][1] * w1[e]) + cT[1][2] * w2[e];
+                z2[e] = (cT[2][0] * w0[e] + cT[2][1] * w1[e]) + cT[2][2] * w2[e];
+                yn[e] = yy[e] + z2[e];
+            }
+            store_col<E>(fin->ynew, task, lane, yn);
+            const double xs[3] = {fin->x0, fin->x1, fin->x2};
+            double o[3][E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double qq[3];
+#pragma unroll
+                for (int cidx = 0; cidx < 3; ++cidx) qq[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double p1 = xs[i], p2 = p1 * xs[i], p3 = p2 * xs[i];
+                    double v = (qq[0] * p1 + qq[1] * p2) + qq[2] * p3;
+                    v = v + yy[e];
+                    o[i][e] = v - yn[e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) store_col<E>(fin->znext + i * A.st.nv, task, lane, o[i]);
+            double wv[E];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
+                store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wv);
+            }
+        } else {
+            for (int r = w; r < 3; r += NS) {
+                double zz[E], wr[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    wr[e] = (r == 0) ? w0[e] : ((r == 1) ? w1[e] : w2[e]);
+                    zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+                }
+                store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wr);
+                store_col<E>(A.st.zout + (size_t)r * A.st.nv, task, lane, zz);
+            }
+        }
     }
     __syncthreads();   // barrier 3
+}
+
+template <int E, int KIND, int FACTOR, int STAGE>
+__global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs A) {
+    GUARD_RETURN(P.guard)
+    __shared__ TeamLds<E, 3> S;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int task = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // see TASK_PROLOGUE_XCD
+    if (task >= P.ncol) return;
+    newton_team_body<E, KIND, FACTOR, STAGE, 4, 0>(P, A, S, task, w, lane, nullptr);
+}
+
+// pairs: two waves per column (newton_team_body, NW = 2); FIN: the launch also ends a frozen step (plane workgroups of
+// 128 threads behind the Fin.nblk_cols column workgroups)
+template <int E, int KIND, int FACTOR, int STAGE, int FIN>
+__global__ void __launch_bounds__(128, 2) k_newton_pair(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J) {
+    GUARD_RETURN(P.guard)
+    __shared__ TeamLds<E, 0> S;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (FIN) {
+        if ((int)blockIdx.x >= Fin.nblk_cols) {
+            const int ptask = ((int)blockIdx.x - Fin.nblk_cols) * 2 + w;
+            if (ptask < P.ny * 3) {
+                double kv[E];
+                vmix_body_kv<E>(P, V, ptask, lane, kv);
+                const int ti = ptask / P.ny;
+                if (ti == J.stage)
+                    jac_core<E, 0>(P, kv, V.out[ti], J.JL, J.JU, J.JS, J.JN, J.JC, nullptr, nullptr, ptask - ti * P.ny, lane);
+            }
+            return;
+        }
+    }
+    const int task = (int)blockIdx.x;
+    if (task >= P.ncol) return;
+    newton_team_body<E, KIND, FACTOR, STAGE, 2, FIN>(P, A, S, task, w, lane, FIN ? &Fin : nullptr);
 }
 
 // error estimate right-hand side  f + Z^T E / h   (radau.py:478-479)
@@ -2449,7 +2554,19 @@ static void fill_fused_args(nk2d_ctx* c, FusedArgs& A, bool do_stage, bool first
 }
 
 static int launch_fused(nk2d_ctx* c, const DevP& P, const FusedArgs& A, bool do_factor, bool do_stage) {
-    if (c->team) {    // one workgroup per column (k_newton_team)
+    if (c->team == 2) {    // a pair of waves per column (k_newton_pair)
+        FinalArgs Fin = {};
+        VmixArgs V = {};
+        JacOut J = {};
+        const dim3 grid(c->ncol), block(128);
+        if (do_factor) {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_pair<EE, KK, 1, 1, 0>), grid, block, 0, c->stream, P, A, Fin, V, J));
+        } else if (do_stage) {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_pair<EE, KK, 0, 1, 0>), grid, block, 0, c->stream, P, A, Fin, V, J));
+        } else {
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_pair<EE, KK, 0, 0, 0>), grid, block, 0, c->stream, P, A, Fin, V, J));
+        }
+    } else if (c->team) {    // one workgroup of four waves per column (k_newton_team)
         if (do_factor) {
             NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, c->stream, P, A));
         } else if (do_stage) {
@@ -2557,7 +2674,20 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     } else {                                                                                                               \
         NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
     }
-    if (c->kind == 2) { NK2D_FINAL_LAUNCH(2) } else { NK2D_FINAL_LAUNCH(0) }
+    if (c->team == 2) {
+        Fin.nblk_cols = c->ncol;
+        const dim3 pgrid(c->ncol + (c->ny * 3 + 1) / 2), pblock(128);
+#define NK2D_PAIR_FINAL(KK)                                                                                                \
+        if (do_factor) {                                                                                                   \
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_pair<EE, KK, 1, 1, 1>), pgrid, pblock, 0, c->stream, P, A, Fin, V, J)); \
+        } else if (do_stage) {                                                                                             \
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_pair<EE, KK, 0, 1, 1>), pgrid, pblock, 0, c->stream, P, A, Fin, V, J)); \
+        } else {                                                                                                           \
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_pair<EE, KK, 0, 0, 1>), pgrid, pblock, 0, c->stream, P, A, Fin, V, J)); \
+        }
+        if (c->kind == 2) { NK2D_PAIR_FINAL(2) } else { NK2D_PAIR_FINAL(0) }
+#undef NK2D_PAIR_FINAL
+    } else if (c->kind == 2) { NK2D_FINAL_LAUNCH(2) } else { NK2D_FINAL_LAUNCH(0) }
 #undef NK2D_FINAL_LAUNCH
     NK2D_CHECK(c, hipGetLastError());
     std::swap(c->Y, c->YOLD);

@@ -21,7 +21,7 @@ def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
 def _year_variants(eng, x, counters=("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps")):
     eng.set_option("device_ctl", 0)
     ref = None
-    for team, xcd in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    for team, xcd in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 0)):       # 2: a pair of waves per column
         eng.set_option("team", team)
         eng.set_option("xcd_map", xcd)
         fx, stats, sched = eng.comp_fcn(x, record=True)
@@ -72,7 +72,7 @@ def test_team_min_sweeps_two_and_replay():
         rep.append(eng.download(fx))
     assert np.array_equal(rep[0], rep[1])
     with pytest.raises(Exception, match="team"):
-        eng.set_option("team", 2)
+        eng.set_option("team", 3)
 
 
 def test_team_phosphorus_bitwise():
@@ -135,3 +135,23 @@ def test_profile_replay_and_shapes():
         eng.profile_replay(3, 4)
     fx2, _, _ = eng.comp_fcn(x)
     assert np.array_equal(eng.download(fx2), first)
+
+
+@pytest.mark.parametrize("nz,ny", [(26, 26), (130, 21), (416, 9)])
+def test_pair_frozen_year_bitwise(nz, ny):
+    """pairs also end frozen steps (k_newton_pair with the FinalArgs epilogue on the stage wave): a year frozen on the
+    recorded steps is the recorded year whichever launch shape runs it"""
+    eng = make_engine(nz, ny)
+    model, _ = oracle_iage(nz, ny)
+    rng = np.random.default_rng(6)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2) + 0.01 * rng.standard_normal((2, nz, ny)))
+    eng.set_option("device_ctl", 0)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    want = eng.download(fx)
+    for team in (0, 1, 2):
+        eng.set_option("team", team)
+        fx2, st2 = eng.comp_fcn_frozen(x, sched)
+        assert np.array_equal(eng.download(fx2), want), team
+        assert st2["nlaunch"] < 0.6 * st["nlaunch"]
+    eng.close()

@@ -26,13 +26,14 @@ for n in [int(v) for v in (args or ["26", "104", "416"])]:
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * tc).copy())
     out = {}
     for rep in range(2):
-        for team, xcd in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        for team, xcd in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0)):
             eng.set_option("team", team)
             eng.set_option("xcd_map", xcd)
-            fx, st, _ = eng.comp_fcn(x)
-            out[(team, xcd)] = (st["seconds"], st["nsteps"], st["nnewton"], st["nsweeps"], eng.download(fx))
+            fx, st, sched = eng.comp_fcn(x, record=True)
+            _, stf = eng.comp_fcn_frozen(x, sched)
+            out[(team, xcd)] = (st["seconds"], st["nsteps"], st["nnewton"], st["nsweeps"], eng.download(fx), stf["seconds"])
     ref = out[(0, 0)]
     for key, val in out.items():
-        print(f"n={n}: team {key[0]} xcd_map {key[1]}: {val[0]:.4f} s ({ref[0] / val[0]:.2f}x), steps {val[1]}, Newton {val[2]}, "
+        print(f"n={n}: team {key[0]} xcd_map {key[1]}: {val[0]:.4f} s ({ref[0] / val[0]:.2f}x), frozen year {val[5]:.4f} s ({ref[5] / val[5]:.2f}x), steps {val[1]}, Newton {val[2]}, "
               f"sweeps {val[3]}, identical to (0, 0): {np.array_equal(val[4], ref[4])}", flush=True)
     eng.close()
