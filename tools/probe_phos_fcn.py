@@ -21,3 +21,14 @@ for rep in range(2):
     t0 = time.time()
     fx, st, _ = eng.comp_fcn(x)
     print(f"n={n} wall={time.time()-t0:.3f}s " + " ".join(f"{k}={v}" for k, v in st.items() if k != "seconds"), flush=True)
+# the perturbed year of a product: frozen on the steps of the year above
+sched = eng.last_schedule()
+for rep in range(2):
+    rng = np.random.default_rng(rep)
+    xp = eng.upload(y0 * (1.0 + 1.0e-5 * rng.standard_normal(y0.shape)))
+    t0 = time.time()
+    fxp, stf = eng.comp_fcn_frozen(xp, sched)
+    print(f"n={n} frozen year wall={time.time()-t0:.3f}s " + " ".join(f"{k}={v}" for k, v in stf.items() if k != "seconds"),
+          f"rejected={eng.frozen_fallbacks()}", flush=True)
+fx2, _ = eng.comp_fcn_frozen(x, sched)
+print("frozen year of the recorded state bit-identical:", bool(np.array_equal(eng.download(fx2), eng.download(fx))), flush=True)
