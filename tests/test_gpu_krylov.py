@@ -104,7 +104,7 @@ def _setup_run(tmp_path, nz, ny, extra_modelinfo=None, extra_solverinfo=None):
     return cfg, ModelState
 
 
-def test_krylov_column_regions_vs_reference_baselines(tmp_path, monkeypatch):
+def test_krylov_column_regions_vs_reference_baselines(tmp_path):
     """the ci_py_driver_2d_iage_column_regions case end to end on the GPU, compared with the
     reference's committed files at the tolerances of its CI script"""
     import json

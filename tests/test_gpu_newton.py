@@ -22,7 +22,7 @@ def _read_state(fname):
     return np.stack([data["iage"], data["iage_slow_rest"]]).reshape(-1)
 
 
-def test_newton_column_regions(tmp_path, monkeypatch):
+def test_newton_column_regions(tmp_path):
     from nk_ooc_amd import ncio, nk_driver
     from nk_ooc_amd.model_state import ModelState
     from nk_ooc_amd.setup_solver import make_config, setup
