@@ -693,6 +693,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         return -1;
     };
     int pre_jstage = -1;       // stage whose Jacobian the boundary launch of the row before derived for this row
+    bool kv3_at_t = true;      // KV[3] holds the mixing plane at the current t (year start; after a boundary launch)
     for (int64_t i = 0; i < n; ++i) {
         const double* r = sched + i * NK2D_SCHED_WIDTH;
         const double t = r[0], t_new = r[1], h = r[2], t_jac = r[4], h_lu = r[5];
@@ -721,7 +722,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
                 if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[jstage], nullptr));
                 s.t_jac = t_jac;
             } else {
-                NK2D_TRY(refresh_jac(s, t_jac, false));
+                NK2D_TRY(refresh_jac(s, t_jac, t_jac == t && kv3_at_t));   // the plane at t is at hand after a boundary launch
             }
             c->st.njev++;
             have = false;
@@ -778,6 +779,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
                 std::swap(c->Y, c->YOLD);
                 std::swap(c->Z, c->ZP);
             }
+            kv3_at_t = !final_fused;
             s.have_dense = true;
             s.dense_t_old = t;
             s.dense_h = t_new - t;
@@ -792,6 +794,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             }
         } else {
             NK2D_TRY(commit_step(s, t, t_new));
+            kv3_at_t = false;
         }
         // nothing is read back during a replay: bound the depth of the launch queue (a year is 10^4 launches; the
         // counter-collecting profiler of this ROCm falls over behind a few thousand unsynchronised dispatches, as it
