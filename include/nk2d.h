@@ -262,7 +262,9 @@ int nk2d_timer_end(nk2d_ctx* ctx, double* elapsed_ms);
    w = (F(x + sigma v) - fx) * (1 / sigma), region by region.  fx = F(x) is the caller's (the Newton
    solver has it).  perturb_fcn (optional, may be null) receives F(x + sigma v), the vector the
    reference dumps as perturb_fcn_w_raw_NN.nc; sigma_out (optional) [nreg]; stats (optional) of the
-   perturbed forward year. */
+   perturbed forward year.  The perturbed year is a free-running one, as the reference's, unless a schedule is
+   installed (nk2d_set_frozen_schedule): then it repeats the accepted steps of the year that produced fx, and a
+   state the recorded Newton counts do not converge for gets a free-running year after all (nk2d_frozen_fallbacks). */
 int nk2d_jvp(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_vec v, nk2d_vec w, nk2d_vec perturb_fcn,
              double* sigma_out, nk2d_stats* stats);
 
