@@ -7,4 +7,4 @@ numerics run in hand-written HIP kernels for gfx950 behind the C ABI declared in
 fallback: importing the device layer without the built library raises.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
