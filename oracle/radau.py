@@ -330,8 +330,10 @@ class RadauOracle:
             assert t == self.t
             y = self.y
             if t_jac != t_jac_cur:
-                # a Jacobian is only ever evaluated at the start point of a step
-                assert t_jac == t
+                # SciPy only ever evaluates a Jacobian at the start point of a step; the schedules of the HIP library's
+                # production mode (option "jac_stage") take it at a stage time of the step, t + c_i h, for modules
+                # whose Jacobian is a function of time alone -- evaluated here with the state at the step start, which
+                # such a Jacobian does not read
                 self.J = csc_matrix(self._jac(t_jac, y), dtype=float)
                 t_jac_cur = t_jac
                 h_lu_cur = None

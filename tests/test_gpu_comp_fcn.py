@@ -166,3 +166,30 @@ def test_comp_fcn_strong_lateral_coupling(vv, kh):
     assert np.allclose(eng.download(fx_def).reshape(-1), want, rtol=1.0e-3, atol=1.0e-6)
     for key, ref in (("nfev", solver.stats.nfev), ("njev", solver.stats.njev), ("nlu", solver.stats.nlu)):
         assert abs(stats[key] - ref) <= 0.1 * ref + 5, (key, stats[key], ref)
+
+
+@pytest.mark.parametrize("nz,ny,vv,kh", [(20, 3, 0.0, 0.0), (26, 26, 0.1, 1000.0)])
+def test_default_mode_schedule_replayed_by_the_oracle(nz, ny, vv, kh):
+    """the production mode from the other side: a free-running year in the engines' default mode (Jacobian at the second
+    stage time of every attempt) records its steps; the CPU oracle -- SciPy's sparse LU, its own Jacobian and mixing
+    coefficient functions -- replays exactly those steps and Jacobian times, and so does the device with the inner
+    tolerance of a replay.  1e-10, as for SciPy's own schedules: stage planes, stage-time Jacobian and step boundary of
+    the default mode compute what the restated reference functions compute."""
+    from oracle import radau
+
+    eng = make_engine(nz, ny, vv, kh)
+    model, tm = oracle_iage(nz, ny, vv, kh)
+    rng = np.random.default_rng(17)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2) + 0.01 * rng.standard_normal((2, nz, ny))
+    x = eng.upload(x0)
+    eng.set_option("device_ctl", 0)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    off_start = int(np.sum(sched[:, 4] != sched[:, 0]))
+    assert off_start > 0.9 * len(sched)              # the Jacobian times are stage times, not step starts
+    rows = [(r[0], r[1], r[2], int(r[3]), r[4], r[5]) for r in sched]
+    want = radau.comp_fcn(tm, x0.reshape(-1), replay=rows)
+    got, _, _ = eng.comp_fcn(x, replay=sched)
+    assert rel_err(eng.download(got).reshape(-1), want) < 1e-10
+    # and the free-running year itself is that map to the Newton tolerance
+    assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1e-6, atol=1e-8)
