@@ -193,3 +193,31 @@ def test_default_mode_schedule_replayed_by_the_oracle(nz, ny, vv, kh):
     assert rel_err(eng.download(got).reshape(-1), want) < 1e-10
     # and the free-running year itself is that map to the Newton tolerance
     assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("nz,ny,vv,kh", [(20, 3, 0.0, 0.0), (26, 26, 0.1, 1000.0)])
+def test_frozen_product_against_the_oracle(nz, ny, vv, kh):
+    """the finite-difference product on frozen years, device against CPU oracle: both difference two years on the SAME
+    recorded steps (the oracle with SciPy's sparse LU), sigma as the reference takes it"""
+    from oracle import radau
+
+    eng = make_engine(nz, ny, vv, kh)
+    model, tm = oracle_iage(nz, ny, vv, kh)
+    weight = np.outer(model.depth.delta, model.ypos.delta)
+    eng.set_region(np.ones((nz, ny), dtype=np.int32), weight)
+    rng = np.random.default_rng(23)
+    col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2) + 0.01 * rng.standard_normal((2, nz, ny))
+    v = np.cumsum(rng.standard_normal(x0.shape), axis=1)
+    x, vd = eng.upload(x0), eng.upload(v)
+    vd = eng.scale(vd, 1.0 / np.sqrt(eng.dot(vd, vd)))
+    v = eng.download(vd)
+    eng.set_option("device_ctl", 0)
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    w, sigma, stp = eng.jvp(x, fx, vd, sched=sched)
+    assert eng.frozen_fallbacks() == 0 and stp["nrejected"] == 0
+    rows = [(r[0], r[1], r[2], int(r[3]), r[4], r[5]) for r in sched]
+    f0 = radau.comp_fcn(tm, x0.reshape(-1), replay=rows)
+    f1 = radau.comp_fcn(tm, (x0 + sigma[0] * v).reshape(-1), replay=rows)
+    w_oracle = (f1 - f0) / sigma[0]
+    assert rel_err(eng.download(w).reshape(-1), w_oracle) < 2e-3
