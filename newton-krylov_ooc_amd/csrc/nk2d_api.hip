@@ -132,6 +132,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
+    if (key == "jac_stage_state") { c->jac_stage_state = value != 0.0; return 0; }
     if (key == "jac_stage") {
         if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: jac_stage must be -1, 0, 1 or 2");
         c->jac_stage = (int)value;
@@ -358,6 +359,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->xcd_map = 0;
     c->jac_stage = -1;
     c->final_fuse = 1;
+    c->jac_stage_state = 1;
     c->part_cur = nullptr;
     NK2D_TRY(dev_alloc(c, &c->W, 3 * c->nv));
     NK2D_TRY(dev_alloc(c, &c->BR, c->nv));

@@ -83,6 +83,7 @@ struct nk2d_ctx {
     std::vector<double> last_sched;     // accepted steps of the most recent free-running year (nk2d_last_schedule)
     std::vector<double> own_rec;        // its record buffer when the caller gave none
     std::vector<double> frozen_sched;   // accepted steps the perturbed years of nk2d_jvp repeat (nk2d_set_frozen_schedule)
+    int jac_stage_state;   // 1: option "jac_stage" also for modules whose Jacobian reads the state (plane of the stage time, state of the step start)
     int final_fuse;    // 1: a frozen step ends in the launch of its last Newton iteration (option "final_fuse", for A/B runs)
     int jac_stage;     // >= 0: Jacobian of a step attempt from the vertical mixing plane of this stage time (option "jac_stage"); -1: step start
     int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")

@@ -453,7 +453,10 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         else if (s.h_abs < min_step) { h_abs = min_step; has_h_old = has_err_old = false; }
         else { h_abs = s.h_abs; h_abs_old = s.h_abs_old; err_old = s.err_old; has_h_old = s.has_old_h; has_err_old = s.has_old_err; }
         const bool jac_needs_state0 = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
-        const bool jac_at_stage = c->jac_stage >= 0 && c->jac_fresh && s.device_ctl == 0 && !jac_needs_state0;
+        // (modules whose Jacobian reads the state: only with option "jac_stage_state" -- the mixing plane of the stage time,
+        // the state of the step start, in a launch of its own)
+        const bool jac_at_stage = c->jac_stage >= 0 && c->jac_fresh && s.device_ctl == 0 && (!jac_needs_state0 || c->jac_stage_state);
+        const int jst_inlaunch = (jac_at_stage && !jac_needs_state0) ? c->jac_stage : -1;
         if (c->jac_fresh && !s.current_jac && !jac_at_stage) {
             // evaluating J costs two small launches here (SciPy pays a Python double loop and two
             // SuperLU factorisations, hence its reuse heuristics): never start a step on a stale J
@@ -483,9 +486,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 predicted = true;            // queued with the commit of the step before
                 jac_done = s.pre_jac;
             } else if (s.device_ctl == 0 && s.have_dense) {
-                NK2D_TRY(setup_attempt(s, t, h, jac_at_stage ? c->jac_stage : -1));
+                NK2D_TRY(setup_attempt(s, t, h, jst_inlaunch));
                 predicted = true;
-                jac_done = jac_at_stage;
+                jac_done = jst_inlaunch >= 0;
             } else {
                 NK2D_TRY(stage_planes(s, t, h));
             }
@@ -493,7 +496,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             if (jac_at_stage) {
                 // option "jac_stage": the Jacobian of this attempt from the vertical mixing plane of one of ITS stage
                 // times instead of the step start (normally derived by the launch that computed the plane)
-                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[c->jac_stage], nullptr));
+                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[c->jac_stage], jac_needs_state0 ? c->Y : nullptr));
                 s.t_jac = t + (h * RC[c->jac_stage]);
                 c->st.njev++;
                 s.current_jac = true;
@@ -614,7 +617,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // stage buffers nobody needs any more and to the buffer of the plane at the old t
             double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
             NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_due && !jac_needs_state && !jac_at_stage, times, out, x[0], x[1], x[2],
-                                          jac_at_stage ? c->jac_stage : -1));
+                                          jst_inlaunch));
             std::swap(c->KV[3], c->KV[2]);
             std::swap(c->Y, c->YOLD);
             std::swap(c->Z, c->ZP);
@@ -624,7 +627,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             s.t = t_new;
             c->st.nsteps++;
             c->st.nfev++;
-            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2; s.pre_jac = jac_at_stage;
+            s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2; s.pre_jac = jst_inlaunch >= 0;
             if (jac_at_stage) {
                 s.current_jac = false;   // evaluated inside the next attempt
             } else if (jac_due) {
@@ -687,7 +690,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
     const bool fast = s.device_ctl == 0 && c->hist_n == 0;
     // stage of the attempt (t, h) whose time is t_jac, or -1
     auto stage_of = [&](double t, double h, double t_jac) {
-        if (needs_state || !fast) return -1;
+        if ((needs_state && !c->jac_stage_state) || !fast) return -1;
         for (int k = 0; k < 3; ++k)
             if (t_jac == t + (h * RC[k])) return k;
         return -1;
@@ -701,17 +704,18 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         if (t != s.t) return nk2d_fail(c, "nk2d_comp_fcn: replay schedule does not start where the state is", -5);
         // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
         // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
-        if (t_jac != s.t_jac && t_jac != t && needs_state)
+        if (t_jac != s.t_jac && t_jac != t && needs_state && stage_of(t, h, t_jac) < 0)
             return nk2d_fail(c, "nk2d_comp_fcn: replay schedule refreshes the Jacobian off a step start", -5);
         const int jstage = (t_jac != s.t_jac) ? stage_of(t, h, t_jac) : -1;
         bool predicted = false, jac_done = false;
+        const int jstage_inlaunch = needs_state ? -1 : jstage;    // a Jacobian that reads the state: a launch of its own
         if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
             predicted = true;
-            jac_done = jstage >= 0 && pre_jstage == jstage;
+            jac_done = jstage_inlaunch >= 0 && pre_jstage == jstage_inlaunch;
         } else if (fast && s.have_dense) {
-            NK2D_TRY(setup_attempt(s, t, h, jstage));
+            NK2D_TRY(setup_attempt(s, t, h, jstage_inlaunch));
             predicted = true;
-            jac_done = jstage >= 0;
+            jac_done = jstage_inlaunch >= 0;
         } else {
             NK2D_TRY(stage_planes(s, t, h));
         }
@@ -719,7 +723,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         pre_jstage = -1;
         if (t_jac != s.t_jac) {
             if (jstage >= 0) {
-                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[jstage], nullptr));
+                if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[jstage], needs_state ? c->Y : nullptr));
                 s.t_jac = t_jac;
             } else {
                 NK2D_TRY(refresh_jac(s, t_jac, t_jac == t && kv3_at_t));   // the plane at t is at hand after a boundary launch
@@ -742,7 +746,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             h2 = r2[2];
             const double t_jac2 = r2[4];
             const bool jac_new = t_jac2 != s.t_jac;
-            jstage2 = jac_new ? stage_of(t_new, h2, t_jac2) : -1;
+            jstage2 = (jac_new && !needs_state) ? stage_of(t_new, h2, t_jac2) : -1;
             jac_at_tnew = jac_new && jstage2 < 0 && t_jac2 == t_new && !needs_state;
             for (int k = 0; k < 3; ++k) {
                 times[k] = t_new + (h2 * RC[k]);
