@@ -319,7 +319,8 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    taken at the time of that stage of the attempt, t + c_i h, instead of the step start -- the simplified Newton
    iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
    the launch that computes the stage's mixing plane derives the Jacobian planes from it.  -1, the library default:
-   the step start, as SciPy.  Ignored by modules whose Jacobian reads the state),
+   the step start, as SciPy.  Modules whose Jacobian also reads the state take the mixing plane of that time and the
+   state of the step start, in a launch of their own -- option "jac_stage_state" 1, the default; 0: step start for both),
    "team" (launch shape of the Newton-iteration launches: 0 one wave per column; 1 one workgroup of four waves per
    column -- the three stages and the complex system on waves of their own; 2 a pair of waves per column -- stages and
    real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
