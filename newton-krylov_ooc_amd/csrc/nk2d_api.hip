@@ -132,6 +132,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
+    if (key == "prefactor") { c->prefactor = value != 0.0; return 0; }
     if (key == "jac_stage_state") { c->jac_stage_state = value != 0.0; return 0; }
     if (key == "jac_stage") {
         if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: jac_stage must be -1, 0, 1 or 2");
@@ -376,6 +377,14 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->FR_TAB, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABR, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABI, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FB_INV, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FCB_INVR, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FCB_INVI, c->nv));
+    NK2D_TRY(dev_alloc(c, &c->FB_TAB, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FCB_TABR, (size_t)c->ncol * 14 * 64));
+    NK2D_TRY(dev_alloc(c, &c->FCB_TABI, (size_t)c->ncol * 14 * 64));
+    c->prefactor = 1;
+    c->prefactored = 0;
     NK2D_TRY(dev_alloc(c, &c->FR32_INV, c->nv));
     NK2D_TRY(dev_alloc(c, &c->FC32_INVR, c->nv));
     NK2D_TRY(dev_alloc(c, &c->FC32_INVI, c->nv));
@@ -525,7 +534,8 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->JB[2], c->JB[3], c->JB[4], c->Y,
                       c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->STEP_PART, c->RED, c->STAGE, c->RCOEF,
-                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI, c->LIGHT, c->UPR, c->YLIN,
+                      c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI,
+                      c->FB_INV, c->FCB_INVR, c->FCB_INVI, c->FB_TAB, c->FCB_TABR, c->FCB_TABI, c->LIGHT, c->UPR, c->YLIN,
                       c->SMSREC, c->RESTREC};
     for (double* b : bufs)
         if (b) (void)hipFree(b);

@@ -30,6 +30,12 @@
 #define NK2D_MAX_E 8
 #define NK2D_OWN_REC_CAP 65536   /* rows of the context's own schedule record */
 
+struct nk2d_plane_job {
+    double times[3];   // stage times of the next attempt
+    int jstage;        // stage whose plane its Jacobian derives from (-1: none due)
+    int done;
+};
+
 struct nk2d_ctx {
     nk2d_desc d;
     int nz, ny, tc, E, nzp, ncol, nreg;
@@ -93,6 +99,15 @@ struct nk2d_ctx {
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
     double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
     double *FR_TAB, *FC_TABR, *FC_TABI;   // ncol * NK2D_TAB * 64 each
+    // second set: the launch that ends a frozen step writes the NEXT step's factorisation here while its own sweep reads
+    // the current one (PreFactor in nk2d_kernels.hip; option "prefactor"); prefactored: the current set holds the
+    // tables for the shifts pre_c*, computed ahead of the integrator's "LU" event
+    double *FB_INV, *FCB_INVR, *FCB_INVI, *FB_TAB, *FCB_TABR, *FCB_TABI;
+    int prefactor, prefactored;
+    double pre_cre, pre_ccr, pre_cci;
+    // the next attempt's planes, to ride on the next Newton-iteration launch that does not factorise (set by the replay
+    // around the launches of a frozen step; k_newton_fused_pl)
+    struct nk2d_plane_job* plane_job;
     // single precision copies for the fused Newton launches: the line factorisation is an approximate
     // inverse inside an iteration that re-evaluates the exact residual, its storage precision only
     // touches the contraction rate (nk2d_set_option "factor_fp32")
@@ -537,7 +552,8 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
                          double x0, double x1, double x2, int jac_stage = -1, bool with_tend = true);
 int nk2d_r_rows_sum(nk2d_ctx* c, const double* rows, int64_t nrows, double* out);
 int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
-                        const double* times, double x0, double x1, double x2, int jac_stage);
+                        const double* times, double x0, double x1, double x2, int jac_stage, bool planes_done = false,
+                        const double* next_shifts = nullptr);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 int nk2d_prof_window_begin(nk2d_ctx* c);

@@ -516,17 +516,13 @@ __device__ __forceinline__ void jac_body(const DevP& P, const double* __restrict
     jac_core<E, MP>(P, kv, kvp, JL, JU, JS, JN, JC, ylin, UPR, task, lane);
 }
 
-// the same from a vertical mixing column held in registers (kvp: its bundle in memory, read only for the source plane of
-// a forced module with a thresholded sink)
-template <int E, int MP = 0>
-__device__ __forceinline__ void jac_core(const DevP& P, const double (&kv)[E], const double* __restrict__ kvp,
-                                         double* __restrict__ JL, double* __restrict__ JU, double* __restrict__ JS,
-                                         double* __restrict__ JN, double* __restrict__ JC, const double* __restrict__ ylin,
-                                         double* __restrict__ UPR, int task, int lane) {
-    const int j = task;
+// the five Jacobian diagonals of ypos column j (tracer independent part) from its vertical mixing column, in registers
+template <int E>
+__device__ __forceinline__ void jac_cols(const DevP& P, const double (&kv)[E], int j, int lane, double (&up)[E],
+                                         double (&dn)[E], double (&so)[E], double (&no)[E], double (&ce)[E]) {
     ColCoef<E> cf;
     load_coef<E>(P, j, lane, cf);
-    double kvprev[E], up[E], dn[E], so[E], no[E], ce[E];
+    double kvprev[E];
     shift_prev<E>(kv, kvprev, lane, 0.0);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -549,6 +545,18 @@ __device__ __forceinline__ void jac_core(const DevP& P, const double (&kv)[E], c
         no[e] = a_n + h_n;
         ce[e] = (a_c + h_c) + v_c;
     }
+}
+
+// the same from a vertical mixing column held in registers (kvp: its bundle in memory, read only for the source plane of
+// a forced module with a thresholded sink)
+template <int E, int MP = 0>
+__device__ __forceinline__ void jac_core(const DevP& P, const double (&kv)[E], const double* __restrict__ kvp,
+                                         double* __restrict__ JL, double* __restrict__ JU, double* __restrict__ JS,
+                                         double* __restrict__ JN, double* __restrict__ JC, const double* __restrict__ ylin,
+                                         double* __restrict__ UPR, int task, int lane) {
+    const int j = task;
+    double up[E], dn[E], so[E], no[E], ce[E];
+    jac_cols<E>(P, kv, j, lane, up, dn, so, no, ce);
     store_col<E, MP>(JL, j, lane, up);
     store_col<E, MP>(JU, j, lane, dn);
     store_col<E, MP>(JS, j, lane, so);
@@ -676,11 +684,10 @@ __device__ __forceinline__ void line_offdiag(const DevP& P, int tr, int lane, co
 
 // real part of the diagonal of the column tridiagonal: shift - JC + module terms; identity rows
 // past the column end
-template <int E, int KIND, int MP = 0>
-__device__ __forceinline__ void line_diag(const DevP& P, const double* __restrict__ JC, int tr, int j, int lane,
-                                          double shift_re, double (&dre)[E]) {
-    double jc[E], upr[E], dzr[E];
-    load_col<E, MP>(JC, j, lane, jc);
+template <int E, int KIND>
+__device__ __forceinline__ void line_diag_from(const DevP& P, const double (&jc)[E], int tr, int j, int lane,
+                                               double shift_re, double (&dre)[E]) {
+    double upr[E], dzr[E];
     if constexpr (KIND == 1) {
         load_col<E>(P.UPR, j, lane, upr);
         load_col<E>(P.DZR, 0, lane, dzr);
@@ -699,6 +706,13 @@ __device__ __forceinline__ void line_diag(const DevP& P, const double* __restric
         }
         dre[e] = (k < P.nz) ? d : 1.0;
     }
+}
+template <int E, int KIND, int MP = 0>
+__device__ __forceinline__ void line_diag(const DevP& P, const double* __restrict__ JC, int tr, int j, int lane,
+                                          double shift_re, double (&dre)[E]) {
+    double jc[E];
+    load_col<E, MP>(JC, j, lane, jc);
+    line_diag_from<E, KIND>(P, jc, tr, j, lane, shift_re, dre);
 }
 
 // coupling between the tracers of the phosphorus module, kept on the right-hand side of the
@@ -766,8 +780,7 @@ __global__ void k_jac_apply(DevP P, SweepArgs A, const double* __restrict__ v, d
 // pivots and PCR tables of every column's tridiagonal T_j = tridiag(-JL, c - JC + extra, -JU)
 // for the real and/or the complex shift; one launch per SciPy "LU" event
 template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
-    TASK_PROLOGUE(A.ntasks)
+__device__ __forceinline__ void factor_body(const DevP& P, const SweepArgs& A, int task, int lane) {
     // the (system, tracer) variants of one ypos column sit in adjacent waves of a block, so
     // that their identical Jacobian-plane loads hit in the CU's L1
     const int nvar = A.ntasks / P.ny, j = task / nvar, var = task - j * nvar;
@@ -812,6 +825,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
             store_tab32(A.fc_tabi32, col, lane, tim);
         }
     }
+}
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
+    TASK_PROLOGUE(A.ntasks)
+    factor_body<E, KIND>(P, A, task, lane);
 }
 
 template <int E, int KIND, int MP = 0>
@@ -1553,9 +1572,51 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A
     newton_fused_body<E, KIND, FACTOR, STAGE, 0>(P, A, task, lane);
 }
 
-// the launch that ends a frozen step (FinalArgs): column workgroups first, then the workgroups of the next attempt's planes
+// Work of the NEXT step that depends on time alone, hidden behind the column waves of this step's launches (a frozen
+// year knows every step ahead; the launches without the factorisation hold 232 registers, so a second wave fits on
+// every SIMD beside the 832 column waves of a 416^2 launch):
+//   * its mixing planes at the three stage times and the Jacobian planes derived from one of them ride on the first
+//     launch of this step that does not factorise (k_newton_fused_pl; the exp of a mixing column is a 5 us chain);
+//   * its line factorisation -- pivots and PCR tables of both systems of every column, from those Jacobian planes -- on
+//     the launch that ends this step (PreFactor tasks of k_newton_final, the work of k_factor), into the second set of
+//     factor buffers.
+// The next step then opens with the launch that LOADS its factorisation instead of the factorising instantiation (303
+// registers, one wave per SIMD, 22.9 us instead of 16.5 us at 416^2).  Where the planes could not ride ahead (a step of
+// one launch) the final launch computes them as before and the next step factorises for itself.
+struct PreFactor {
+    int mode;        // 0: plane tasks behind the columns (the round-2 launch); 1: nothing; 2: factor tasks (planes done earlier)
+    SweepArgs sa;    // Jacobian planes of the next step, its shifts, the second set of factor buffers
+};
+
+// one (stage time, ypos column) task of the next attempt's planes; the plane the Jacobian derives from comes first
+template <int E>
+__device__ __forceinline__ void plane_task(const DevP& P, const VmixArgs& V, const JacOut& J, int ptask, int lane) {
+    int ti = ptask / P.ny;
+    const int j = ptask - ti * P.ny;
+    if (J.stage > 0) ti = (ti == 0) ? J.stage : ((ti <= J.stage) ? ti - 1 : ti);
+    double kv[E];
+    vmix_body_kv<E>(P, V, ti * P.ny + j, lane, kv);
+    if (ti == J.stage) jac_core<E, 0>(P, kv, V.out[ti], J.JL, J.JU, J.JS, J.JN, J.JC, nullptr, nullptr, j, lane);
+}
+
+// a Newton-iteration launch without the factorisation, with the plane tasks of the next attempt behind its columns
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused_pl(DevP P, FusedArgs A, int nblk_cols, VmixArgs V, JacOut J) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if ((int)blockIdx.x < nblk_cols) {
+        const int task = blockIdx.x * wpb + wave;
+        if (task < P.ncol) newton_fused_body<E, KIND, 0, 1, 0>(P, A, task, lane);
+        return;
+    }
+    const int ptask = (blockIdx.x - nblk_cols) * wpb + wave;
+    if (ptask < P.ny * 3) plane_task<E>(P, V, J, ptask, lane);
+}
+
+// the launch that ends a frozen step (FinalArgs): column workgroups first, then the workgroups of the next attempt's
+// planes or of its line factorisation (PreFactor)
 template <int E, int KIND, int FACTOR, int STAGE>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J) {
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J, PreFactor F) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     if ((int)blockIdx.x < Fin.nblk_cols) {
@@ -1563,13 +1624,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A
         if (task < P.ncol) newton_fused_body<E, KIND, FACTOR, STAGE, 0, 1>(P, A, task, lane, &Fin);
         return;
     }
-    const int task = (blockIdx.x - Fin.nblk_cols) * wpb + wave;
-    if (task < P.ny * 3) {
-        double kv[E];
-        vmix_body_kv<E>(P, V, task, lane, kv);
-        const int ti = task / P.ny;
-        if (ti == J.stage)
-            jac_core<E, 0>(P, kv, V.out[ti], J.JL, J.JU, J.JS, J.JN, J.JC, nullptr, nullptr, task - ti * P.ny, lane);
+    const int ptask = (blockIdx.x - Fin.nblk_cols) * wpb + wave;
+    if (F.mode == 0) {
+        if (ptask < P.ny * 3) plane_task<E>(P, V, J, ptask, lane);
+    } else if (F.mode == 2) {
+        if (ptask < F.sa.ntasks) factor_body<E, KIND>(P, F.sa, ptask, lane);
     }
 }
 
@@ -2618,7 +2677,31 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
             c->win_bytes += 8.0 * words;
         }
     }
-    NK2D_TRY(launch_fused(c, P, A, do_factor, do_stage));
+    nk2d_plane_job* job = c->plane_job;
+    if (job && !job->done && !do_factor && c->team == 0 && c->kind != 1 && !c->xcd_map && P.guard == nullptr) {
+        // the next attempt's planes behind this launch's columns (k_newton_fused_pl; see PreFactor)
+        VmixArgs V;
+        for (int i = 0; i < 3; ++i) {
+            nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, job->times[i], &V.frac[i]);
+            V.out[i] = c->KVN[i];
+        }
+        V.frac[3] = 0.0; V.out[3] = nullptr;
+        vmix_forcing_args(c, 3, job->times, V);
+        V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
+        V.hw = c->d.vmix_half_width;
+        JacOut J = {c->JB[0], c->JB[1], c->JB[2], c->JB[3], c->JB[4], job->jstage};
+        const int nblk_cols = nk2d_grid(c->ncol);
+        const dim3 grid(nblk_cols + nk2d_grid(c->ny * 3));
+        if (c->kind == 2) {
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused_pl<EE, 2>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, nblk_cols, V, J));
+        } else {
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused_pl<EE, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, nblk_cols, V, J));
+        }
+        NK2D_CHECK(c, hipGetLastError());
+        job->done = 1;
+    } else {
+        NK2D_TRY(launch_fused(c, P, A, do_factor, do_stage));
+    }
     if (swap_z) std::swap(c->Z, c->ZN);
     c->st.nlaunch++;
     c->st.nsweeps++;
@@ -2630,7 +2713,8 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
 // are swapped into their new roles here: Y <-> YOLD, Z <-> ZN (when this launch also evaluated the stages), the stage
 // planes and -- when derived -- the Jacobian planes with their second sets.
 int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
-                        const double* times, double x0, double x1, double x2, int jac_stage) {
+                        const double* times, double x0, double x1, double x2, int jac_stage, bool planes_done,
+                        const double* next_shifts) {
     if (c->kind == 1) return nk2d_fail(c, "nk2d_r_newton_final: not for modules whose Jacobian reads the state");
     FusedArgs A;
     fill_fused_args(c, A, do_stage, first, true, mreal, mcr, mci, src, delta);
@@ -2665,14 +2749,31 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
         c->sweep_launches++;
         c->fused_bytes_all += 8.0 * words;
     }
-    const dim3 grid(Fin.nblk_cols + nk2d_grid(c->ny * 3));
+    // planes_done: an earlier launch of this step already computed the next attempt's planes (k_newton_fused_pl); this
+    // launch then carries that attempt's line factorisation instead, when its shifts are known and its Jacobian is new
+    PreFactor F = {};
+    F.mode = planes_done ? 1 : 0;
+    const bool prefactor = planes_done && next_shifts != nullptr && jac_stage >= 0;
+    if (prefactor) {
+        F.mode = 2;
+        F.sa.JL = c->JB[0]; F.sa.JU = c->JB[1]; F.sa.JS = c->JB[2]; F.sa.JN = c->JB[3]; F.sa.JC = c->JB[4];
+        F.sa.cre = next_shifts[0]; F.sa.ccr = next_shifts[1]; F.sa.cci = next_shifts[2];
+        F.sa.fr_inv = c->FB_INV; F.sa.fc_invr = c->FCB_INVR; F.sa.fc_invi = c->FCB_INVI;
+        F.sa.fr_tab = c->FB_TAB; F.sa.fc_tabr = c->FCB_TABR; F.sa.fc_tabi = c->FCB_TABI;
+        F.sa.f32 = 0;
+        F.sa.nreal = c->ncol;
+        F.sa.ntasks = 2 * c->ncol;
+        const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
+        c->fused_bytes_all += 8.0 * (3.0 * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N);     // planes read, tables written
+    }
+    const dim3 grid(Fin.nblk_cols + (F.mode == 0 ? nk2d_grid(c->ny * 3) : (F.mode == 2 ? nk2d_grid(2 * c->ncol) : 0)));
 #define NK2D_FINAL_LAUNCH(KK)                                                                                              \
     if (do_factor) {                                                                                                       \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 1, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 1, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J, F)); \
     } else if (do_stage) {                                                                                                 \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J, F)); \
     } else {                                                                                                               \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A, Fin, V, J, F)); \
     }
     if (c->team == 2) {
         Fin.nblk_cols = c->ncol;
@@ -2696,6 +2797,14 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     if (jac_stage >= 0) {
         std::swap(c->JL, c->JB[0]); std::swap(c->JU, c->JB[1]); std::swap(c->JS, c->JB[2]);
         std::swap(c->JN, c->JB[3]); std::swap(c->JC, c->JB[4]);
+    }
+    c->prefactored = 0;
+    if (prefactor) {
+        // the tables of the step that begins now: the integrator's next "LU" event with these shifts finds them in place
+        std::swap(c->FR_INV, c->FB_INV); std::swap(c->FC_INVR, c->FCB_INVR); std::swap(c->FC_INVI, c->FCB_INVI);
+        std::swap(c->FR_TAB, c->FB_TAB); std::swap(c->FC_TABR, c->FCB_TABR); std::swap(c->FC_TABI, c->FCB_TABI);
+        c->prefactored = 1;
+        c->pre_cre = F.sa.cre; c->pre_ccr = F.sa.ccr; c->pre_cci = F.sa.cci;
     }
     c->st.nlaunch++;
     c->st.nsweeps++;

@@ -73,8 +73,8 @@ class DevVec:
     def __del__(self):
         eng, ptr = self.eng, self.ptr
         self.ptr = None
-        if ptr is not None and eng is not None and eng._ctx is not None:
-            eng._lib.nk2d_vec_free(eng._ctx, ptr)
+        if ptr is not None and eng is not None and eng._handle is not None:
+            eng._lib.nk2d_vec_free(eng._handle, ptr)
 
     def to_host(self):
         return self.eng.download(self)
@@ -94,7 +94,7 @@ class ModuleEngine:
                  lin_tol=None, module_kind=0, phos_params=None, light_lim=None,
                  restore_series=None, sms_series=None, sink_thres=None):
         self._lib = _lib.load()
-        self._ctx = None
+        self._handle = None
         self.grid = grid
         self.nz = len(grid.depth)
         self.ny = len(grid.ypos)
@@ -158,7 +158,7 @@ class ModuleEngine:
             if ctx:
                 self._lib.nk2d_destroy(ctx)
             raise Nk2dError(f"nk2d_create failed ({rc}): {msg}")
-        self._ctx = ctx
+        self._handle = ctx
         self.device_ctl = 0
         self._precond_ready = False
         if "NK2D_DEVICE_CTL" in os.environ:
@@ -169,10 +169,17 @@ class ModuleEngine:
         self.set_option("growth_cap", float(os.environ.get("NK2D_GROWTH_CAP", DEFAULT_GROWTH_CAP)))
         self.set_option("jac_stage", float(os.environ.get("NK2D_JAC_STAGE", DEFAULT_JAC_STAGE)))
 
+    @property
+    def _ctx(self):
+        """the library context; a closed engine raises instead of handing NULL to the C ABI"""
+        if self._handle is None:
+            raise Nk2dError("this engine is closed (ModelState.reset_class / ModuleEngine.close)")
+        return self._handle
+
     def close(self):
-        if self._ctx is not None:
-            self._lib.nk2d_destroy(self._ctx)
-            self._ctx = None
+        if self._handle is not None:
+            self._lib.nk2d_destroy(self._handle)
+            self._handle = None
 
     def __del__(self):
         try:

@@ -3,7 +3,8 @@
 
 Run ONLY in the build container (needs /root/reference):
 
-    python tests/golden/gen_ref_traces.py [krylov|newton|all]
+    python tests/golden/gen_ref_traces.py [krylov|newton|all] [n]      (n x n grid: 26 (default), 30 = the grid of
+                                                                        scripts/ci_py_driver_2d_iage.sh:13-14, 52)
 
 It runs, in this process and with the I/O stand-ins of tests/ref_harness/shims.py (netCDF4 / xarray / pint are
 absent from the image; none of them is on the arithmetic path), exactly what the reference's CI scripts run:
@@ -19,6 +20,9 @@ logs (with the work directory spelled $workdir).
   newton : the reference's default tolerances, Newton run to convergence       -> newton_trace_26x26.npz
 
 Fixtures are data (inputs + the reference's outputs); no reference source text is stored.
+
+Run with OMP_NUM_THREADS=1 (the 30 x 30 and 52 x 52 fixtures were): SciPy's Radau is not bit-reproducible across BLAS thread
+counts, and tests/test_ref_traces.py replays the traces bit for bit under one BLAS thread.
 """
 import json
 import os
@@ -101,8 +105,7 @@ def collect_krylov(kdir, workdir):
     return out, state["step_log"]
 
 
-def gen(kind):
-    n = 26
+def gen(kind, n=26):
     workdir = tempfile.mkdtemp(prefix=f"ref_{kind}_")
     over = {"krylov": {"krylov_rel_tol": "2.0e-4", "newton_max_iter": "1"}, "newton": {}}[kind]
     ended = run_reference(workdir, n, over)
@@ -137,5 +140,6 @@ def gen(kind):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 26
     for kind in (("krylov", "newton") if what == "all" else (what,)):
-        gen(kind)
+        gen(kind, size)

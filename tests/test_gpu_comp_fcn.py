@@ -195,7 +195,7 @@ def test_default_mode_schedule_replayed_by_the_oracle(nz, ny, vv, kh):
     assert np.allclose(eng.download(fx).reshape(-1), want, rtol=1e-6, atol=1e-8)
 
 
-@pytest.mark.parametrize("nz,ny,vv,kh", [(20, 3, 0.0, 0.0), (26, 26, 0.1, 1000.0)])
+@pytest.mark.parametrize("nz,ny,vv,kh", [(20, 3, 0.0, 0.0), (26, 26, 0.1, 1000.0), (52, 52, 0.1, 1000.0)])
 def test_frozen_product_against_the_oracle(nz, ny, vv, kh):
     """the finite-difference product on frozen years, device against CPU oracle: both difference two years on the SAME
     recorded steps (the oracle with SciPy's sparse LU), sigma as the reference takes it"""
@@ -217,7 +217,13 @@ def test_frozen_product_against_the_oracle(nz, ny, vv, kh):
     w, sigma, stp = eng.jvp(x, fx, vd, sched=sched)
     assert eng.frozen_fallbacks() == 0 and stp["nrejected"] == 0
     rows = [(r[0], r[1], r[2], int(r[3]), r[4], r[5]) for r in sched]
-    f0 = radau.comp_fcn(tm, x0.reshape(-1), replay=rows)
-    f1 = radau.comp_fcn(tm, (x0 + sigma[0] * v).reshape(-1), replay=rows)
+    # the two CPU replays side by side (SuperLU releases the GIL; at 52 x 52 each takes two minutes on the GPU box's host)
+    from concurrent.futures import ThreadPoolExecutor
+
+    _, tm2 = oracle_iage(nz, ny, vv, kh)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        job0 = pool.submit(radau.comp_fcn, tm, x0.reshape(-1), replay=rows)
+        job1 = pool.submit(radau.comp_fcn, tm2, (x0 + sigma[0] * v).reshape(-1), replay=rows)
+        f0, f1 = job0.result(), job1.result()
     w_oracle = (f1 - f0) / sigma[0]
     assert rel_err(eng.download(w).reshape(-1), w_oracle) < 2e-3
