@@ -64,7 +64,11 @@ typedef void* nk2d_vec;
 
 #define NK2D_MAX_TRACERS 4
 #define NK2D_MAX_SHIFTS 4
-#define NK2D_SCHED_WIDTH 6 /* doubles per accepted step: t, t_new, h, n_newton, t_jac, h_lu */
+/* doubles per accepted step of a schedule: t, t_new, h, n_newton, t_jac, h_lu, err, fingerprint.
+   err: the error-estimate norm the step was accepted with (0 in a schedule from elsewhere);
+   fingerprint: nk2d_schedule_fingerprint of the context that recorded the step (0: a schedule from elsewhere, e.g.
+   SciPy's steps for the step-replay parity tests -- never checked) */
+#define NK2D_SCHED_WIDTH 8
 
 typedef struct nk2d_desc {
     int32_t nz;            /* depth levels */
@@ -128,6 +132,9 @@ typedef struct nk2d_stats {
     int64_t nsweeps;               /* line-relaxation sweeps (kernel launches) */
     int64_t nlaunch;               /* total kernel launches */
     double seconds;                /* host wall time of the call */
+    int64_t nresumed;              /* frozen year: times it was resumed from a checkpoint with one more Newton iteration */
+    int64_t nerr_checked;          /* frozen year: steps whose error estimate was evaluated (option "frozen_err_check") */
+    double max_err;                /* ... and the largest of them (SciPy accepts a step at <= 1) */
 } nk2d_stats;
 
 int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out);
@@ -185,9 +192,21 @@ int nk2d_comp_fcn_frozen(nk2d_ctx* ctx, nk2d_vec x, nk2d_vec fx, nk2d_stats* sta
 int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n);
 /* A frozen year checks afterwards, for every step, SciPy's Newton convergence test on the last recorded iteration
    (with a slack of 30) -- the norm partials of those iterations are kept, one reduction launch and one read-back per year.
-   A state for which the recorded counts are not enough makes nk2d_comp_fcn_frozen return -7; nk2d_jvp then runs a
-   free-running year instead.  n: how often that has happened on this context. */
+   Where the recorded count is not enough for the state given, the year is RESUMED from the checkpoint before the first
+   such step (the state is kept every 128 steps) with one more Newton iteration there, at most twice; a year that still
+   fails -- or a step already at SciPy's six iterations -- makes nk2d_comp_fcn_frozen return -7, and nk2d_jvp then runs a
+   free-running year instead.  Option "frozen_err_check" k > 0 (default 32) also evaluates SciPy's error estimate on
+   every k-th step of a frozen year (one launch each, plus the tendency at the step start): a step whose estimate
+   exceeds 1.5 * max(1, recorded estimate) returns -7 as well.  A schedule whose fingerprint is not this context's
+   (other options, grid or library build) is refused with -8 before anything runs.
+   nk2d_frozen_fallbacks: how often a frozen year was given up (-7) on this context; nk2d_frozen_resumes: how often one was
+   resumed. */
 int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
+int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
+/* hash of everything a recorded schedule depends on besides the state: grid, module description, tolerances, the
+   controller options (jac_fresh, jac_stage, lin_tol, min_sweeps, growth_cap, factor storage) and the library version;
+   an integer below 2^52, never 0 */
+int nk2d_schedule_fingerprint(nk2d_ctx* ctx, double* out);
 /* accepted steps of the most recent free-running year of this context (whichever entry point ran it: nk2d_comp_fcn,
    nk2d_comp_fcn_hist, the perturbed year of a free-running nk2d_jvp): n rows of NK2D_SCHED_WIDTH doubles; out may be
    NULL to ask for n only */

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libnk2d.so")
 
 MAX_TRACERS = 4
-SCHED_WIDTH = 6
+SCHED_WIDTH = 8
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -75,6 +75,9 @@ class Stats(ctypes.Structure):
         ("nsweeps", ctypes.c_int64),
         ("nlaunch", ctypes.c_int64),
         ("seconds", ctypes.c_double),
+        ("nresumed", ctypes.c_int64),
+        ("nerr_checked", ctypes.c_int64),
+        ("max_err", ctypes.c_double),
     ]
 
     def as_dict(self):
@@ -114,6 +117,8 @@ SIGNATURES = {
     "nk2d_set_frozen_schedule": (_ci, [_vp, c_double_p, _i64]),
     "nk2d_last_schedule": (_ci, [_vp, c_double_p, _i64, c_int64_p]),
     "nk2d_frozen_fallbacks": (_ci, [_vp, c_int64_p]),
+    "nk2d_frozen_resumes": (_ci, [_vp, c_int64_p]),
+    "nk2d_schedule_fingerprint": (_ci, [_vp, c_double_p]),
     "nk2d_comp_fcn_hist": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), _i32, c_double_p, c_double_p]),
     "nk2d_precond_setup": (_ci, [_vp]),
     "nk2d_precond_setup_states": (_ci, [_vp, ctypes.POINTER(_vp)]),

@@ -133,6 +133,11 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
     if (key == "prefactor") { c->prefactor = value != 0.0; return 0; }
+    if (key == "frozen_err_check") {
+        if (!(value >= 0.0) || value > 1.0e6) return nk2d_fail(c, "nk2d_set_option: frozen_err_check must be 0 (off) or a step stride");
+        c->frozen_err_check = (int)value;
+        return 0;
+    }
     if (key == "jac_stage_state") { c->jac_stage_state = value != 0.0; return 0; }
     if (key == "jac_stage") {
         if (value != -1.0 && value != 0.0 && value != 1.0 && value != 2.0) return nk2d_fail(c, "nk2d_set_option: jac_stage must be -1, 0, 1 or 2");
@@ -282,6 +287,29 @@ extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, 
     return 0;
 }
 
+// FNV-1a over raw bytes
+static uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+template <class T>
+static uint64_t fnv_val(uint64_t h, const T& v) { return fnv1a(h, &v, sizeof(T)); }
+
+// everything a recorded schedule depends on besides the state (nk2d_schedule_fingerprint): the grid and module
+// description hashed at create, the tolerances, the controller options and the library version
+double nk2d_fingerprint(const nk2d_ctx* c) {
+    uint64_t h = c->grid_hash;
+    const char* ver = nk2d_version();
+    h = fnv1a(h, ver, std::strlen(ver));
+    h = fnv_val(h, c->d.rtol); h = fnv_val(h, c->d.atol); h = fnv_val(h, c->d.max_step_frac);
+    h = fnv_val(h, c->d.t0); h = fnv_val(h, c->d.t1); h = fnv_val(h, c->d.lin_tol);
+    h = fnv_val(h, c->jac_fresh); h = fnv_val(h, c->jac_stage); h = fnv_val(h, c->jac_stage_state);
+    h = fnv_val(h, c->min_sweeps); h = fnv_val(h, c->growth_cap); h = fnv_val(h, c->factor_fp32);
+    h &= (1ull << 52) - 1;
+    return (double)(h ? h : 1ull);
+}
+
 static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->d = *desc;
     c->nz = desc->nz; c->ny = desc->ny; c->tc = desc->tc;
@@ -322,6 +350,37 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int nz = c->nz, ny = c->ny;
+    {
+        uint64_t h = 14695981039346656037ull;
+        h = fnv_val(h, c->nz); h = fnv_val(h, c->ny); h = fnv_val(h, c->tc); h = fnv_val(h, c->kind);
+        h = fnv1a(h, desc->depth_edges, sizeof(double) * (nz + 1));
+        h = fnv1a(h, desc->ypos_edges, sizeof(double) * (ny + 1));
+        h = fnv1a(h, desc->vvel, sizeof(double) * (size_t)nz * (ny + 1));
+        h = fnv1a(h, desc->wvel, sizeof(double) * (size_t)(nz + 1) * ny);
+        if (ny > 1) h = fnv1a(h, desc->hmix_coeff, sizeof(double) * (size_t)nz * (ny - 1));
+        h = fnv1a(h, desc->bldepth_max, sizeof(double) * ny);
+        h = fnv_val(h, desc->bldepth_min); h = fnv1a(h, desc->bld_tvals, sizeof(desc->bld_tvals));
+        h = fnv1a(h, desc->bld_fvals, sizeof(desc->bld_fvals));
+        h = fnv_val(h, desc->vmix_log_shallow); h = fnv_val(h, desc->vmix_log_deep); h = fnv_val(h, desc->vmix_half_width);
+        h = fnv1a(h, desc->surf_rate, sizeof(desc->surf_rate)); h = fnv1a(h, desc->surf_target, sizeof(desc->surf_target));
+        h = fnv1a(h, desc->decay_rate, sizeof(desc->decay_rate)); h = fnv_val(h, desc->const_src);
+        if (c->kind == 1) {
+            h = fnv1a(h, desc->phos_params, sizeof(desc->phos_params));
+            h = fnv1a(h, desc->light_lim, sizeof(double) * (size_t)nz * ny);
+        }
+        if (c->kind == 2) {
+            h = fnv_val(h, c->d.restore_nrec); h = fnv_val(h, c->d.sms_nrec); h = fnv_val(h, c->d.sink_thres);
+            if (c->d.restore_nrec > 0) {
+                h = fnv1a(h, desc->restore_times, sizeof(double) * c->d.restore_nrec);
+                h = fnv1a(h, desc->restore_vals, sizeof(double) * (size_t)c->d.restore_nrec * ny);
+            }
+            if (c->d.sms_nrec > 0) {
+                h = fnv1a(h, desc->sms_times, sizeof(double) * c->d.sms_nrec);
+                h = fnv1a(h, desc->sms_vals, sizeof(double) * (size_t)c->d.sms_nrec * nz * ny);
+            }
+        }
+        c->grid_hash = h;
+    }
     // ---- packed static planes
     NK2D_TRY(dev_alloc(c, &c->VV, (size_t)(ny + 1) * c->nzp));
     NK2D_TRY(dev_alloc(c, &c->KH, (size_t)(ny + 1) * c->nzp));
@@ -383,7 +442,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->FB_TAB, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FCB_TABR, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FCB_TABI, (size_t)c->ncol * 14 * 64));
-    c->prefactor = 1;
+    c->prefactor = 0;   // measured neutral at best (profiles/r03_prefactor): an option for A/B runs
     c->prefactored = 0;
     NK2D_TRY(dev_alloc(c, &c->FR32_INV, c->nv));
     NK2D_TRY(dev_alloc(c, &c->FC32_INVR, c->nv));
@@ -396,8 +455,10 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->TMP2, c->nv));
     NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol));
     NK2D_TRY(dev_alloc(c, &c->PART2, (size_t)c->ncol));
-    NK2D_TRY(dev_alloc(c, &c->STEP_NORM, (size_t)2 * NK2D_OWN_REC_CAP));
+    NK2D_TRY(dev_alloc(c, &c->STEP_NORM, (size_t)3 * NK2D_OWN_REC_CAP));
     c->frozen_fallbacks = 0;
+    c->frozen_resumes = 0;
+    c->frozen_err_check = 32;
     c->STEP_PART = nullptr;
     c->step_part_rows = 0;
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
@@ -542,6 +603,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     delete[] c->sms_t;
     delete[] c->rest_t;
     for (double* b : c->vec_pool) (void)hipFree(b);
+    for (double* b : c->ckpt) (void)hipFree(b);
     float* fbufs[] = {c->FR32_INV, c->FC32_INVR, c->FC32_INVI, c->FR32_TAB, c->FC32_TABR, c->FC32_TABI};
     for (float* b : fbufs)
         if (b) (void)hipFree(b);
@@ -809,6 +871,16 @@ extern "C" int nk2d_comp_fcn_frozen(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_s
 
 extern "C" int nk2d_frozen_fallbacks(nk2d_ctx* c, int64_t* n) {
     if (n) *n = c->frozen_fallbacks;
+    return 0;
+}
+
+extern "C" int nk2d_frozen_resumes(nk2d_ctx* c, int64_t* n) {
+    if (n) *n = c->frozen_resumes;
+    return 0;
+}
+
+extern "C" int nk2d_schedule_fingerprint(nk2d_ctx* c, double* out) {
+    if (out) *out = nk2d_fingerprint(c);
     return 0;
 }
 

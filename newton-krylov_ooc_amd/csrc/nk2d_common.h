@@ -29,6 +29,7 @@
 #define NK2D_BLOCK (NK2D_WAVE * NK2D_WAVES_PER_BLOCK)
 #define NK2D_MAX_E 8
 #define NK2D_OWN_REC_CAP 65536   /* rows of the context's own schedule record */
+#define NK2D_CKPT_EVERY 128      /* steps between two checkpoints of a frozen year */
 
 struct nk2d_plane_job {
     double times[3];   // stage times of the next attempt
@@ -132,8 +133,13 @@ struct nk2d_ctx {
     double* PART2;   // second buffer [ncol]
     double* STEP_PART;      // frozen year: norm partials of the last two Newton iterations of every step, rows of ncol
     size_t step_part_rows;  // rows allocated
-    double* STEP_NORM;  // [2 * NK2D_OWN_REC_CAP] per step of a frozen year: sum((dW/scale)^2) of its last and last-but-one iteration
+    double* STEP_NORM;  // [3 * NK2D_OWN_REC_CAP] per step of a frozen year: sum((dW/scale)^2) of its last and last-but-one iteration, sum((err/scale)^2)
     int64_t frozen_fallbacks;   // frozen years rejected by the a-posteriori Newton check (nk2d_frozen_fallbacks)
+    int64_t frozen_resumes;     // ... and resumed from a checkpoint with one more Newton iteration (nk2d_frozen_resumes)
+    int frozen_err_check;       // k > 0: SciPy's error estimate on every k-th step of a frozen year (option "frozen_err_check")
+    uint64_t grid_hash;         // hash of the grid / module description given to nk2d_create (nk2d_fingerprint)
+    // state kept every NK2D_CKPT_EVERY steps of a frozen year (Y, YOLD, ZP: 5 nv doubles each) for the resume
+    std::vector<double*> ckpt;
     double* RED;     // reduced scalars (device)
     double* hRED;    // pinned host mirror
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
@@ -556,6 +562,7 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
                         const double* next_shifts = nullptr);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
+double nk2d_fingerprint(const nk2d_ctx* c);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);

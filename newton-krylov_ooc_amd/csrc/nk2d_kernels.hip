@@ -2999,6 +2999,7 @@ struct YearArgs {
     int* abort_flag;
     double* out;               // [32]: status, t, counters, swap parities, bytes
     double* record;            // accepted steps [cap][NK2D_SCHED_WIDTH] or null
+    double fingerprint;        // of the context (recorded with every step)
     long long record_cap;
 };
 
@@ -3428,6 +3429,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
         if (A.record && nrec < A.record_cap && wave == 0 && lane == 0) {
             double* r = A.record + (size_t)nrec * NK2D_SCHED_WIDTH;
             r[0] = t; r[1] = t_new; r[2] = h; r[3] = (double)n_iter; r[4] = t_jac; r[5] = h_lu_used;
+            r[6] = err; r[7] = A.fingerprint;
         }
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
@@ -3584,6 +3586,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     A.out = c->YR_OUT;
     A.record = record ? c->YR_REC : nullptr;
     A.record_cap = record ? record_cap : 0;
+    A.fingerprint = nk2d_fingerprint(c);
     DevP P = make_devp(c);
     P.guard = nullptr;
     void* args[2] = {&P, &A};

@@ -216,11 +216,12 @@ extern "C" int nk2d_jvp(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_vec v, nk2d_v
     if (!c->frozen_sched.empty()) {
         rc = nk2d_radau_year(c, xp, fp, stats, c->frozen_sched.data(),
                              (int64_t)(c->frozen_sched.size() / NK2D_SCHED_WIDTH), nullptr, 0, nullptr, true);
-        // -7: the recorded iteration counts do not converge for the perturbed state -- a free-running year instead
-        // (counted, nk2d_frozen_fallbacks); not with a norm hook, where every shard would have to fall back together
-        if (rc != 0 && (rc != -7 || c->norm_hook)) return rc;
+        // -7: the recorded iteration counts do not converge for the perturbed state even after the resumes, or its error
+        // estimates are out of bounds; -8: the schedule is not this context's (fingerprint) -- a free-running year instead
+        // (-7 counted, nk2d_frozen_fallbacks); not with a norm hook, where every shard would have to fall back together
+        if (rc != 0 && ((rc != -7 && rc != -8) || c->norm_hook)) return rc;
     }
-    if (rc == -7) NK2D_TRY(nk2d_radau_year(c, xp, fp, stats, nullptr, 0, nullptr, 0, nullptr));
+    if (rc == -7 || rc == -8) NK2D_TRY(nk2d_radau_year(c, xp, fp, stats, nullptr, 0, nullptr, 0, nullptr));
     // (perturb_fcn - fcn) / sigma (:523)
     NK2D_TRY(nk2d_diff_scale(c, w, fp, fx, rsig.data()));
     if (sigma_out) std::memcpy(sigma_out, sigma.data(), sizeof(double) * nreg);

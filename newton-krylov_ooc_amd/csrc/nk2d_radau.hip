@@ -20,6 +20,7 @@
 // schedule -> y(T); see tests/test_gpu_comp_fcn.py.
 #include "nk2d_common.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -51,6 +52,7 @@ struct Ctl {
     bool pre_setup;
     bool pre_jac;        // ... and so was the Jacobian of that attempt (option "jac_stage")
     double pre_t, pre_h;
+    double fingerprint;  // nk2d_fingerprint of the context at the start of the year (recorded with every step)
 };
 
 double rms_from_sum(double s, double count) { return std::sqrt(s) / std::sqrt(count); }
@@ -588,6 +590,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         if (record && nrec < record_cap) {
             double* r = record + nrec * NK2D_SCHED_WIDTH;
             r[0] = t; r[1] = t_new; r[2] = h; r[3] = (double)n_iter; r[4] = s.t_jac; r[5] = h_lu_used;
+            r[6] = err; r[7] = s.fingerprint;
         }
         ++nrec;
         // y_new, f_new = fun(t_new, y_new)
@@ -676,20 +679,28 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
 // free-running loop: step boundary (commit + planes + predicted stage values + Jacobian of the next row) and fused
 // Newton iterations; a row whose Jacobian time is a stage time of its own attempt takes the Jacobian from that
 // stage's plane, as the free run with option "jac_stage" does.
-int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
-    nk2d_ctx* c = s.c;
-    if (check_newton && n > NK2D_OWN_REC_CAP) return nk2d_fail(c, "nk2d_comp_fcn_frozen: schedule too long", -4);
-    if (check_newton && c->step_part_rows < (size_t)(2 * n)) {
-        // norm partials of the last two Newton iterations of every step, one row of ncol each
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-        if (c->STEP_PART) NK2D_CHECK(c, hipFree(c->STEP_PART));
-        c->STEP_PART = nullptr;
-        c->step_part_rows = 0;
-        NK2D_CHECK(c, hipMalloc((void**)&c->STEP_PART, sizeof(double) * (size_t)(2 * n) * c->ncol));
-        c->step_part_rows = (size_t)(2 * n);
-    }
+//
+// A frozen year (check = true: a schedule this library recorded, replayed for another state) additionally
+//   * keeps the norm partials of the last two Newton iterations of every step (rows of STEP_PART) for the check after
+//     the year, and -- every err_every-th step -- evaluates SciPy's error estimate (a third row);
+//   * keeps the state every NK2D_CKPT_EVERY steps (Y, YOLD, ZP), so that a year whose recorded Newton iteration count
+//     turns out not to be enough at some step can be resumed from the checkpoint before it (run_frozen).
+struct ReplayLocal {
     double h_lu_cur = 0.0;
     bool have = false;
+    int pre_jstage = -1;     // stage whose Jacobian the boundary launch of the row before derived for this row
+    bool kv3_at_t = true;    // KV[3] holds the mixing plane at the current t (year start; after a boundary launch)
+    bool f_at_t = true;      // F holds the tendency at the current (t, y) (year start; after a boundary launch with it)
+    std::vector<char>* err_done = nullptr;   // per row: its error estimate was evaluated in this pass
+};
+
+// steps whose error estimate a frozen year evaluates
+inline bool err_checked(const nk2d_ctx* c, bool check, int64_t i) {
+    return check && c->frozen_err_check > 0 && (i % c->frozen_err_check) == 0;
+}
+
+int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, ReplayLocal& L) {
+    nk2d_ctx* c = s.c;
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
     const bool fast = s.device_ctl == 0 && c->hist_n == 0;
     // stage of the attempt (t, h) whose time is t_jac, or -1
@@ -699,13 +710,25 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             if (t_jac == t + (h * RC[k])) return k;
         return -1;
     };
-    int pre_jstage = -1;       // stage whose Jacobian the boundary launch of the row before derived for this row
-    bool kv3_at_t = true;      // KV[3] holds the mixing plane at the current t (year start; after a boundary launch)
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = i0; i < n; ++i) {
         const double* r = sched + i * NK2D_SCHED_WIDTH;
         const double t = r[0], t_new = r[1], h = r[2], t_jac = r[4], h_lu = r[5];
         const int n_iter = (int)r[3];
         if (t != s.t) return nk2d_fail(c, "nk2d_comp_fcn: replay schedule does not start where the state is", -5);
+        if (check && fast && (i % NK2D_CKPT_EVERY) == 0) {
+            // checkpoint: the row before ended in a boundary launch of its own (below), so Y, YOLD and ZP are what a
+            // restart needs (state, and the collocation polynomial of the last step for the predicted stage values)
+            const size_t slot = (size_t)(i / NK2D_CKPT_EVERY);
+            while (c->ckpt.size() <= slot) {
+                double* buf = nullptr;
+                NK2D_CHECK(c, hipMalloc((void**)&buf, sizeof(double) * 5 * c->nv));
+                c->ckpt.push_back(buf);
+            }
+            double* buf = c->ckpt[slot];
+            NK2D_CHECK(c, hipMemcpyAsync(buf, c->Y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(buf + c->nv, c->YOLD, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(buf + 2 * c->nv, c->ZP, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, c->stream));
+        }
         // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
         // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
         if (t_jac != s.t_jac && t_jac != t && needs_state && stage_of(t, h, t_jac) < 0)
@@ -715,7 +738,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         const int jstage_inlaunch = needs_state ? -1 : jstage;    // a Jacobian that reads the state: a launch of its own
         if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
             predicted = true;
-            jac_done = jstage_inlaunch >= 0 && pre_jstage == jstage_inlaunch;
+            jac_done = jstage_inlaunch >= 0 && L.pre_jstage == jstage_inlaunch;
         } else if (fast && s.have_dense) {
             NK2D_TRY(setup_attempt(s, t, h, jstage_inlaunch));
             predicted = true;
@@ -724,21 +747,26 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             NK2D_TRY(stage_planes(s, t, h));
         }
         s.pre_setup = false;
-        pre_jstage = -1;
+        L.pre_jstage = -1;
         if (t_jac != s.t_jac) {
             if (jstage >= 0) {
                 if (!jac_done) NK2D_TRY(nk2d_k_jac(c, c->KV[jstage], needs_state ? c->Y : nullptr));
                 s.t_jac = t_jac;
             } else {
-                NK2D_TRY(refresh_jac(s, t_jac, t_jac == t && kv3_at_t));   // the plane at t is at hand after a boundary launch
+                NK2D_TRY(refresh_jac(s, t_jac, t_jac == t && L.kv3_at_t));   // the plane at t is at hand after a boundary launch
             }
             c->st.njev++;
-            have = false;
+            L.have = false;
         }
-        if (!have || h_lu != h_lu_cur) { NK2D_TRY(set_lu(s, h_lu)); h_lu_cur = h_lu; have = true; }
+        if (!L.have || h_lu != L.h_lu_cur) { NK2D_TRY(set_lu(s, h_lu)); L.h_lu_cur = h_lu; L.have = true; }
         if (!predicted) NK2D_TRY(predict(s, t, h));
-        double* row_last = check_newton ? c->STEP_PART + (size_t)(2 * i) * c->ncol : nullptr;
-        double* row_prev = check_newton ? c->STEP_PART + (size_t)(2 * i + 1) * c->ncol : nullptr;
+        double* row_last = check ? c->STEP_PART + (size_t)(3 * i) * c->ncol : nullptr;
+        double* row_prev = check ? c->STEP_PART + (size_t)(3 * i + 1) * c->ncol : nullptr;
+        double* row_err = check ? c->STEP_PART + (size_t)(3 * i + 2) * c->ncol : nullptr;
+        // the error estimate of this step (frozen year, every err_every-th step): needs the tendency at the step start
+        // and the stage values in memory, i.e. neither this step nor the one before may end in a final launch
+        const bool want_err = err_checked(c, check, i) && fast && L.f_at_t && s.m_real <= 2 && n_iter >= 1;
+        const bool next_err = err_checked(c, check, i + 1) && fast;
         // With a next row that starts where this one ends, its planes, predicted stage values and (where its Jacobian
         // time is the step start or one of its stage times) its Jacobian are computed before this step is left:
         const double* r2 = (i + 1 < n) ? r + NK2D_SCHED_WIDTH : nullptr;
@@ -758,8 +786,11 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
             }
         }
         // ... in the launch that ends the last Newton iteration (nk2d_r_newton_final) where the Jacobian does not read
-        // the state and no Jacobian at t_new is due; otherwise in a step boundary launch of its own
-        const bool final_fused = chained && !needs_state && !jac_at_tnew && n_iter >= 1 && c->final_fuse;
+        // the state and no Jacobian at t_new is due; otherwise in a step boundary launch of its own (also before a
+        // checkpoint and around a step whose error estimate is evaluated)
+        const bool ckpt_next = check && ((i + 1) % NK2D_CKPT_EVERY) == 0;
+        const bool final_fused = chained && !needs_state && !jac_at_tnew && n_iter >= 1 && c->final_fuse && !ckpt_next &&
+                                 !want_err && !next_err;
         if (final_fused) {
             // the next row's planes ride on the first launch of this step that does not factorise, its line
             // factorisation on the launch that ends the step (PreFactor in nk2d_kernels.hip)
@@ -793,30 +824,39 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         } else {
             NK2D_TRY(newton_fixed(s, h, 0, n_iter, n_iter, row_last, row_prev));
         }
+        if (want_err) {
+            int buf = 0;
+            NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf, row_err));
+            c->st.nerr_checked++;
+            if (L.err_done) (*L.err_done)[(size_t)i] = 1;
+        }
         if (chained) {
             if (!final_fused) {
                 double* out[3] = {c->KV[0], c->KV[1], c->KV[3]};
-                NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_at_tnew, times, out, x[0], x[1], x[2], jstage2, false));
+                NK2D_TRY(nk2d_r_step_boundary(c, c->KV[2], jac_at_tnew, times, out, x[0], x[1], x[2], jstage2, next_err));
+                if (next_err) c->st.nfev++;
                 std::swap(c->KV[3], c->KV[2]);
                 std::swap(c->Y, c->YOLD);
                 std::swap(c->Z, c->ZP);
             }
-            kv3_at_t = !final_fused;
+            L.kv3_at_t = !final_fused;
+            L.f_at_t = !final_fused && next_err;
             s.have_dense = true;
             s.dense_t_old = t;
             s.dense_h = t_new - t;
             s.t = t_new;
             c->st.nsteps++;
             s.pre_setup = true; s.pre_t = t_new; s.pre_h = h2;
-            pre_jstage = jstage2;
+            L.pre_jstage = jstage2;
             if (jac_at_tnew) {
                 s.t_jac = t_new;
                 c->st.njev++;
-                have = false;
+                L.have = false;
             }
         } else {
             NK2D_TRY(commit_step(s, t, t_new));
-            kv3_at_t = false;
+            L.kv3_at_t = false;
+            L.f_at_t = false;
         }
         // nothing is read back during a replay: bound the depth of the launch queue (a year is 10^4 launches; the
         // counter-collecting profiler of this ROCm falls over behind a few thousand unsynchronised dispatches, as it
@@ -824,24 +864,82 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
         // and a drain every 64 steps costs forty hand-overs a year
         if ((i & 63) == 63) NK2D_CHECK(c, hipStreamSynchronize(c->stream));
     }
-    if (check_newton && n > 0) {
+    return 0;
+}
+
+int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
+    nk2d_ctx* c = s.c;
+    if (!check) {
+        ReplayLocal L;
+        return replay_rows(s, sched, n, 0, false, L);
+    }
+    // ---- a frozen year ------------------------------------------------------------------------------------------------
+    if (n > NK2D_OWN_REC_CAP) return nk2d_fail(c, "nk2d_comp_fcn_frozen: schedule too long", -4);
+    // the schedule must be this context's own, recorded under the options it has now: anything else is not the discrete
+    // map the caller is differentiating (a side file from another run, an option changed in between)
+    for (int64_t i = 0; i < n; ++i)
+        if (sched[i * NK2D_SCHED_WIDTH + 7] != s.fingerprint)
+            return nk2d_fail(c, "nk2d_comp_fcn_frozen: the schedule was recorded under other options, another grid or another "
+                                "build of the library (fingerprint of step " + std::to_string(i) + ")", -8);
+    if (c->step_part_rows < (size_t)(3 * n)) {
+        // norm partials of the last two Newton iterations and of the error estimate of every step, one row of ncol each
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->STEP_PART) NK2D_CHECK(c, hipFree(c->STEP_PART));
+        c->STEP_PART = nullptr;
+        c->step_part_rows = 0;
+        NK2D_CHECK(c, hipMalloc((void**)&c->STEP_PART, sizeof(double) * (size_t)(3 * n) * c->ncol));
+        c->step_part_rows = (size_t)(3 * n);
+    }
+    std::vector<double> mine;            // the schedule with the iteration counts a resume has raised
+    const double* cur = sched;
+    std::vector<double> sums((size_t)3 * n);
+    const double slack = 30.0;
+    // a sharded module (norm hook) checks its own tracers against their own count: nothing is exchanged, and if
+    // every shard passes so does the module
+    const bool hooked = c->norm_hook != nullptr;
+    const double n_unknowns = hooked ? (double)c->tc * c->nz * c->ny : s.n_total;
+    int64_t start = 0;
+    std::vector<char> err_done((size_t)n, 0);
+    for (int round = 0;; ++round) {
+        ReplayLocal L;
+        L.err_done = &err_done;
+        std::fill(err_done.begin() + start, err_done.end(), 0);
+        if (round > 0) {
+            // resume at row `start` (a multiple of NK2D_CKPT_EVERY): state and collocation polynomial from the checkpoint;
+            // planes, predicted stage values, Jacobian and factorisation are recomputed by the launches of a first row
+            const double* buf = c->ckpt[(size_t)(start / NK2D_CKPT_EVERY)];
+            NK2D_CHECK(c, hipMemcpyAsync(c->Y, buf, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(c->YOLD, buf + c->nv, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(c->ZP, buf + 2 * c->nv, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            const double* r = cur + start * NK2D_SCHED_WIDTH;
+            s.t = r[0];
+            s.have_dense = start > 0;
+            if (start > 0) {
+                const double* rp = r - NK2D_SCHED_WIDTH;
+                s.dense_t_old = rp[0];
+                s.dense_h = rp[1] - rp[0];
+            }
+            s.pre_setup = false;
+            s.t_jac = std::numeric_limits<double>::quiet_NaN();    // whatever Jacobian is in place is not this row's
+            L.kv3_at_t = false;
+            L.f_at_t = false;
+        }
+        NK2D_TRY(replay_rows(s, cur, n, start, true, L));
         // SciPy's convergence test (radau.py:120-129) on what the LAST recorded iteration of every step left, with
         // slack: the perturbed state of a finite-difference product converges like the state the schedule was
         // recorded for, give or take; a state that does not (the recorded year converged at once on a special
         // structure, say) must not be integrated with its iteration counts
-        std::vector<double> sums((size_t)2 * n);
-        NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART, 2 * n, c->STEP_NORM));
-        NK2D_CHECK(c, hipMemcpyAsync(sums.data(), c->STEP_NORM, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+        NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART + (size_t)(3 * start) * c->ncol, 3 * (n - start), c->STEP_NORM));
+        NK2D_CHECK(c, hipMemcpyAsync(sums.data() + 3 * start, c->STEP_NORM, sizeof(double) * 3 * (n - start),
+                                     hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-        const double slack = 30.0;
-        // a sharded module (norm hook) checks its own tracers against their own count: nothing is exchanged, and if
-        // every shard passes so does the module
-        const bool hooked = c->norm_hook != nullptr;
-        const double n_unknowns = hooked ? (double)c->tc * c->nz * c->ny : s.n_total;
-        for (int64_t i = 0; i < n; ++i) {
-            if ((int)sched[i * NK2D_SCHED_WIDTH + 3] < 1) continue;
-            const double s_last = sums[2 * i];
-            const double s_prev = ((int)sched[i * NK2D_SCHED_WIDTH + 3] >= 2) ? sums[2 * i + 1] : -1.0;
+        int64_t bad = -1;
+        std::string why;
+        for (int64_t i = start; i < n && bad < 0; ++i) {
+            const int n_it = (int)cur[i * NK2D_SCHED_WIDTH + 3];
+            if (n_it < 1) continue;
+            const double s_last = sums[3 * i];
+            const double s_prev = (n_it >= 2) ? sums[3 * i + 1] : -1.0;
             const double n_last = rms_from_sum(s_last, 3.0 * n_unknowns);
             bool ok = n_last == n_last;
             if (ok && n_last != 0.0) {
@@ -853,14 +951,48 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check_newton) {
                     ok = n_last < slack * s.newton_tol;   // one iteration: the recorded year's first correction vanished
                 }
             }
-            if (!ok) {
-                c->frozen_fallbacks++;
-                return nk2d_fail(c, "nk2d_comp_fcn_frozen: the recorded Newton iteration counts do not converge for this state "
-                                    "(step " + std::to_string(i) + " of " + std::to_string(n) + ")", -7);
-            }
+            if (!ok) { bad = i; why = "the recorded Newton iteration count does not converge for this state"; }
         }
+        // the sampled error estimates (not with a norm hook: a shard sees only its own tracers' share)
+        double max_err = 0.0;
+        int64_t bad_err = -1;
+        if (!hooked)
+            for (int64_t i = start; i < n; ++i) {
+                if (bad >= 0 && i >= bad) break;       // beyond a step that did not converge the state means nothing
+                if (!err_done[(size_t)i]) continue;
+                const double err = rms_from_sum(sums[3 * i + 2], n_unknowns);
+                if (!(err == err)) { bad_err = i; break; }
+                max_err = std::max(max_err, err);
+                const double base = cur[i * NK2D_SCHED_WIDTH + 6];
+                if (err > 1.5 * std::max(1.0, base) && bad_err < 0) bad_err = i;
+            }
+        c->st.max_err = std::max(c->st.max_err, max_err);
+        if (bad_err >= 0) {
+            c->frozen_fallbacks++;
+            return nk2d_fail(c, "nk2d_comp_fcn_frozen: the error estimate of step " + std::to_string(bad_err) + " of " +
+                                std::to_string(n) + " exceeds what the recorded step was accepted with: the recorded steps "
+                                "do not control the error for this state", -7);
+        }
+        if (bad < 0) return 0;
+        // one more Newton iteration at the first step that did not converge, from the checkpoint before it -- where that
+        // can be done (host-launched replay, SciPy's cap of six iterations, two resumes per year)
+        const int n_it = (int)cur[bad * NK2D_SCHED_WIDTH + 3];
+        const bool can = s.device_ctl == 0 && c->hist_n == 0 && round < 2 && n_it < NEWTON_MAXITER &&
+                         c->ckpt.size() > (size_t)(bad / NK2D_CKPT_EVERY);
+        if (!can) {
+            c->frozen_fallbacks++;
+            return nk2d_fail(c, "nk2d_comp_fcn_frozen: " + why + " (step " + std::to_string(bad) + " of " + std::to_string(n) +
+                                (round > 0 ? ", after " + std::to_string(round) + " resume(s)" : "") + ")", -7);
+        }
+        if (mine.empty()) { mine.assign(sched, sched + (size_t)n * NK2D_SCHED_WIDTH); cur = mine.data(); }
+        mine[(size_t)bad * NK2D_SCHED_WIDTH + 3] = (double)(n_it + 1);
+        start = (bad / NK2D_CKPT_EVERY) * NK2D_CKPT_EVERY;
+        // a checkpoint is a place to resume only if its row computes its own Jacobian (the default mode: every row does; a
+        // SciPy-mode schedule may carry one over from an earlier step, whose state is gone)
+        while (start > 0 && cur[start * NK2D_SCHED_WIDTH + 4] == cur[(start - 1) * NK2D_SCHED_WIDTH + 4]) start -= NK2D_CKPT_EVERY;
+        c->frozen_resumes++;
+        c->st.nresumed++;
     }
-    return 0;
 }
 
 }  // namespace
@@ -893,6 +1025,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     if (c->norm_hook && c->device_ctl != 0 && c->device_ctl != 3 && !replay)
         return nk2d_fail(c, "nk2d_comp_fcn: a norm hook (sharded tracer module) needs host-side decisions (device_ctl 0)");
     s.newton_tol = std::max(10 * std::numeric_limits<double>::epsilon() / c->d.rtol, std::min(0.03, std::sqrt(c->d.rtol)));
+    s.fingerprint = nk2d_fingerprint(c);
     s.has_old_h = s.has_old_err = false;
     s.h_abs_old = s.err_old = 0;
     s.have_lu = false; s.have_dense = false;

@@ -57,8 +57,26 @@ class Nk2dFrozenMismatch(Nk2dError):
     """a frozen year (comp_fcn_frozen) whose recorded Newton iteration counts do not converge for the state given"""
 
 
+class Nk2dScheduleMismatch(Nk2dError):
+    """a frozen year asked to repeat a schedule that was recorded under other options, another grid or another build of
+    the library (its fingerprint is not this engine's)"""
+
+
 def _dp(arr):
     return arr.ctypes.data_as(_lib.c_double_p)
+
+
+def sched_rows(sched):
+    """a schedule as [n, SCHED_WIDTH] rows.  Rows from elsewhere -- the oracle's / SciPy's accepted steps (t, t_new, h,
+    n_newton, t_jac, h_lu) -- are padded with err = 0 and fingerprint = 0 (never checked; only step-replay mode takes them)"""
+    sched = np.asarray(sched, dtype=np.float64)
+    if sched.ndim != 2:
+        raise ValueError(f"a schedule is a 2-d array of rows with 6 or {_lib.SCHED_WIDTH} columns")
+    if sched.shape[1] == 6:
+        sched = np.concatenate((sched, np.zeros((sched.shape[0], _lib.SCHED_WIDTH - 6))), axis=1)
+    if sched.shape[1] != _lib.SCHED_WIDTH:
+        raise ValueError(f"schedule rows must have 6 or {_lib.SCHED_WIDTH} columns")
+    return np.ascontiguousarray(sched)
 
 
 class DevVec:
@@ -190,6 +208,8 @@ class ModuleEngine:
     def _chk(self, rc):
         if rc == -7:
             raise Nk2dFrozenMismatch(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
+        if rc == -8:
+            raise Nk2dScheduleMismatch(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
         if rc != 0:
             raise Nk2dError(f"nk2d call failed ({rc}): {self._lib.nk2d_last_error(self._ctx).decode()}")
 
@@ -277,7 +297,7 @@ class ModuleEngine:
         stats = _lib.Stats()
         rp, rn = None, 0
         if replay is not None:
-            replay = np.ascontiguousarray(replay, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+            replay = sched_rows(replay)
             rp, rn = _dp(replay), replay.shape[0]
         rec, recn = None, ctypes.c_int64(0)
         if record:
@@ -295,7 +315,7 @@ class ModuleEngine:
         (fx, stats dict)."""
         out = self.new_vec() if out is None else out
         stats = _lib.Stats()
-        sched = np.ascontiguousarray(sched, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+        sched = sched_rows(sched)
         self._chk(self._lib.nk2d_comp_fcn_frozen(self._ctx, x.ptr, out.ptr, ctypes.byref(stats), _dp(sched),
                                                  sched.shape[0]))
         return out, stats.as_dict()
@@ -315,12 +335,24 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_frozen_fallbacks(self._ctx, ctypes.byref(n)))
         return n.value
 
+    def frozen_resumes(self):
+        """how many frozen years of this engine were resumed from a checkpoint with one more Newton iteration so far"""
+        n = ctypes.c_int64(0)
+        self._chk(self._lib.nk2d_frozen_resumes(self._ctx, ctypes.byref(n)))
+        return n.value
+
+    def schedule_fingerprint(self):
+        """what the steps this engine records now are stamped with (grid, module, tolerances, controller options, build)"""
+        out = ctypes.c_double(0.0)
+        self._chk(self._lib.nk2d_schedule_fingerprint(self._ctx, ctypes.byref(out)))
+        return out.value
+
     def set_frozen_schedule(self, sched):
         """the schedule the perturbed years of jvp / gmres_solve repeat from now on (None: free-running years)"""
         if sched is None:
             self._chk(self._lib.nk2d_set_frozen_schedule(self._ctx, None, 0))
             return
-        sched = np.ascontiguousarray(sched, dtype=np.float64).reshape(-1, _lib.SCHED_WIDTH)
+        sched = sched_rows(sched)
         self._chk(self._lib.nk2d_set_frozen_schedule(self._ctx, _dp(sched), sched.shape[0]))
 
     # ---- sampled timing of the dominant kernel ----------------------------------------

@@ -24,7 +24,8 @@ import numpy as np
 
 from . import hist as hist_mod
 from . import ncio
-from .engine import PHOSPHORUS_PARAM_NAMES, Nk2dFrozenMismatch, forced_engine, iage_engine, phosphorus_engine
+from .engine import (PHOSPHORUS_PARAM_NAMES, Nk2dFrozenMismatch, Nk2dScheduleMismatch, forced_engine, iage_engine,
+                     phosphorus_engine)
 from .limiter import scalef_for_bound
 from .grid import Grid2d, SpatialAxis
 
@@ -47,6 +48,14 @@ def _class_name(obj):
 # side file of a comp_fcn result: the accepted Radau steps of the year that produced it, per tracer module (what the
 # perturbed years of the finite-difference products around that result repeat); not part of the reference's file set
 SCHED_SUFFIX = ".sched.npz"
+_CRC_PREFIX = "__crc__"
+
+
+def _crc(host):
+    """checksum of a module's values as they are written to / read from the state file"""
+    import zlib
+
+    return zlib.crc32(np.ascontiguousarray(host, dtype=np.float64).tobytes())
 
 
 class TracerModuleState:
@@ -204,6 +213,7 @@ class ModelState:
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
     _precond_state = {}     # precond file -> {module name: linearisation field}
     last_stats = None       # stats of the most recent comp_fcn, per module
+    last_jvp_mode = None    # "frozen" / "free_running": how the most recent finite-difference product ran its perturbed year
 
     # ---- class-level set-up (py_driver_2d/model_state.py:44-65) -----------------------
     @classmethod
@@ -259,20 +269,30 @@ class ModelState:
             return
         cached = self._resident.get(os.path.abspath(fname)) if isinstance(fname, str) else None
         # the accepted steps of the forward year that produced this file, if it is the result of one (comp_fcn):
-        # remembered by name in this process, and kept next to the file for a resumed run
+        # remembered by name in this process (dump() forgets them when the name is written again), and kept next to the
+        # file for a resumed run -- with a checksum of the values they belong to, verified against what the file holds now
+        side = None
         if isinstance(fname, str):
             self._sched = self._sched_by_name.get(os.path.abspath(fname))
-            if self._sched is None and os.path.exists(fname + SCHED_SUFFIX):
+            if self._sched is None and cached is None and os.path.exists(fname + SCHED_SUFFIX):
                 with np.load(fname + SCHED_SUFFIX) as data:
-                    self._sched = {key: data[key] for key in data.files}
+                    side = {key: data[key] for key in data.files}
         for ind, name in enumerate(names):
             module_def = cfg.tracer_module_defs[name]
             eng = self._engines[name]
             if cached is not None:
                 vec = cached[ind].copy()
             else:
-                vec = eng.upload(self._load_host(fname, module_def, eng))
+                host = self._load_host(fname, module_def, eng)
+                if side is not None and int(side.get(_CRC_PREFIX + name, -1)) != _crc(host):
+                    logging.getLogger(__name__).warning(
+                        "%s: the schedule side file does not belong to these values (checksum of %s) -- ignored",
+                        fname, name)
+                    side = None
+                vec = eng.upload(host)
             self.tracer_modules[ind] = TracerModuleState(name, module_def, eng, vec)
+        if side is not None:
+            self._sched = {key: val for key, val in side.items() if not key.startswith(_CRC_PREFIX)}
 
     def _load_host(self, fname, module_def, eng):
         """(tc, nz, ny) host values of one module from a file or pseudo-file
@@ -321,6 +341,10 @@ class ModelState:
         # file read.  Oldest snapshots are dropped beyond RESIDENT_MAX whether or not the files are
         # written: the cache is bounded (a Krylov solve re-opens only names of its own iteration range).
         cache = self._resident
+        # whatever schedule was known under this name belonged to the values it held before
+        self._sched_by_name.pop(os.path.abspath(fname), None)
+        if self.write_files and os.path.exists(fname + SCHED_SUFFIX):
+            os.remove(fname + SCHED_SUFFIX)
         cache.pop(os.path.abspath(fname), None)
         cache[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
         while len(cache) > self.RESIDENT_MAX:
@@ -468,8 +492,9 @@ class ModelState:
                 try:
                     fx, st = tms.eng.comp_fcn_frozen(tms.vec, frozen[tms.name])
                     return fx, st, None
-                except Nk2dFrozenMismatch as msg:
-                    # the recorded Newton iteration counts are not enough for this state: a free-running year
+                except (Nk2dFrozenMismatch, Nk2dScheduleMismatch) as msg:
+                    # the recorded Newton iteration counts are not enough for this state even after the resumes, its error
+                    # estimates are out of bounds, or the schedule is not this engine's: a free-running year
                     logger.warning("%s: %s -- free-running year instead", tms.name, msg)
             if hist_fname is None:
                 return tms.eng.comp_fcn(tms.vec)
@@ -510,18 +535,18 @@ class ModelState:
         type(self).last_stats = stats
         res_ms = self._new(mods)
         res_ms._sched = scheds if frozen is None else None
+        # zero_extra_tracers: no shadow tracers in the py_driver_2d modules handled here;
+        # apply_region_mask is fused into the kernel that forms y(T) - x
+        caller = f"{_class_name(self)}.comp_fcn_postprocess called from {_class_name(self)}.comp_fcn"
+        res_ms.dump(res_fname, caller)       # (forgets any schedule known under this name)
         if res_fname is not None and res_ms._sched:
             by_name = type(self)._sched_by_name
-            by_name.pop(os.path.abspath(res_fname), None)
             by_name[os.path.abspath(res_fname)] = res_ms._sched
             while len(by_name) > self.RESIDENT_MAX:
                 by_name.pop(next(iter(by_name)))
             if self.write_files:
-                np.savez(res_fname + SCHED_SUFFIX[:-4], **res_ms._sched)
-        # zero_extra_tracers: no shadow tracers in the py_driver_2d modules handled here;
-        # apply_region_mask is fused into the kernel that forms y(T) - x
-        caller = f"{_class_name(self)}.comp_fcn_postprocess called from {_class_name(self)}.comp_fcn"
-        res_ms.dump(res_fname, caller)
+                crcs = {_CRC_PREFIX + tms.name: np.int64(_crc(tms.get_tracer_vals_all())) for tms in res_ms.tracer_modules}
+                np.savez(res_fname + SCHED_SUFFIX[:-4], **res_ms._sched, **crcs)
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
             modelinfo = self.model_config_obj.modelinfo
@@ -677,6 +702,10 @@ class ModelState:
         # difference of their discretisation errors over sigma is 5 ... 90 % of the product (DESIGN.md section 3c,
         # tools/probe_jvp_noise.py).  NK2D_JVP_FROZEN=0, or an `fcn` read back from a file, gives free-running years.
         frozen = getattr(fcn, "_sched", None) if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else None
+        mode = ("frozen controller: the perturbed year repeats the accepted steps of the year behind F(x)" if frozen
+                else "two free-running years (the reference's product)")
+        logger.info("comp_jacobian_fcn_state_prod mode: %s", mode)
+        type(self).last_jvp_mode = "frozen" if frozen else "free_running"
         perturb_fcn = perturb_ms.comp_fcn(perturb_fcn_fname, solver_state, frozen=frozen or None)
         caller = f"{_class_name(self)}.comp_jacobian_fcn_state_prod"
         res = ((perturb_fcn - fcn) / sigma).dump(res_fname, caller)
