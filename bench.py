@@ -114,7 +114,9 @@ def cpu_baseline(grid_n, gpu_attempts_per_year, budget_s):
         "cores": 1,
         "kind": "port",
         "sample": f"oracle (NumPy+SciPy SuperLU Radau restatement) on iage {grid_n}x{grid_n}: {how}; "
-                  "one JVP = one forward year; preconditioner and Arnoldi cost ignored",
+                  "one JVP = one forward year; preconditioner and Arnoldi cost ignored; the cost of an attempt is the two "
+                  "SuperLU factorisations of the year's Jacobian pattern (the same at any step size), so the first attempts "
+                  "are representative and, Newton iterations being fewest on the short first steps, a LOWER bound",
     }
 
 
@@ -163,6 +165,195 @@ class Workload:
 
         ModelState.reset_class()
         shutil.rmtree(self.workdir, ignore_errors=True)
+
+
+MIX_NAMES = ["iage", "phosphorus", "forced_dye"]
+MIX_CFG_NAMES = {"iage": "iage", "phosphorus": "phosphorus", "forced_dye": "forced_{suff}:dye"}
+MIX_DECAY = {"forced_surf_restore_opt": "none", "forced_sms_opt": "decay", "forced_sms_decay_rate": "1.0e-8"}
+
+
+class MixWorkload:
+    """BASELINE.json configs[3]: the three tracer modules of py_driver_2d together -- iage, phosphorus and the decay variant
+    of forced (py_driver_2d's analogue of dye_decay) -- or the subset of them a rank holds; set up as the Newton solver
+    calls the Krylov solver: F(x) from a year with history (the phosphorus preconditioner is made from it), products on
+    the accepted steps of that year, every module an engine (HIP stream) of its own on the rank's GPU"""
+
+    def __init__(self, n, names, device_ordinal, tag):
+        import numpy as np
+
+        from nk_ooc_amd.model_config import ModelConfig
+        from nk_ooc_amd.model_state import ModelState
+        from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config
+
+        self.n, self.names = n, list(names)
+        self.workdir = tempfile.mkdtemp(prefix=f"nk2d_mix_{tag}_")
+        self.cfg = make_config(self.workdir, n, n, tracer_module_names=",".join(MIX_CFG_NAMES[m] for m in names),
+                               extra_modelinfo=MIX_DECAY, extra_solverinfo={"krylov_rel_tol": "0.0"})
+        gen_grid_vars_file(self.cfg["modelinfo"])
+        ModelState.reset_class()
+        ModelState.device_map = {m: device_ordinal for m in names}
+        ModelState.write_files = False          # a 0.5 GB history file per year at 416 x 416: this leg times the path
+        ModelState.model_config_obj = ModelConfig(self.cfg["modelinfo"])
+        self.iterate = ModelState("gen_init_iterate")
+        for tms in self.iterate.tracer_modules:
+            if tms.name == "forced_dye":
+                # the initial iterate of the module is exactly uniform; give it structure (DESIGN.md section 5)
+                rng = np.random.default_rng(3)
+                bump = np.cumsum(np.cumsum(rng.standard_normal((1, n, n)), axis=1), axis=2)
+                tms.eng.upload(1.0 + 0.3 * bump / np.max(np.abs(bump)), out=tms.vec)
+        self.hist_fname = os.path.join(self.workdir, "hist_00.nc")
+        self.fcn = self.iterate.comp_fcn(os.path.join(self.workdir, "fcn_00.nc"), None, self.hist_fname)
+        self.base_stats = {tms.name: st for tms, st in zip(self.iterate.tracer_modules, ModelState.last_stats)}
+
+    def krylov(self, k_iters, tag, device, group=None):
+        from nk_ooc_amd import dist as nkdist
+
+        solverinfo = dict(self.cfg["solverinfo"])
+        solverinfo["krylov_workdir"] = os.path.join(self.workdir, tag)
+        solverinfo["krylov_max_iter"] = str(k_iters)
+        solver = nkdist.DistributedKrylovSolver(self.iterate, solverinfo, resume=False, rewind=False,
+                                                hist_fname=self.hist_fname, device=device, group=group)
+        solver.solve(os.path.join(self.workdir, f"increment_{tag}.nc"), self.fcn)
+        return solver
+
+    def sync(self):
+        for tms in self.iterate.tracer_modules:
+            tms.eng.sync()
+
+    def counters(self):
+        return {tms.name: {"frozen_years_rejected": tms.eng.frozen_fallbacks(), "frozen_years_resumed": tms.eng.frozen_resumes()}
+                for tms in self.iterate.tracer_modules}
+
+    def close(self):
+        from nk_ooc_amd.model_state import ModelState
+
+        ModelState.reset_class()
+        ModelState.device_map = None
+        ModelState.write_files = True
+        shutil.rmtree(self.workdir, ignore_errors=True)
+
+
+def run_config4_mix(args, rank, local_rank, world, device):
+    """the three-module mix timed (i) on ONE GPU, its three forward years running concurrently on three streams, and, for
+    N >= 2, (ii) with the modules dealt round-robin to min(N, 3) ranks (dist.partition_modules; the one collective is the
+    all-reduce of the convergence flag per Krylov iteration): the strong-scaling figure of the line -- the same work on
+    more GPUs -- next to the weak one of `value`"""
+    import torch
+
+    from nk_ooc_amd import dist as nkdist
+
+    n = args.mix_grid or args.grid
+    k = args.mix_steps
+    out = {"what": "BASELINE.json configs[3]: iage + phosphorus + forced (decay) through KrylovSolver, products on frozen years, "
+                   "no file trail (ModelState.write_files False)",
+           "grid": [n, n], "modules": MIX_NAMES, "krylov_iterations": k}
+
+    def timed(wl, tag, group=None, nranks=1):
+        wl.krylov(1, f"{tag}_warm", device, group)
+        wl.sync()
+        if nranks > 1:
+            torch.distributed.barrier(group=group)
+        t0 = time.perf_counter()
+        wl.krylov(k, f"{tag}_timed", device, group)
+        wl.sync()
+        if nranks > 1:
+            torch.distributed.barrier(group=group)
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if nranks > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX, group=group)
+        return float(el.item())
+
+    if rank == 0:
+        wl = MixWorkload(n, MIX_NAMES, local_rank, "one")
+        try:
+            t_one = timed(wl, "one")
+            out["one_gpu"] = {"ms_per_krylov_iteration": 1000.0 * t_one / k, "module_jvps_per_s": len(MIX_NAMES) * k / t_one,
+                              "base_year_seconds": {m: st["seconds"] for m, st in wl.base_stats.items()},
+                              "counters": wl.counters()}
+        finally:
+            wl.close()
+    if world >= 2:
+        used = min(world, len(MIX_NAMES))
+        group = torch.distributed.new_group(list(range(used)))
+        parts = nkdist.partition_modules(MIX_NAMES, used)
+        torch.distributed.barrier()
+        if rank < used:
+            wl = MixWorkload(n, parts[rank], local_rank, f"r{rank}")
+            try:
+                t_dist = timed(wl, f"dist{rank}", group, used)
+            finally:
+                wl.close()
+            if rank == 0:
+                out["distributed"] = {"ranks_used": used, "layout": {f"rank{r}": parts[r] for r in range(used)},
+                                      "ms_per_krylov_iteration": 1000.0 * t_dist / k,
+                                      "module_jvps_per_s": len(MIX_NAMES) * k / t_dist,
+                                      "speedup_over_one_gpu": out["one_gpu"]["ms_per_krylov_iteration"] / (1000.0 * t_dist / k),
+                                      "collectives_per_krylov_iteration": 1}
+        torch.distributed.barrier()
+    return out if rank == 0 else None
+
+
+def run_shard_e3(args, rank, local_rank, world, backend):
+    """SURVEY.md section 8(e) level 3 / BASELINE.json configs[4], measured: the phosphorus module with the columns of its
+    Krylov basis (and the preconditioned products) dealt round-robin to the ranks -- dist.column_sharded_gmres: the owner
+    of a column computes the product and broadcasts it, Gram-Schmidt and the linear combinations are partial sums plus
+    all-reduces of whole vectors -- against the same loop on one rank.  The layout buys HBM, not time: whatever the
+    scaling is, it is what this leg reports."""
+    import numpy as np
+    import torch
+    import torch.distributed as tdist
+
+    from nk_ooc_amd import dist as nkdist
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    n = args.shard3_grid or args.grid
+    k = args.mix_steps
+    grid = Grid2d.default(n, n)
+    eng = phosphorus_engine(grid, device_id=local_rank)
+    try:
+        eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(grid.depth.delta, grid.ypos.delta))
+        prof = [np.interp(grid.depth.mid, d, v) for d, v in (([1.3e2, 2.6e2], [5.5e-3, 4.1]), ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                             ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+        x0 = np.stack([np.broadcast_to(p[:, None], (n, n)) for p in prof]).copy()
+        x = eng.upload(x0)
+        fx, st, _ = eng.comp_fcn(x)
+        sched = eng.last_schedule()
+        eng.precond_setup_state((x0 + eng.download(fx))[0])
+        device = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
+        out = {"what": "BASELINE.json configs[4]: phosphorus, Krylov basis columns sharded over the ranks (level 3)",
+               "grid": [n, n], "krylov_iterations": k, "backend": backend, "base_year_seconds": st["seconds"]}
+        alone = nkdist.ColumnComm(0, 1, device)
+        nkdist.column_sharded_gmres(eng, alone, x, fx, 0.0, 0, 1, sched=sched)          # warm-up
+        eng.sync()
+        t0 = time.perf_counter()
+        nkdist.column_sharded_gmres(eng, alone, x, fx, 0.0, 0, k, sched=sched)
+        eng.sync()
+        t_one = time.perf_counter() - t0
+        out["one_gpu"] = {"ms_per_jvp": 1000.0 * t_one / k, "jvps_per_s": k / t_one}
+        if world >= 2:
+            comm = nkdist.ColumnComm(rank, world, device)
+            nkdist.column_sharded_gmres(eng, comm, x, fx, 0.0, 0, 1, sched=sched)
+            eng.sync()
+            calls0, vec0, bytes0 = comm.calls, comm.vec_calls, comm.vec_bytes
+            tdist.barrier()
+            t0 = time.perf_counter()
+            _, info = nkdist.column_sharded_gmres(eng, comm, x, fx, 0.0, 0, k, sched=sched)
+            eng.sync()
+            tdist.barrier()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+            t_n = float(el.item())
+            out["sharded"] = {"ranks": world, "ms_per_jvp": 1000.0 * t_n / k, "jvps_per_s": k / t_n,
+                              "speedup_over_one_gpu": t_one / t_n,
+                              "small_allreduces_per_jvp": (comm.calls - calls0) / k,
+                              "vector_collectives_per_jvp": (comm.vec_calls - vec0) / k,
+                              "vector_bytes_per_jvp": (comm.vec_bytes - bytes0) / k,
+                              "columns_on_rank0": info["columns_here"]}
+        out["frozen_years_rejected"] = eng.frozen_fallbacks()
+        return out if rank == 0 else None
+    finally:
+        eng.close()
 
 
 def roofline_of(eng, n):
@@ -389,6 +580,11 @@ def main():
     ap.add_argument("--ladder-steps", type=int, default=3)
     ap.add_argument("--no-shard", action="store_true", help="skip the sharded-module leg of N >= 2 runs")
     ap.add_argument("--shard-grid", type=int, default=0, help="grid of the sharded-module leg (default: --grid)")
+    ap.add_argument("--no-shard3", action="store_true", help="skip the basis-column-sharded phosphorus leg (shard_e3)")
+    ap.add_argument("--shard3-grid", type=int, default=0, help="grid of that leg (default: --grid)")
+    ap.add_argument("--no-mix", action="store_true", help="skip the three-module leg (config4_mix)")
+    ap.add_argument("--mix-grid", type=int, default=0, help="grid of the three-module leg (default: --grid)")
+    ap.add_argument("--mix-steps", type=int, default=3, help="Krylov iterations timed in the three-module leg")
     ap.add_argument("--shard-budget", type=float, default=120.0,
                     help="skip the sharded-module leg when its expected wall time exceeds this many seconds")
     ap.add_argument("--launch-check", action="store_true",
@@ -459,8 +655,11 @@ def main():
             totals = eng.profile_totals()
             roof = roofline_of(eng, n)
             out = {
-                "metric": "GMRES JVPs/sec, py_driver_2d iage",
+                "metric": "GMRES JVPs/sec, py_driver_2d iage (value = value_frozen: products on frozen years, the default; "
+                          "value_reference_semantic: the reference's product, two free-running years, same solver, same run)",
                 "value": total_jvps / elapsed,
+                "value_frozen": total_jvps / elapsed,
+                "value_reference_semantic": None,
                 "unit": "JVPs/s",
                 "n_gpus": world,
                 "steps": args.steps,
@@ -501,6 +700,18 @@ def main():
                     "perturbed_year": {k: jvp_stats[k] for k in year_keys},
                     "base_year_free_running": {k: wl.fwd_stats[k] for k in year_keys},
                     "frozen_years_rejected": eng.frozen_fallbacks(),
+                    "frozen_years_resumed": eng.frozen_resumes(),
+                    "error_estimates_checked_last_year": jvp_stats.get("nerr_checked"),
+                    "largest_error_estimate_last_year": jvp_stats.get("max_err"),
+                },
+                "roofline_year": {
+                    "what": "algorithmic bytes of ALL Newton-iteration launches of one perturbed (frozen) year / the seconds "
+                            "of that year (every other kernel of the year in the time, its bytes not counted)",
+                    "bytes_per_year": totals["bytes"] / args.steps,
+                    "seconds_per_year": jvp_stats["seconds"],
+                    "achieved": totals["bytes"] / args.steps / jvp_stats["seconds"] / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": totals["bytes"] / args.steps / jvp_stats["seconds"] / 1e9 / HBM_PEAK_GBS,
                 },
                 "setup_seconds": {"total": wl.setup_s, "precond_factorisation": wl.precond_setup_s},
             }
@@ -518,20 +729,32 @@ def main():
                 t_g = time.perf_counter() - t_g
                 out["gmres_solve_in_hbm"] = {"what": "nk2d_gmres_solve: the same Krylov iterations in one C call, no files",
                                              "jvps_per_s": args.steps / t_g, "ms_per_jvp": 1000.0 * t_g / args.steps}
-                if os.environ.get("NK2D_JVP_FROZEN", "1") != "0":
-                    # the reference's own product, two free-running years, through the same solver: what `value` would
-                    # be without the frozen controller (measured, two Krylov iterations)
-                    os.environ["NK2D_JVP_FROZEN"] = "0"
-                    try:
-                        eng.sync()
-                        t_f = time.perf_counter()
-                        wl.krylov(2, "krylov_free", device)
-                        eng.sync()
-                        t_f = time.perf_counter() - t_f
-                    finally:
-                        os.environ["NK2D_JVP_FROZEN"] = "1"
-                    out["jvp"]["free_running_products"] = {"jvps_per_s": 2.0 / t_f, "ms_per_jvp": 1000.0 * t_f / 2.0,
-                                                           "krylov_iterations": 2}
+        if os.environ.get("NK2D_JVP_FROZEN", "1") != "0":
+            # the reference's own product, two free-running years, through the same solver on every rank: what `value`
+            # is without the frozen controller (measured, two Krylov iterations, same barriers and MAX over ranks)
+            os.environ["NK2D_JVP_FROZEN"] = "0"
+            try:
+                eng.sync()
+                if world > 1:
+                    torch.distributed.barrier()
+                t_f = time.perf_counter()
+                wl.krylov(2, "krylov_free", device)
+                eng.sync()
+                if world > 1:
+                    torch.distributed.barrier()
+                el = torch.tensor([time.perf_counter() - t_f], dtype=torch.float64, device=device)
+                if world > 1:
+                    torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+                t_f = float(el.item())
+            finally:
+                os.environ["NK2D_JVP_FROZEN"] = "1"
+            if rank == 0:
+                out["value_reference_semantic"] = 2.0 * world / t_f
+                out["jvp"]["free_running_products"] = {"jvps_per_s": 2.0 * world / t_f, "ms_per_jvp": 1000.0 * t_f / 2.0,
+                                                       "krylov_iterations": 2}
+        elif rank == 0:
+            out["value_reference_semantic"] = out["value"]
+            out["value_frozen"] = None
         one_gpu_ms = 1000.0 * elapsed / args.steps
         wl_base_stats = dict(wl.fwd_stats)
         faithful_attempts = None
@@ -550,6 +773,22 @@ def main():
             shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
             if rank == 0:
                 out["shard_e2"] = shard
+        if not args.no_mix:
+            mix = run_config4_mix(args, rank, local_rank, world, device)
+            if rank == 0:
+                out["config4_mix"] = mix
+                if "distributed" in mix:
+                    out["strong_scaling"] = {
+                        "what": "config4_mix: the same three-module Krylov iterations on one GPU and on "
+                                f"{mix['distributed']['ranks_used']} GPUs (modules dealt round-robin)",
+                        "n_gpus_used": mix["distributed"]["ranks_used"],
+                        "speedup": mix["distributed"]["speedup_over_one_gpu"],
+                        "one_gpu_ms_per_krylov_iteration": mix["one_gpu"]["ms_per_krylov_iteration"],
+                        "ms_per_krylov_iteration": mix["distributed"]["ms_per_krylov_iteration"]}
+        if not args.no_shard3:
+            shard3 = run_shard_e3(args, rank, local_rank, world, backend)
+            if rank == 0:
+                out["shard_e3"] = shard3
         if rank == 0:
             if world == 1 and not args.no_ladder:
                 out["ladder"] = run_ladder(local_rank, device, args)

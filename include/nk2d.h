@@ -135,6 +135,7 @@ typedef struct nk2d_stats {
     int64_t nresumed;              /* frozen year: times it was resumed from a checkpoint with one more Newton iteration */
     int64_t nerr_checked;          /* frozen year: steps whose error estimate was evaluated (option "frozen_err_check") */
     double max_err;                /* ... and the largest of them (SciPy accepts a step at <= 1) */
+    int64_t nbarrier_timeouts;     /* 1: the one-launch year timed out at a grid barrier and was rerun under host control */
 } nk2d_stats;
 
 int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out);
@@ -203,6 +204,14 @@ int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n
    resumed. */
 int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
 int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
+/* Small grids (at most "frozen_persistent_max_e" levels per lane, default 2 = 128 levels; modules whose Jacobian is a function
+   of time alone): a frozen year runs as ONE cooperative launch (a wave per column, grid barriers between the simplified-Newton
+   iterations) on a cache of everything its schedule fixes besides the state -- mixing planes, Jacobian planes and line
+   factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
+   "frozen_cache_gb").  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
+   barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
+   "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes". */
+int nk2d_get_counter(nk2d_ctx* ctx, const char* name, int64_t* out);
 /* hash of everything a recorded schedule depends on besides the state: grid, module description, tolerances, the
    controller options (jac_fresh, jac_stage, lin_tol, min_sweeps, growth_cap, factor storage) and the library version;
    an integer below 2^52, never 0 */

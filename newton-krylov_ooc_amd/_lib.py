@@ -78,6 +78,7 @@ class Stats(ctypes.Structure):
         ("nresumed", ctypes.c_int64),
         ("nerr_checked", ctypes.c_int64),
         ("max_err", ctypes.c_double),
+        ("nbarrier_timeouts", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "nk2d_last_schedule": (_ci, [_vp, c_double_p, _i64, c_int64_p]),
     "nk2d_frozen_fallbacks": (_ci, [_vp, c_int64_p]),
     "nk2d_frozen_resumes": (_ci, [_vp, c_int64_p]),
+    "nk2d_get_counter": (_ci, [_vp, ctypes.c_char_p, c_int64_p]),
     "nk2d_schedule_fingerprint": (_ci, [_vp, c_double_p]),
     "nk2d_comp_fcn_hist": (_ci, [_vp, _vp, _vp, ctypes.POINTER(Stats), _i32, c_double_p, c_double_p]),
     "nk2d_precond_setup": (_ci, [_vp]),

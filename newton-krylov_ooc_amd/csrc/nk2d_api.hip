@@ -133,6 +133,16 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
     if (key == "prefactor") { c->prefactor = value != 0.0; return 0; }
+    if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
+    if (key == "frozen_persistent") { c->frozen_persistent = value != 0.0; return 0; }
+    if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
+    if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
+    if (key == "frozen_cache_gb") { c->frozen_cache_max_gb = value; return 0; }
+    if (key == "barrier_timeout_ms") {
+        if (!(value >= 0.0)) return nk2d_fail(c, "nk2d_set_option: barrier_timeout_ms must be >= 0");
+        c->barrier_timeout_ms = value;
+        return 0;
+    }
     if (key == "frozen_err_check") {
         if (!(value >= 0.0) || value > 1.0e6) return nk2d_fail(c, "nk2d_set_option: frozen_err_check must be 0 (off) or a step stride");
         c->frozen_err_check = (int)value;
@@ -458,6 +468,15 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->STEP_NORM, (size_t)3 * NK2D_OWN_REC_CAP));
     c->frozen_fallbacks = 0;
     c->frozen_resumes = 0;
+    c->frozen_cache = nullptr;
+    c->frozen_persistent = 1;
+    c->frozen_persistent_max_e = 2;
+    c->frozen_cache_max_gb = 8.0;
+    c->frozen_cache_builds = c->frozen_persistent_years = c->frozen_xcd_years = 0;
+    c->frozen_xcd = 1;
+    c->frozen_xcd_failed = 0;
+    c->barrier_timeout_ms = 2000.0;
+    c->year_fences = 0;
     c->frozen_err_check = 32;
     c->STEP_PART = nullptr;
     c->step_part_rows = 0;
@@ -590,6 +609,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     (void)hipSetDevice(c->dev);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     nk2d_precond_free(c);
+    nk2d_frozen_cache_free(c);
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->KVN[0], c->KVN[1], c->KVN[2], c->JB[0], c->JB[1],
                       c->JB[2], c->JB[3], c->JB[4], c->Y,
@@ -876,6 +896,19 @@ extern "C" int nk2d_frozen_fallbacks(nk2d_ctx* c, int64_t* n) {
 
 extern "C" int nk2d_frozen_resumes(nk2d_ctx* c, int64_t* n) {
     if (n) *n = c->frozen_resumes;
+    return 0;
+}
+
+extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
+    const std::string key(name ? name : "");
+    int64_t v = 0;
+    if (key == "frozen_persistent_years") v = c->frozen_persistent_years;
+    else if (key == "frozen_cache_builds") v = c->frozen_cache_builds;
+    else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
+    else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
+    else if (key == "frozen_resumes") v = c->frozen_resumes;
+    else return nk2d_fail(c, "nk2d_get_counter: unknown counter " + key);
+    if (out) *out = v;
     return 0;
 }
 

@@ -135,6 +135,15 @@ struct nk2d_ctx {
     size_t step_part_rows;  // rows allocated
     double* STEP_NORM;  // [3 * NK2D_OWN_REC_CAP] per step of a frozen year: sum((dW/scale)^2) of its last and last-but-one iteration, sum((err/scale)^2)
     int64_t frozen_fallbacks;   // frozen years rejected by the a-posteriori Newton check (nk2d_frozen_fallbacks)
+    // the frozen year of a small grid in one launch on a schedule cache (k_frozen_persistent, nk2d_kernels.hip)
+    void* frozen_cache;
+    int frozen_persistent;          // option "frozen_persistent": 1 = where eligible (default), 0 = never
+    int frozen_persistent_max_e;    // ... for grids of at most this many levels per lane (option "frozen_persistent_max_e")
+    double frozen_cache_max_gb;     // ... whose schedule cache stays below this size (option "frozen_cache_gb")
+    int64_t frozen_cache_builds, frozen_persistent_years, frozen_xcd_years;
+    int frozen_xcd, frozen_xcd_failed;   // option "frozen_xcd": the year's workgroups on one XCD; set once the placement failed
+    double barrier_timeout_ms;  // longest wait at a grid barrier of the persistent year (option "barrier_timeout_ms")
+    int year_fences;            // 1: release / acquire fences around its grid barriers (option "year_fences", validation)
     int64_t frozen_resumes;     // ... and resumed from a checkpoint with one more Newton iteration (nk2d_frozen_resumes)
     int frozen_err_check;       // k > 0: SciPy's error estimate on every k-th step of a frozen year (option "frozen_err_check")
     uint64_t grid_hash;         // hash of the grid / module description given to nk2d_create (nk2d_fingerprint)
@@ -272,6 +281,16 @@ static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK 
         default: break;                                              \
     }
 
+// the same for the kernels that exist for small grids only (at most 4 levels per lane = 256 depth levels)
+#define NK2D_DISPATCH_E4(Eval, ...)                                \
+    switch (Eval) {                                                  \
+        case 1: { constexpr int EE = 1; __VA_ARGS__; } break;               \
+        case 2: { constexpr int EE = 2; __VA_ARGS__; } break;               \
+        case 3: { constexpr int EE = 3; __VA_ARGS__; } break;               \
+        case 4: { constexpr int EE = 4; __VA_ARGS__; } break;               \
+        default: break;                                              \
+    }
+
 // as above, plus a compile-time module kind KK (0: linear sources, 1: phosphorus, 2: forcing files)
 #define NK2D_DISPATCH_EK(Eval, kind, ...)                                        \
     if ((kind) == 1) {                                                            \
@@ -377,9 +396,12 @@ __device__ __forceinline__ void shift_next(const double (&a)[E], double (&o)[E],
 // stores on gfx950: the load bypasses the CU's L1, the store is written through) for data that OTHER workgroups
 // of a persistent launch read or write between two grid barriers (k_year_persistent): an array accessed with
 // MP = 1 anywhere in such a launch must be accessed with MP = 1 everywhere in it.
+// MP = 1: data other workgroups anywhere on the chip exchange inside a launch -- write-through (sc1) stores, L1-bypassing
+// (sc1) loads.  MP = 2: the same between workgroups that all sit on ONE XCD -- plain stores (they reach, and stay in, the
+// XCD's L2 once the wave has waited for them) and the same L1-bypassing loads, which that L2 then serves.
 template <int MP>
 __device__ __forceinline__ double ld_mp(const double* p) {
-    if constexpr (MP == 1) {
+    if constexpr (MP >= 1) {
         const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
         return __longlong_as_double((long long)bits);
@@ -563,6 +585,8 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 double nk2d_fingerprint(const nk2d_ctx* c);
+int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n);
+void nk2d_frozen_cache_free(nk2d_ctx* c);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);
 int nk2d_host_interp(int n, const double* xp, const double* fp, double x, double* out);

@@ -1525,7 +1525,7 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
             z2[e] = (cT[2][0] * w0[e] + cT[2][1] * w1[e]) + cT[2][2] * w2[e];
             yn[e] = yy[e] + z2[e];
         }
-        store_col<E>(fin->ynew, task, lane, yn);
+        store_col<E, MP>(fin->ynew, task, lane, yn);
         const double xs[3] = {fin->x0, fin->x1, fin->x2};
         double o[3][E];
 #pragma unroll
@@ -1542,7 +1542,7 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
             }
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) store_col<E>(fin->znext + i * A.st.nv, task, lane, o[i]);
+        for (int i = 0; i < 3; ++i) store_col<E, MP>(fin->znext + i * A.st.nv, task, lane, o[i]);
         double wv[E];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -3001,6 +3001,8 @@ struct YearArgs {
     double* record;            // accepted steps [cap][NK2D_SCHED_WIDTH] or null
     double fingerprint;        // of the context (recorded with every step)
     long long record_cap;
+    long long spin_ticks;      // longest wait at a grid barrier, in ticks of s_memrealtime (100 MHz)
+    int fences;                // 1: agent-scope release / acquire fences around every grid barrier (option "year_fences")
 };
 
 // Arrival counter in NK2D_BAR_SHARDS shards, each on a 128-byte line of its own: an agent-scope atomic executes at
@@ -3015,20 +3017,30 @@ struct GridBarrier {
     int* abort_flag;
     unsigned nwg, epoch;
     int* lds_ok;
+    long long spin_ticks;
+    int fences;
+    int xcd = 0;     // 1: every workgroup of the barrier sits on one XCD -- ONE counter, adds executed in that XCD's L2
+    int wg_id = 0;   // this workgroup's number among them (xcd = 0: blockIdx.x)
     __device__ __forceinline__ bool sync() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
+        // validation mode: the textbook hand-off as well (every wave releases before the barrier and acquires after it), which
+        // also covers an array the write-through / L1-bypassing accessors might have missed -- results must not change
+        if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (threadIdx.x < 64) {     // the first wave arrives for the workgroup and polls
             const int lane = threadIdx.x;
             const unsigned target = (epoch + 1u) * nwg;
-            if (lane == 0)
-                __hip_atomic_fetch_add(arrive + (size_t)(blockIdx.x % NK2D_BAR_SHARDS) * NK2D_BAR_STRIDE, 1u,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                if (xcd) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_add(arrive + (size_t)(blockIdx.x % NK2D_BAR_SHARDS) * NK2D_BAR_STRIDE, 1u,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             int good = 1;
             long long spins = 0;
+            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
             for (;;) {
                 unsigned v = 0u;
-                if (lane < NK2D_BAR_SHARDS)
+                if (lane < (xcd ? 1 : NK2D_BAR_SHARDS))
                     v = __hip_atomic_load(arrive + (size_t)lane * NK2D_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -3036,7 +3048,10 @@ struct GridBarrier {
                 if (total >= target) break;
                 const int ab = __builtin_amdgcn_readfirstlane(
                     (lane == 0) ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
-                if (++spins > NK2D_SPIN_LIMIT || ab != 0) {
+                // bounded by TIME (a slow co-tenant must not fail a year that is merely waiting), and by a spin count as a
+                // last resort should the clock not advance
+                const bool late = (++spins & 63) == 0 && (long long)__builtin_amdgcn_s_memrealtime() - t_begin > spin_ticks;
+                if (late || spins > 4000LL * NK2D_SPIN_LIMIT || ab != 0) {
                     if (lane == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = 0;
                     break;
@@ -3046,6 +3061,7 @@ struct GridBarrier {
             if (lane == 0) *lds_ok = good;
         }
         __syncthreads();
+        if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         ++epoch;
         return *lds_ok != 0;
     }
@@ -3110,7 +3126,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_year_persistent(DevP P, YearArgs
     const int wave = uni_i((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     const bool col_wave = wave < P.ncol;             // this wave owns column `wave` for the whole year
-    GridBarrier bar{A.arrive, A.abort_flag, gridDim.x, 0u, &lds_ok};
+    GridBarrier bar{A.arrive, A.abort_flag, gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences};
     const double RC0 = 0.15505102572168222, RC1 = 0.6449489742783178, RC2 = 1.0;
     const double MU_REAL = 3.637834252744496, MU_CR = 2.6810828736277523, MU_CI = -3.050430199247411;
     const int NEWTON_MAXITER = 6;
@@ -3587,6 +3603,8 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     A.record = record ? c->YR_REC : nullptr;
     A.record_cap = record ? record_cap : 0;
     A.fingerprint = nk2d_fingerprint(c);
+    A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
+    A.fences = c->year_fences;
     DevP P = make_devp(c);
     P.guard = nullptr;
     void* args[2] = {&P, &A};
@@ -3619,7 +3637,9 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         c->prof_ms_sum += ms; c->prof_windows += 1; c->prof_cnt += 1;
         c->sweep_launches += 1; c->sweep_bytes += o[14]; c->fused_bytes_all += o[14];
     }
-    if (status == 1) return nk2d_fail(c, "nk2d_comp_fcn: a grid barrier of the persistent year timed out", -6);
+    // a grid barrier timed out (a co-tenant held the chip, say): the input is intact (the caller re-copies it), the year
+    // reruns under host control -- counted, not failed
+    if (status == 1) return 2;
     if (status == 2) return nk2d_fail(c, "Radau: step size is not finite (non-finite state or tendency)", -3);
     if (status == 3) return nk2d_fail(c, "Radau: required step size is less than spacing between numbers", -3);
     const int64_t nrec = (int64_t)o[10];
@@ -3630,5 +3650,580 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     if (record_n) *record_n = nrec;
     if (record && nrec > record_cap && record != c->own_rec.data())
         return nk2d_fail(c, "nk2d_comp_fcn: schedule record buffer too small", -4);
+    return 0;
+}
+
+
+// =================================================================================================
+// The frozen year of a small grid in ONE launch, on a schedule cache.
+//
+// A frozen year (nk2d_comp_fcn_frozen: the perturbed year of a finite-difference product) decides nothing, and for
+// the modules whose Jacobian is a function of time alone everything but the state is known from the schedule:
+// the mixing planes of every step's stage times, its Jacobian planes, its line factorisation.  Up to 208 x 208 that is
+// at most a few GB per schedule, computed ONCE per schedule (= once per Newton iteration) by two batched launches over
+// (step, column) -- k_cache_planes, k_cache_factor -- and read by every year of the Krylov solve.  What is left of a
+// year are its simplified-Newton iterations, one phase each: k_frozen_persistent runs them all in one cooperative
+// launch, a wave per column, the phases separated by the grid barrier of k_year_persistent, with the launch-per-phase
+// path's own device functions (newton_fused_body; the last iteration of a step ends it: FINAL) -- bit-identical to it.
+// At 26 x 26 a launch-per-phase year is 2 200 launches of 7.6 us; a phase here costs its barrier plus a microsecond.
+// =================================================================================================
+struct CacheRow {
+    VmixArgs v;          // slots 0..2: the stage times of the row (out: its planes in the cache); slot 3: its Jacobian time
+    double cre, ccr, cci;    // shifts of its line factorisation (h_lu)
+};
+
+struct CachePtrs {
+    double *KV, *J;                                     // [n][3][kv_len], [n][5][np]
+    double *fr_inv, *fc_invr, *fc_invi;                 // [n][nv]
+    double *fr_tab, *fc_tabr, *fc_tabi;                 // [n][ncol * NK2D_TAB * 64]
+    size_t kv_len, np, nv, ntab;
+};
+
+// planes and Jacobian of every row: task = (row, slot 0..3, ypos column)
+template <int E>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_cache_planes(DevP P, const CacheRow* __restrict__ rows, CachePtrs C, int n) {
+    const int lane = threadIdx.x & 63;
+    const long long task = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long per_row = 4LL * P.ny;
+    if (task >= per_row * n) return;
+    const int i = (int)(task / per_row), rem = (int)(task - (long long)i * per_row);
+    const int slot = rem / P.ny, j = rem - slot * P.ny;
+    const CacheRow& R = rows[i];
+    if (slot < 3) {
+        double kv[E];
+        vmix_body_kv<E>(P, R.v, slot * P.ny + j, lane, kv);
+    } else {
+        double kv[E], up[E], dn[E], so[E], no[E], ce[E];
+        vmix_col_regs<E>(P, R.v.bldmin, R.v.y0, R.v.y1, R.v.hw, R.v.frac[3], j, lane, kv);
+        jac_cols<E>(P, kv, j, lane, up, dn, so, no, ce);
+        double* J = C.J + (size_t)i * 5 * C.np;
+        store_col<E>(J, j, lane, up);
+        store_col<E>(J + C.np, j, lane, dn);
+        store_col<E>(J + 2 * C.np, j, lane, so);
+        store_col<E>(J + 3 * C.np, j, lane, no);
+        store_col<E>(J + 4 * C.np, j, lane, ce);
+    }
+}
+
+// line factorisation of every row: task = (row, (system, tracer), ypos column) -- the work of k_factor per row
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_cache_factor(DevP P, const CacheRow* __restrict__ rows, CachePtrs C, int n) {
+    const int lane = threadIdx.x & 63;
+    const long long task = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long per_row = 2LL * P.ncol;
+    if (task >= per_row * n) return;
+    const int i = (int)(task / per_row), rem = (int)(task - (long long)i * per_row);
+    const CacheRow& R = rows[i];
+    SweepArgs A = {};
+    const double* J = C.J + (size_t)i * 5 * C.np;
+    A.JL = J; A.JU = J + C.np; A.JS = J + 2 * C.np; A.JN = J + 3 * C.np; A.JC = J + 4 * C.np;
+    A.fr_inv = C.fr_inv + (size_t)i * C.nv; A.fc_invr = C.fc_invr + (size_t)i * C.nv; A.fc_invi = C.fc_invi + (size_t)i * C.nv;
+    A.fr_tab = C.fr_tab + (size_t)i * C.ntab; A.fc_tabr = C.fc_tabr + (size_t)i * C.ntab; A.fc_tabi = C.fc_tabi + (size_t)i * C.ntab;
+    A.f32 = 0;
+    A.cre = R.cre; A.ccr = R.ccr; A.cci = R.cci;
+    A.nreal = P.ncol; A.ntasks = 2 * P.ncol;
+    factor_body<E, KIND>(P, A, rem, lane);
+}
+
+// The single-phase Newton iteration (stage + one sweep + update) of newton_fused_body for the one-launch year of a small
+// grid, with EVERY operand requested before the first is used.  A wave issues in order: in the generic body the Jacobian
+// planes and the factorisation are asked for behind the stage arithmetic, W again behind the solves -- four round trips
+// to memory in a row, 4 of the 6 us a phase takes at one level per lane.  Here there is one.  The arithmetic is the
+// generic body's, operation for operation (the same inline functions, the same expressions in the same order), so the
+// results are its results bit for bit; the re-loads of y and W before the update read what the stage part read.
+// KIND 0, no factorisation in the phase, double precision tables.
+template <int E, int MP, int FINAL>
+__device__ __forceinline__ void newton_single_body(const DevP& P, const FusedArgs& A, int task, int lane, const FinalArgs* fin = nullptr) {
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    // ---- every load
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double y0[E], ys[E], yn[E], zc[3][E], zs[3][E], zn[3][E], kvs[3][E], w0[E], w1[E], w2[E], jl[E], ju[E];
+    load_col<E, MP>(A.st.y, task, lane, y0);
+    load_col<E, MP>(A.st.y, cs_col, lane, ys);
+    load_col<E, MP>(A.st.y, cn_col, lane, yn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        load_col<E, MP>(A.st.z + i * A.st.nv, task, lane, zc[i]);
+        load_col<E, MP>(A.st.z + i * A.st.nv, cs_col, lane, zs[i]);
+        load_col<E, MP>(A.st.z + i * A.st.nv, cn_col, lane, zn[i]);
+        load_col<E>(A.st.kv[i], j, lane, kvs[i]);              // the schedule cache: constant during the launch
+    }
+    load_col<E>(A.st.w, task, lane, w0);
+    load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+    load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+    load_col<E>(A.sw.JL, j, lane, jl);
+    load_col<E>(A.sw.JU, j, lane, ju);
+    double inv_r[E], tab_r[NK2D_TAB], t0[E], t1[E], tr0[NK2D_TAB], ti0[NK2D_TAB];
+    load_col<E>(A.sw.fr_inv, task, lane, inv_r);
+    load_tab<E>(A.sw.fr_tab, task, lane, tab_r);
+    load_col<E>(A.sw.fc_invr, task, lane, t0);
+    load_col<E>(A.sw.fc_invi, task, lane, t1);
+    load_tab<E>(A.sw.fc_tabr, task, lane, tr0);
+    load_tab<E>(A.sw.fc_tabi, task, lane, ti0);
+    // ---- stage tendencies and transformed residuals
+    double fr[E], fcr[E], fci[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { fr[e] = 0.0; fcr[e] = 0.0; fci[e] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double c[E], cs[E], cn[E], f[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { c[e] = y0[e] + zc[i][e]; cs[e] = ys[e] + zs[i][e]; cn[e] = yn[e] + zn[i][e]; }
+        tend_col<E, 0>(P, cf, c, cs, cn, kvs[i], tr, lane, f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            fr[e] = fr[e] + f[e] * cTI[0][i];
+            fcr[e] = fcr[e] + f[e] * cTI[1][i];
+            fci[e] = fci[e] + f[e] * cTI[2][i];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        fr[e] = fr[e] - A.st.mreal * w0[e];
+        fcr[e] = fcr[e] - (A.st.mcr * w1[e] - A.st.mci * w2[e]);
+        fci[e] = fci[e] - (A.st.mcr * w2[e] + A.st.mci * w1[e]);
+    }
+    // ---- the two line solves of the column (first sweep: no lateral terms)
+    double a[E], cc[E];
+    line_offdiag<E, 0>(P, tr, lane, jl, ju, a, cc);
+#pragma unroll
+    for (int e = 0; e < E; ++e) fr[e] = ((lane * E + e) < P.nz) ? fr[e] : 0.0;
+    tridiag_apply<E, double>(a, cc, inv_r, tab_r, fr, lane);
+    {
+        cplx r[E], inv[E], tab[NK2D_TAB];
+#pragma unroll
+        for (int e = 0; e < E; ++e) inv[e] = c_make(t0[e], t1[e]);
+#pragma unroll
+        for (int i = 0; i < NK2D_TAB; ++i) tab[i] = c_make(tr0[i], ti0[i]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane * E + e) < P.nz;
+            r[e] = c_make(valid ? fcr[e] : 0.0, valid ? fci[e] : 0.0);
+        }
+        tridiag_apply<E, cplx>(a, cc, inv, tab, r, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
+    }
+    // ---- dW = (fr, fcr, fci): norm partial, W += dW, Z = T W
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double sc = P.atol + fabs(y0[e]) * P.rtol;
+        const double d0 = fr[e] / sc, d1 = fcr[e] / sc, d2 = fci[e] / sc;
+        acc += (d0 * d0 + d1 * d1) + d2 * d2;
+        w0[e] = w0[e] + fr[e];
+        w1[e] = w1[e] + fcr[e];
+        w2[e] = w2[e] + fci[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) st_mp<0>(A.part + task, acc);
+    double* wout = const_cast<double*>(A.st.w);
+    if constexpr (FINAL) {
+        double z0[E], z1[E], z2[E], ynw[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            z0[e] = (cT[0][0] * w0[e] + cT[0][1] * w1[e]) + cT[0][2] * w2[e];
+            z1[e] = (cT[1][0] * w0[e] + cT[1][1] * w1[e]) + cT[1][2] * w2[e];
+            z2[e] = (cT[2][0] * w0[e] + cT[2][1] * w1[e]) + cT[2][2] * w2[e];
+            ynw[e] = y0[e] + z2[e];
+        }
+        store_col<E, MP>(fin->ynew, task, lane, ynw);
+        const double xs[3] = {fin->x0, fin->x1, fin->x2};
+        double o[3][E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            double q[3];
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double p1 = xs[i], p2 = p1 * xs[i], p3 = p2 * xs[i];
+                double v = (q[0] * p1 + q[1] * p2) + q[2] * p3;
+                v = v + y0[e];
+                o[i][e] = v - ynw[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store_col<E, MP>(fin->znext + i * A.st.nv, task, lane, o[i]);
+        double wv[E];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
+            store_col<E>(wout + r * A.st.nv, task, lane, wv);
+        }
+        return;
+    }
+    store_col<E>(wout, task, lane, w0);
+    store_col<E>(wout + A.st.nv, task, lane, w1);
+    store_col<E>(wout + 2 * A.st.nv, task, lane, w2);
+    double zz[E];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
+        store_col<E, MP>(A.st.zout + r * A.st.nv, task, lane, zz);
+    }
+}
+
+struct FrozenRow {
+    double mreal, mcr, mci;      // MU / h of the row
+    double x0, x1, x2;           // dense-output abscissae of the NEXT row's stage times (the step-ending launch)
+    int n_iter, m;               // simplified-Newton iterations, sweeps per solve
+};
+
+struct FrozenArgs {
+    double *Y, *YOLD, *Z, *ZN, *W;
+    double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2];
+    double* PART;                // scratch partials [ncol]
+    double* STEP_PART;           // rows of ncol: 3 per step (last iteration, the one before, error estimate -- unused here)
+    const FrozenRow* rows;
+    CachePtrs C;
+    int n;
+    unsigned* arrive;
+    int* abort_flag;
+    double* out;                 // [32]: status, rows done, parities
+    long long spin_ticks;
+    int fences;
+    unsigned* tickets;           // XCD flavour: the workgroups that find themselves on XCD 0 take a number here
+    int nwg;                     // ... until this many have one
+};
+
+// XCD = 1: launched plainly with eight times the workgroups it needs (and some); a workgroup reads the XCD it landed on
+// (HW_REG_XCC_ID), those on XCD 0 take a ticket, the first nwg of them are the year's workgroups, everybody else exits.
+// All exchanges then stay in ONE L2: plain stores + L1-bypassing loads (MP = 2), ONE arrival counter with L2-executed adds
+// -- a barrier costs 1.0-1.5 us instead of 2.1 us and a neighbour's column comes from L2 instead of the fabric
+// (tools/proto_xcd_barrier.hip, profiles/r03_xcd_barrier.log).  HIP promises no placement: if XCD 0 does not get its nwg
+// workgroups the barrier times out, the abort flag is raised and the caller runs the cooperative flavour (XCD = 0).
+template <int E, int KIND, int XCD>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, FrozenArgs A) {
+    __shared__ int lds_ok;
+    __shared__ int lds_id;
+    constexpr int MPX = XCD ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    int wg = (int)blockIdx.x;
+    if constexpr (XCD) {
+        if (threadIdx.x == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            int id = -1;
+            if ((xcc & 7u) == 0u) {
+                const unsigned t = __hip_atomic_fetch_add(A.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < (unsigned)A.nwg) id = (int)t;
+            }
+            lds_id = id;
+        }
+        __syncthreads();
+        wg = lds_id;
+        if (wg < 0) return;
+    }
+    const int wave = uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+    const bool col_wave = wave < P.ncol;
+    GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
+    const size_t nv = A.C.nv;
+    int swapY = 0, swapZ = 0, status = 0, done = 0;
+#define FZ_Y (swapY ? A.YOLD : A.Y)
+#define FZ_YOLD (swapY ? A.Y : A.YOLD)
+#define FZ_Z (swapZ ? A.ZN : A.Z)
+#define FZ_ZN (swapZ ? A.Z : A.ZN)
+#define FZ_SYNC() \
+    if (!bar.sync()) { status = 1; goto finish; }
+    // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
+    if (col_wave) {
+        double zero[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zero[e] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            store_col<E, MPX>(FZ_Z + i * nv, wave, lane, zero);
+            store_col<E>(A.W + i * nv, wave, lane, zero);
+        }
+    }
+    FZ_SYNC()
+    for (int i = 0; i < A.n; ++i) {
+        const FrozenRow R = A.rows[i];
+        const int n_iter = uni_i(R.n_iter), m = uni_i(R.m);
+        const bool last_row = i == A.n - 1;
+        const double* kvb = A.C.KV + (size_t)i * 3 * A.C.kv_len;
+        const double* J = A.C.J + (size_t)i * 5 * A.C.np;
+        for (int k = 0; k < n_iter; ++k) {
+            int src = 0;
+            for (int it = 0; it < m; ++it) {
+                const bool do_stage = it == 0, first = it == 0, do_update = it == m - 1, delta = m == 2;
+                const bool is_final = do_update && k == n_iter - 1 && !last_row;
+                FusedArgs FA = {};
+                FA.st.y = FZ_Y; FA.st.z = FZ_Z; FA.st.w = A.W;
+                FA.st.zout = (do_stage && do_update) ? FZ_ZN : FZ_Z;
+                FA.st.kv[0] = kvb; FA.st.kv[1] = kvb + A.C.kv_len; FA.st.kv[2] = kvb + 2 * A.C.kv_len;
+                FA.st.br = A.BR; FA.st.bcr = A.BCR; FA.st.bci = A.BCI;
+                FA.st.nv = nv; FA.st.mreal = R.mreal; FA.st.mcr = R.mcr; FA.st.mci = R.mci;
+                FA.sw.JL = J; FA.sw.JU = J + A.C.np; FA.sw.JS = J + 2 * A.C.np; FA.sw.JN = J + 3 * A.C.np; FA.sw.JC = J + 4 * A.C.np;
+                FA.sw.fr_inv = A.C.fr_inv + (size_t)i * nv; FA.sw.fc_invr = A.C.fc_invr + (size_t)i * nv;
+                FA.sw.fc_invi = A.C.fc_invi + (size_t)i * nv;
+                FA.sw.fr_tab = A.C.fr_tab + (size_t)i * A.C.ntab; FA.sw.fc_tabr = A.C.fc_tabr + (size_t)i * A.C.ntab;
+                FA.sw.fc_tabi = A.C.fc_tabi + (size_t)i * A.C.ntab;
+                FA.sw.f32 = 0;
+                FA.sw.br = A.BR; FA.sw.bcr = A.BCR; FA.sw.bci = A.BCI;
+                FA.sw.xr_old = src ? A.XR[1] : A.XR[0]; FA.sw.xcr_old = src ? A.XCR[1] : A.XCR[0];
+                FA.sw.xci_old = src ? A.XCI[1] : A.XCI[0];
+                FA.sw.xr_new = src ? A.XR[0] : A.XR[1]; FA.sw.xcr_new = src ? A.XCR[0] : A.XCR[1];
+                FA.sw.xci_new = src ? A.XCI[0] : A.XCI[1];
+                FA.sw.first = first ? 1 : 0;
+                FA.part = (k == n_iter - 1) ? A.STEP_PART + (size_t)(3 * i) * P.ncol
+                                            : ((k == n_iter - 2) ? A.STEP_PART + (size_t)(3 * i + 1) * P.ncol : A.PART);
+                FA.do_stage = do_stage ? 1 : 0; FA.do_update = do_update ? 1 : 0; FA.delta = delta ? 1 : 0;
+                if (is_final) {
+                    FinalArgs Fin;
+                    Fin.ynew = FZ_YOLD;
+                    Fin.znext = do_stage ? FZ_ZN : FZ_Z;
+                    Fin.x0 = R.x0; Fin.x1 = R.x1; Fin.x2 = R.x2;
+                    Fin.nblk_cols = 0;
+                    if (col_wave) {
+                        bool taken = false;
+                        if constexpr (KIND == 0 && E <= 2) {
+                            if (m == 1) { newton_single_body<E, MPX, 1>(P, FA, wave, lane, &Fin); taken = true; }
+                        }
+                        if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 1>(P, FA, wave, lane, &Fin);
+                    }
+                    swapY ^= 1;
+                    if (do_stage) swapZ ^= 1;
+                } else {
+                    if (col_wave) {
+                        bool taken = false;
+                        if constexpr (KIND == 0 && E <= 2) {
+                            if (m == 1) { newton_single_body<E, MPX, 0>(P, FA, wave, lane); taken = true; }
+                        }
+                        if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 0>(P, FA, wave, lane);
+                    }
+                    if (do_stage && do_update) swapZ ^= 1;
+                }
+                src = 1 - src;
+                FZ_SYNC()
+            }
+        }
+        done = i + 1;
+    }
+finish:
+    if (wave == 0 && lane == 0) {
+        A.out[0] = (double)status; A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ;
+        A.out[4] = (double)bar.epoch;
+    }
+#undef FZ_SYNC
+#undef FZ_Y
+#undef FZ_YOLD
+#undef FZ_Z
+#undef FZ_ZN
+}
+
+// the cache of everything a schedule fixes besides the state; rebuilt when another schedule comes
+struct nk2d_frozen_cache {
+    uint64_t key = 0;
+    int64_t n = 0;
+    CachePtrs C = {};
+    CacheRow* rows_dev = nullptr;      // [n]
+    FrozenRow* frows_dev = nullptr;    // [n]
+    size_t cap_rows = 0;
+    std::vector<FrozenRow> frows;
+};
+
+static uint64_t sched_key(const double* sched, int64_t n) {
+    uint64_t h = 14695981039346656037ull;
+    const unsigned char* p = (const unsigned char*)sched;
+    const size_t nb = sizeof(double) * (size_t)n * NK2D_SCHED_WIDTH;
+    for (size_t i = 0; i < nb; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+
+void nk2d_frozen_cache_free(nk2d_ctx* c) {
+    nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
+    if (!fc) return;
+    double* bufs[] = {fc->C.KV, fc->C.J, fc->C.fr_inv, fc->C.fc_invr, fc->C.fc_invi, fc->C.fr_tab, fc->C.fc_tabr, fc->C.fc_tabi};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    if (fc->rows_dev) (void)hipFree(fc->rows_dev);
+    if (fc->frows_dev) (void)hipFree(fc->frows_dev);
+    delete fc;
+    c->frozen_cache = nullptr;
+}
+
+// 0: the year ran in one launch (buffers in their roles after the last-but-one row's end; the last row's Newton iterations
+//    done, its commit left to the caller);  1: not for this context / schedule (the launch-per-phase path runs);
+// 2: a grid barrier timed out (the same);  < 0: error
+int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
+    const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
+    if (!c->frozen_persistent || needs_state || c->hist_n != 0 || c->norm_hook || n < 1) return 1;
+    if (c->E > c->frozen_persistent_max_e || c->E > 4) return 1;
+    // every row but the last must hand over to the next one (t_new == next t, whole step taken): the step-ending launch
+    // predicts the next attempt from this step's collocation polynomial
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        const double* r = sched + i * NK2D_SCHED_WIDTH;
+        if (!(r[0] + r[2] == r[1] && r[NK2D_SCHED_WIDTH] == r[1] && r[NK2D_SCHED_WIDTH + 2] > 0.0 && (int)r[3] >= 1)) return 1;
+    }
+    if ((int)sched[(n - 1) * NK2D_SCHED_WIDTH + 3] < 1) return 1;
+    const size_t ntab = (size_t)c->ncol * NK2D_TAB * 64;
+    const double bytes = 8.0 * (double)n * (3.0 * c->kv_len + 5.0 * c->np + 3.0 * c->nv + 3.0 * ntab);
+    if (bytes > c->frozen_cache_max_gb * 1.0e9) return 1;
+    nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
+    if (!fc) { fc = new nk2d_frozen_cache(); c->frozen_cache = fc; }
+    const uint64_t key = sched_key(sched, n) ^ (uint64_t)nk2d_fingerprint(c);
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    if (fc->key != key || fc->n != n) {
+        // ---- (re)build the cache for this schedule
+        if (fc->cap_rows < (size_t)n) {
+            NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+            double** bufs[] = {&fc->C.KV, &fc->C.J, &fc->C.fr_inv, &fc->C.fc_invr, &fc->C.fc_invi, &fc->C.fr_tab, &fc->C.fc_tabr, &fc->C.fc_tabi};
+            for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+            if (fc->rows_dev) (void)hipFree(fc->rows_dev);
+            if (fc->frows_dev) (void)hipFree(fc->frows_dev);
+            fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
+            const size_t cap = (size_t)n + (size_t)n / 8 + 16;
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.KV, sizeof(double) * cap * 3 * c->kv_len));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.J, sizeof(double) * cap * 5 * c->np));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fr_inv, sizeof(double) * cap * c->nv));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_invr, sizeof(double) * cap * c->nv));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_invi, sizeof(double) * cap * c->nv));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fr_tab, sizeof(double) * cap * ntab));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_tabr, sizeof(double) * cap * ntab));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_tabi, sizeof(double) * cap * ntab));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->rows_dev, sizeof(CacheRow) * cap));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->frows_dev, sizeof(FrozenRow) * cap));
+            fc->cap_rows = cap;
+        }
+        fc->C.kv_len = c->kv_len; fc->C.np = c->np; fc->C.nv = c->nv; fc->C.ntab = ntab;
+        const double RCs[3] = {0.15505102572168222, 0.6449489742783178, 1.0};
+        const double MU_REAL = 3.637834252744496, MU_CR = 2.6810828736277523, MU_CI = -3.050430199247411;
+        std::vector<CacheRow> rows((size_t)n);
+        fc->frows.assign((size_t)n, FrozenRow());
+        for (int64_t i = 0; i < n; ++i) {
+            const double* r = sched + i * NK2D_SCHED_WIDTH;
+            const double t = r[0], t_new = r[1], h = r[2], t_jac = r[4], h_lu = r[5];
+            CacheRow& R = rows[(size_t)i];
+            double times[4];
+            for (int k = 0; k < 3; ++k) times[k] = t + (h * RCs[k]);
+            times[3] = t_jac;
+            for (int k = 0; k < 4; ++k) {
+                nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, times[k], &R.v.frac[k]);
+                R.v.out[k] = (k < 3) ? fc->C.KV + ((size_t)i * 3 + k) * c->kv_len : nullptr;
+            }
+            vmix_forcing_args(c, 3, times, R.v);
+            R.v.bldmin = c->d.bldepth_min; R.v.y0 = c->d.vmix_log_shallow; R.v.y1 = c->d.vmix_log_deep; R.v.hw = c->d.vmix_half_width;
+            R.cre = MU_REAL / h_lu; R.ccr = MU_CR / h_lu; R.cci = MU_CI / h_lu;
+            FrozenRow& F = fc->frows[(size_t)i];
+            F.mreal = MU_REAL / h; F.mcr = MU_CR / h; F.mci = MU_CI / h;
+            F.n_iter = (int)r[3];
+            int m_real = nk2d_sweeps_for(c, MU_REAL / h_lu), m_cplx = nk2d_sweeps_for(c, MU_CR / h_lu);
+            if (c->min_sweeps > 1 && nk2d_has_lateral(c)) { m_real = std::max(m_real, 2); m_cplx = std::max(m_cplx, 2); }
+            F.m = std::max(m_real, m_cplx);
+            F.x0 = F.x1 = F.x2 = 1.0;
+            if (i + 1 < n) {
+                const double h2 = r[NK2D_SCHED_WIDTH + 2];
+                F.x0 = ((t_new + h2 * RCs[0]) - t) / (t_new - t);
+                F.x1 = ((t_new + h2 * RCs[1]) - t) / (t_new - t);
+                F.x2 = ((t_new + h2 * RCs[2]) - t) / (t_new - t);
+            }
+        }
+        NK2D_CHECK(c, hipMemcpyAsync(fc->rows_dev, rows.data(), sizeof(CacheRow) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(fc->frows_dev, fc->frows.data(), sizeof(FrozenRow) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));    // `rows` leaves scope
+        {
+            const long long tasks = 4LL * c->ny * n;
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_cache_planes<EE>, dim3((unsigned)((tasks + 3) / 4)), dim3(NK2D_BLOCK), 0, c->stream,
+                                                      P, fc->rows_dev, fc->C, (int)n));
+            NK2D_CHECK(c, hipGetLastError());
+            const long long ftasks = 2LL * c->ncol * n;
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_cache_factor<EE, KK>), dim3((unsigned)((ftasks + 3) / 4)), dim3(NK2D_BLOCK), 0,
+                                                               c->stream, P, fc->rows_dev, fc->C, (int)n));
+            NK2D_CHECK(c, hipGetLastError());
+            c->st.nlaunch += 2;
+        }
+        fc->key = key;
+        fc->n = n;
+        c->frozen_cache_builds++;
+    }
+    // ---- the year
+    if (!c->YR_OUT) {
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_PART, sizeof(double) * 2 * c->ncol));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_OUT, sizeof(double) * 32));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 8192));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_MTAB, sizeof(int) * std::max<size_t>(c->rho_tab.size(), 1)));
+        NK2D_CHECK(c, hipHostMalloc((void**)&c->hYR_OUT, sizeof(double) * 32));
+        NK2D_CHECK(c, hipEventCreate(&c->yr_ev[0]));
+        NK2D_CHECK(c, hipEventCreate(&c->yr_ev[1]));
+        c->yr_lin_tol = -1.0;
+        c->yr_rec_cap = 0;
+        c->YR_REC = nullptr;
+    }
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 8192, c->stream));
+    FrozenArgs A = {};
+    A.Y = c->Y; A.YOLD = c->YOLD; A.Z = c->Z; A.ZN = c->ZN; A.W = c->W;
+    A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
+    for (int i = 0; i < 2; ++i) { A.XR[i] = c->XR[i]; A.XCR[i] = c->XCR[i]; A.XCI[i] = c->XCI[i]; }
+    A.PART = c->YR_PART;
+    A.STEP_PART = c->STEP_PART;
+    A.rows = fc->frows_dev;
+    A.C = fc->C;
+    A.n = (int)n;
+    A.arrive = (unsigned*)c->YR_SYNC; A.abort_flag = (int*)((char*)c->YR_SYNC + 4096);
+    A.out = c->YR_OUT;
+    A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
+    A.fences = c->year_fences;
+    void* args[2] = {&P, &A};
+    const int nblk = nk2d_grid(c->ncol);
+    A.tickets = (unsigned*)((char*)c->YR_SYNC + 6144);
+    A.nwg = nblk;
+    const double* o = c->hYR_OUT;
+    bool ran = false;
+    // ---- all of the year's workgroups on ONE XCD (option "frozen_xcd"; at most what an XCD's 32 CUs hold at once)
+    // (one workgroup per CU is what the kernel's registers admit at two levels per lane: an XCD holds 32 of them at once)
+    if (c->frozen_xcd && !c->frozen_xcd_failed && nblk <= 28) {
+        // a workgroup that does not get its partners gives up after 20 ms (the year itself takes less than that per phase)
+        A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
+        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
+        const dim3 grid(8 * nblk + 64);
+        if (c->kind == 2) {
+            NK2D_DISPATCH_E4(c->E, hipLaunchKernelGGL((k_frozen_persistent<EE, 2, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        } else {
+            NK2D_DISPATCH_E4(c->E, hipLaunchKernelGGL((k_frozen_persistent<EE, 0, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A));
+        }
+        NK2D_CHECK(c, hipGetLastError());
+        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        ran = (int)o[0] == 0 && (int64_t)o[1] == n;
+        if (!ran) {
+            // XCD 0 did not get its workgroups (placement is not promised): not again on this context; the state is
+            // where the year started only if nothing ran -- hand the year back to the caller, who restarts it
+            c->frozen_xcd_failed = 1;
+            return 2;
+        }
+        c->frozen_xcd_years++;
+    }
+    if (!ran) {
+        A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
+        hipError_t rc = hipErrorInvalidValue;
+        if (c->kind == 2) {
+            NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 2, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
+        } else {
+            NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 0, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
+        }
+        if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
+        NK2D_CHECK(c, rc);
+        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        if ((int)o[0] != 0 || (int64_t)o[1] != n) return 2;
+    }
+    if ((int)o[2]) std::swap(c->Y, c->YOLD);
+    if ((int)o[3]) std::swap(c->Z, c->ZN);
+    // counters of the year, as the launch-per-phase path books them
+    for (int64_t i = 0; i < n; ++i) {
+        const FrozenRow& F = fc->frows[(size_t)i];
+        c->st.nnewton += F.n_iter; c->st.nfev += 3 * (int64_t)F.n_iter; c->st.nsolve += 2 * (int64_t)F.n_iter;
+        c->st.nsweeps += (int64_t)F.n_iter * F.m;
+    }
+    c->st.nsteps += n - 1;      // the last row's commit is the caller's
+    c->st.njev += n; c->st.nlu += 2 * n;
+    c->st.nlaunch += 1;
     return 0;
 }

@@ -53,6 +53,7 @@ struct Ctl {
     bool pre_jac;        // ... and so was the Jacobian of that attempt (option "jac_stage")
     double pre_t, pre_h;
     double fingerprint;  // nk2d_fingerprint of the context at the start of the year (recorded with every step)
+    bool no_persistent = false;   // the one-launch frozen year was tried and given up for this year
 };
 
 double rms_from_sum(double s, double count) { return std::sqrt(s) / std::sqrt(count); }
@@ -898,6 +899,54 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
     // every shard passes so does the module
     const bool hooked = c->norm_hook != nullptr;
     const double n_unknowns = hooked ? (double)c->tc * c->nz * c->ny : s.n_total;
+    // SciPy's convergence test on the last recorded iteration of the rows from `from` on: the first row that fails, or -1
+    auto first_unconverged = [&](const double* rows, int64_t from) -> int64_t {
+        for (int64_t i = from; i < n; ++i) {
+            const int n_it = (int)rows[i * NK2D_SCHED_WIDTH + 3];
+            if (n_it < 1) continue;
+            const double s_last = sums[3 * i];
+            const double s_prev = (n_it >= 2) ? sums[3 * i + 1] : -1.0;
+            const double n_last = rms_from_sum(s_last, 3.0 * n_unknowns);
+            bool ok = n_last == n_last;
+            if (ok && n_last != 0.0) {
+                if (s_prev >= 0.0) {
+                    const double n_prev = rms_from_sum(s_prev, 3.0 * n_unknowns);
+                    const double rate = (n_prev > 0.0) ? n_last / n_prev : 0.0;
+                    ok = rate < 1.0 && rate / (1.0 - rate) * n_last < slack * s.newton_tol;
+                } else {
+                    ok = n_last < slack * s.newton_tol;   // one iteration: the recorded year's first correction vanished
+                }
+            }
+            if (!ok) return i;
+        }
+        return -1;
+    };
+    auto fetch_sums = [&](int64_t from) -> int {
+        NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART + (size_t)(3 * from) * c->ncol, 3 * (n - from), c->STEP_NORM));
+        NK2D_CHECK(c, hipMemcpyAsync(sums.data() + 3 * from, c->STEP_NORM, sizeof(double) * 3 * (n - from),
+                                     hipMemcpyDeviceToHost, c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    // ---- small grids: the whole year in one launch on the schedule cache (k_frozen_persistent).  Its steps are checked like
+    // any frozen year's; one that does not pass -- or a barrier that timed out -- hands the year back, from x, to the
+    // launch-per-phase path below with its checkpoints and resumes (return 3: the caller restarts the year)
+    if (!s.no_persistent && s.device_ctl == 0) {
+        const int prc = nk2d_frozen_persistent(c, sched, n);
+        if (prc < 0) return prc;
+        if (prc == 0) {
+            const double* r = sched + (n - 1) * NK2D_SCHED_WIDTH;
+            s.t = r[0];
+            NK2D_TRY(commit_step(s, r[0], r[1]));
+            NK2D_TRY(fetch_sums(0));
+            if (first_unconverged(sched, 0) < 0) {
+                c->frozen_persistent_years++;
+                return 0;
+            }
+            return 3;
+        }
+        if (prc == 2) { c->st.nbarrier_timeouts++; return 3; }
+    }
     int64_t start = 0;
     std::vector<char> err_done((size_t)n, 0);
     for (int round = 0;; ++round) {
@@ -929,30 +978,9 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
         // slack: the perturbed state of a finite-difference product converges like the state the schedule was
         // recorded for, give or take; a state that does not (the recorded year converged at once on a special
         // structure, say) must not be integrated with its iteration counts
-        NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART + (size_t)(3 * start) * c->ncol, 3 * (n - start), c->STEP_NORM));
-        NK2D_CHECK(c, hipMemcpyAsync(sums.data() + 3 * start, c->STEP_NORM, sizeof(double) * 3 * (n - start),
-                                     hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-        int64_t bad = -1;
-        std::string why;
-        for (int64_t i = start; i < n && bad < 0; ++i) {
-            const int n_it = (int)cur[i * NK2D_SCHED_WIDTH + 3];
-            if (n_it < 1) continue;
-            const double s_last = sums[3 * i];
-            const double s_prev = (n_it >= 2) ? sums[3 * i + 1] : -1.0;
-            const double n_last = rms_from_sum(s_last, 3.0 * n_unknowns);
-            bool ok = n_last == n_last;
-            if (ok && n_last != 0.0) {
-                if (s_prev >= 0.0) {
-                    const double n_prev = rms_from_sum(s_prev, 3.0 * n_unknowns);
-                    const double rate = (n_prev > 0.0) ? n_last / n_prev : 0.0;
-                    ok = rate < 1.0 && rate / (1.0 - rate) * n_last < slack * s.newton_tol;
-                } else {
-                    ok = n_last < slack * s.newton_tol;   // one iteration: the recorded year's first correction vanished
-                }
-            }
-            if (!ok) { bad = i; why = "the recorded Newton iteration count does not converge for this state"; }
-        }
+        NK2D_TRY(fetch_sums(start));
+        const int64_t bad = first_unconverged(cur, start);
+        const std::string why = "the recorded Newton iteration count does not converge for this state";
         // the sampled error estimates (not with a norm hook: a shard sees only its own tracers' share)
         double max_err = 0.0;
         int64_t bad_err = -1;
@@ -1063,24 +1091,48 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     // (a schedule this library recorded itself under the same inner tolerance -- the frozen-controller year of a
     // finite-difference product -- repeats the recorded year's own solves: replay_own)
     if (replay && !replay_own) c->d.lin_tol = std::min(c->d.lin_tol, 1.0e-3);
-    NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
     if (s.t1 > s.t) {
-        // f = fun(t0, y0);  J = jac(t0, y0)
-        NK2D_TRY(eval_kv(c, s.t, 3));
-        NK2D_TRY(nk2d_k_tend(c, c->Y, c->KV[3], c->F));
-        c->st.nfev++;
-        if (!replay) NK2D_TRY(initial_step(s, &s.h_abs));
-        NK2D_TRY(refresh_jac(s, s.t, true));
-        c->st.njev = 1;
-        s.current_jac = true;
+        // y = x; f = fun(t0, y0); first step size; J = jac(t0, y0)
+        auto start_year = [&]() -> int {
+            NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_TRY(eval_kv(c, s.t, 3));
+            NK2D_TRY(nk2d_k_tend(c, c->Y, c->KV[3], c->F));
+            c->st.nfev++;
+            if (!replay) NK2D_TRY(initial_step(s, &s.h_abs));
+            NK2D_TRY(refresh_jac(s, s.t, true));
+            c->st.njev = 1;
+            s.current_jac = true;
+            return 0;
+        };
+        NK2D_TRY(start_year());
         bool stepped = false;
         if (persistent) {
             const int rc = nk2d_year_persistent(c, s.h_abs, s.newton_tol, s.max_step, s.n_total, record, record_cap, record_n);
             if (rc < 0) return rc;
             stepped = rc == 0;      // 1: the grid does not fit the chip at once -- host control below
+            if (rc == 2) {
+                // a grid barrier timed out: the same year again from x, under host control
+                c->st = nk2d_stats();
+                c->st.nbarrier_timeouts = 1;
+                s.t = c->d.t0;
+                s.have_lu = false; s.have_dense = false;
+                s.has_old_h = s.has_old_err = false;
+                NK2D_TRY(start_year());
+            }
         }
         if (stepped) {}
-        else if (replay) NK2D_TRY(run_replay(s, replay, replay_n, replay_own));
+        else if (replay) {
+            int rrc = run_replay(s, replay, replay_n, replay_own);
+            if (rrc == 3) {
+                // the one-launch year of a small grid was given up: the same year from x, launch by launch
+                s.no_persistent = true;
+                s.t = c->d.t0;
+                s.have_lu = false; s.have_dense = false; s.pre_setup = false;
+                NK2D_TRY(start_year());
+                rrc = run_replay(s, replay, replay_n, replay_own);
+            }
+            if (rrc != 0) return rrc;
+        }
         else NK2D_TRY(run_free(s, record, record_cap, record_n));
         NK2D_TRY(nk2d_r_final(c, (const double*)x, (double*)fx));
     } else {

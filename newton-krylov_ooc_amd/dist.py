@@ -32,34 +32,37 @@ def _dist():
 class _AllFlag:
     """what `.all()` is called on: AND over the local (module, region) flags and over ranks"""
 
-    def __init__(self, flags, buf):
+    def __init__(self, flags, buf, group=None):
         self._flags = np.asarray(flags)
         self._buf = buf
+        self._group = group
 
     def all(self):
         local = bool(self._flags.all())
         dist = _dist()
-        if dist is None or dist.get_world_size() == 1:
+        if dist is None or dist.get_world_size(self._group) == 1:
             return local
         # the solver's one flag tensor, allocated once (on the GPU for nccl = RCCL, on the host for gloo)
         self._buf.fill_(1 if local else 0)
-        dist.all_reduce(self._buf, op=dist.ReduceOp.MIN)
+        dist.all_reduce(self._buf, op=dist.ReduceOp.MIN, group=self._group)
         return bool(self._buf.item())
 
 
 class DistributedKrylovSolver(KrylovSolver):
     """KrylovSolver over the LOCAL tracer modules with a global stopping test"""
 
-    def __init__(self, iterate, solverinfo, resume, rewind, hist_fname, device=None):
+    def __init__(self, iterate, solverinfo, resume, rewind, hist_fname, device=None, group=None):
+        """group: the ranks that hold the modules of this solve (default: all)"""
         super().__init__(iterate, solverinfo, resume, rewind, hist_fname)
         self._flag_buf = None
+        self._group = group
         if _dist() is not None:
             import torch
 
             self._flag_buf = torch.zeros(1, dtype=torch.int32, device=device if device is not None else "cpu")
 
     def converged(self, beta, precond_resid_norm):
-        return _AllFlag(super().converged(beta, precond_resid_norm), self._flag_buf)
+        return _AllFlag(super().converged(beta, precond_resid_norm), self._flag_buf, self._group)
 
 
 def init_process_group_from_env(backend):
@@ -96,8 +99,14 @@ class ShardComm:
 
         self._torch = torch
         self._group = group
+        # everything a call needs exists beforehand: the tensor the collective works on (in HBM for nccl = RCCL, on the
+        # host for gloo) and, for a device tensor, ONE pinned host staging buffer with a NumPy view -- no tensor is
+        # created, no pageable copy made per call (these collectives are 8 ... a few hundred bytes: their fixed cost is all
+        # there is)
         self._buf = torch.zeros(capacity, dtype=torch.float64, device=device)
-        self._host = torch.zeros(capacity, dtype=torch.float64).pin_memory() if str(device) != "cpu" else None
+        self._on_device = str(device) != "cpu"
+        self._stage = torch.zeros(capacity, dtype=torch.float64).pin_memory() if self._on_device else self._buf
+        self._stage_np = self._stage.numpy()
         self.calls = 0
 
     def allreduce(self, arr):
@@ -106,15 +115,29 @@ class ShardComm:
         if dist is None or dist.get_world_size(self._group) == 1:
             return arr.copy()
         n = arr.size
-        flat = self._torch.from_numpy(np.ascontiguousarray(arr).reshape(-1))
+        self._stage_np[:n] = arr.reshape(-1)
         view = self._buf[:n]
-        view.copy_(flat)
+        if self._on_device:
+            view.copy_(self._stage[:n], non_blocking=True)
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self._group)
+        if self._on_device:
+            self._stage[:n].copy_(view)          # waits for the collective on torch's stream
         self.calls += 1
-        return view.cpu().numpy().reshape(arr.shape).copy()
+        return self._stage_np[:n].reshape(arr.shape).copy()
 
     def allreduce_scalar(self, val):
-        return float(self.allreduce(np.array([val]))[0])
+        dist = _dist()
+        if dist is None or dist.get_world_size(self._group) == 1:
+            return float(val)
+        self._stage_np[0] = val
+        view = self._buf[:1]
+        if self._on_device:
+            view.copy_(self._stage[:1], non_blocking=True)
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self._group)
+        if self._on_device:
+            self._stage[:1].copy_(view)
+        self.calls += 1
+        return float(self._stage_np[0])
 
 
 def iage_shard_engine(grid, shard, comm, device_id=0, **kwargs):
@@ -212,3 +235,158 @@ def sharded_gmres(eng, comm, x, fx, rel_tol, min_iter, max_iter, sched=None):
         basis.append(eng.scale(w, 1.0 / hess[0, j, j - 1, :]))
     return approx, {"beta": beta, "h_mat": hess[0], "resid_norm": np.array(resid_norms), "iters": j,
                     "allreduces": comm.calls}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Level 3 of SURVEY.md section 8(e): the columns of the Krylov basis sharded over ranks (BASELINE configs[4]).
+#
+# The reference keeps every Arnoldi vector v_i and every preconditioned product W_i in a file of its own and walks
+# through them in mod_gram_schmidt (nk_ooc/model_state_base.py:365-377) and lin_comb (:619-624).  Here column i lives in
+# the HBM of rank i mod G; the state x, F(x) and the preconditioner are replicated.  Per Krylov iteration j:
+#   * the owner of v_j computes w = M^-1 J v_j (one perturbed year) and BROADCASTS it (N doubles over xGMI);
+#   * Gram-Schmidt, classical and twice (CGS-2): every rank forms the inner products with ITS columns in one fused
+#     multi-dot, the (j + 1) nreg numbers are all-reduced (a gather by zero padding), every rank forms the partial sum
+#     of its columns, the partial sums are all-reduced (N doubles) and subtracted everywhere;
+#   * the preconditioned residual sum_i c_i W_i + M^-1 F: local partial sums + one all-reduce of N doubles; the iterate
+#     x_j = sum_i c_i v_i likewise, once, when the solve ends.
+# Nothing of the product is shared out: the layout buys HBM (a basis that does not fit one GPU), not time -- at these
+# sizes (all vectors of a solve fit one GPU's Infinity Cache) the collectives are pure overhead, and bench.py reports the
+# scaling it measures, which is flat to negative.
+# ---------------------------------------------------------------------------------------------------
+class ColumnComm(ShardComm):
+    """ShardComm + whole-vector collectives on engine vectors: zero-copy on device tensors (RCCL) where the engine hands out
+    a tensor view of its HBM (`vec_tensor`), through host arrays otherwise (gloo rehearsals, NumPy stand-in engines)"""
+
+    def __init__(self, rank, size, device="cpu", group=None, capacity=4096):
+        super().__init__(device=device, group=group, capacity=capacity)
+        self.rank, self.size = rank, size
+        self.device = device
+        self.vec_calls = 0
+        self.vec_bytes = 0
+
+    def allreduce(self, arr):
+        if self.size == 1:
+            return np.asarray(arr, dtype=np.float64).copy()
+        return super().allreduce(arr)
+
+    def _global(self, rank):
+        dist = _dist()
+        return rank if self._group is None else dist.get_global_rank(self._group, rank)
+
+    def _view(self, eng, vec):
+        """(tensor, write_back): a tensor the collective can work on in place"""
+        if str(self.device) != "cpu" and hasattr(eng, "vec_tensor"):
+            eng.sync()
+            return eng.vec_tensor(vec), None
+        host = np.ascontiguousarray(eng.download(vec))
+        return self._torch.from_numpy(host.reshape(-1)), host
+
+    def _done(self, eng, vec, tensor, host):
+        if host is None:
+            self._torch.cuda.current_stream(tensor.device).synchronize()
+        else:
+            eng.upload(host, out=vec)
+        self.vec_calls += 1
+        self.vec_bytes += tensor.numel() * 8
+
+    def bcast_vec(self, eng, vec, src):
+        dist = _dist()
+        if dist is None or self.size == 1:
+            return vec
+        tensor, host = self._view(eng, vec)
+        dist.broadcast(tensor, src=self._global(src), group=self._group)
+        self._done(eng, vec, tensor, host)
+        return vec
+
+    def allreduce_vec(self, eng, vec):
+        dist = _dist()
+        if dist is None or self.size == 1:
+            return vec
+        tensor, host = self._view(eng, vec)
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self._group)
+        self._done(eng, vec, tensor, host)
+        return vec
+
+
+def column_sharded_gmres(eng, comm, x, fx, rel_tol, min_iter, max_iter, sched=None):
+    """KrylovSolver.solve (nk_ooc/krylov_solver.py:85-165) with basis column i and product W_i on rank i mod comm.size
+    (see above); every rank holds the whole module (x, fx, preconditioner) and returns the same increment and numbers.
+    `sched`: the accepted steps of the year behind fx on THIS rank's engine (the products repeat them)."""
+    from .krylov_solver import least_squares_coeffs
+
+    rank, size = comm.rank, comm.size
+    zero = eng.scale(x, 0.0)
+
+    def product(direction):
+        sigma = 1.0e-4 * np.sqrt(eng.dot(x, x))
+        sigma = np.where(sigma == 0.0, 1.0, sigma)
+        perturbed = eng.axpby(1.0, x, sigma, direction)
+        fpert = None
+        if sched is not None and len(sched) > 0:
+            from .engine import Nk2dFrozenMismatch, Nk2dScheduleMismatch
+
+            try:
+                fpert, _ = eng.comp_fcn_frozen(perturbed, sched)
+            except (Nk2dFrozenMismatch, Nk2dScheduleMismatch):
+                fpert = None
+        if fpert is None:
+            fpert, _, _ = eng.comp_fcn(perturbed)
+        return eng.precond_apply(eng.diff_scale(fpert, fx, 1.0 / sigma))
+
+    def local_part(store, coeff_of, fill):
+        """- sum over this rank's columns i of bcast(coeff_of(i)) store[i]  (one fused launch; zero without columns)"""
+        part = eng.scale(zero, 1.0)
+        cols = sorted(store)
+        if cols:
+            eng.multi_axpy(part, [store[i] for i in cols], np.stack([coeff_of(i) for i in cols]), fill=fill)
+        return part
+
+    r0 = eng.precond_apply(fx)
+    beta = np.sqrt(eng.dot(r0, r0))
+    basis, prods = {}, {}
+    if rank == 0:
+        basis[0] = eng.scale(r0, -(1.0 / beta))
+    hess = np.zeros((1, 1, 0, eng.nreg))
+    resid_norms = []
+    coeff = None
+    j = 0
+    while True:
+        owner = j % size
+        w = product(basis[j]) if rank == owner else eng.scale(zero, 1.0)
+        comm.bcast_vec(eng, w, owner)
+        if rank == owner:
+            prods[j] = w.copy()
+        # CGS-2 against the j + 1 columns spread over the ranks
+        h_tot = np.zeros((j + 1, eng.nreg))
+        for sweep in range(2):
+            h_loc = np.zeros((j + 1, eng.nreg))
+            cols = sorted(basis)
+            if cols:
+                h_loc[cols] = eng.multi_dot(w, [basis[i] for i in cols])
+            h_val = comm.allreduce(h_loc)
+            # cells outside every region: the reference subtracts each basis vector once there (region broadcast fills 1.0,
+            # tracer_module_state_base.py:502-515) -- the first pass does that
+            part = local_part(basis, lambda i: h_val[i], 1.0 if sweep == 0 else 0.0)
+            comm.allreduce_vec(eng, part)
+            eng.axpby(1.0, w, 1.0, part, out=w)
+            h_tot += h_val
+        grown = np.zeros((1, j + 2, j + 1, eng.nreg))
+        grown[:, : j + 1, :j, :] = hess
+        grown[0, : j + 1, j, :] = h_tot
+        grown[0, j + 1, j, :] = np.sqrt(eng.dot(w, w))
+        hess = grown
+        coeff = least_squares_coeffs(beta[np.newaxis], hess)[0]
+        resid = local_part(prods, lambda i: -coeff[i], 1.0)
+        comm.allreduce_vec(eng, resid)
+        eng.axpby(1.0, resid, 1.0, r0, out=resid)
+        resid_norms.append(np.sqrt(eng.dot(resid, resid)))
+        j += 1
+        if (j >= min_iter and (resid_norms[-1] < rel_tol * beta).all()) or j >= max_iter:
+            break
+        if rank == j % size:
+            basis[j] = eng.scale(w, 1.0 / hess[0, j, j - 1, :])
+    approx = local_part(basis, lambda i: -coeff[i], 1.0)
+    comm.allreduce_vec(eng, approx)
+    return approx, {"beta": beta, "h_mat": hess[0], "resid_norm": np.array(resid_norms), "iters": j,
+                    "allreduces": comm.calls, "vector_collectives": comm.vec_calls, "vector_bytes": comm.vec_bytes,
+                    "columns_here": sorted(basis)}

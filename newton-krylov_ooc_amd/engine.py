@@ -117,6 +117,7 @@ class ModuleEngine:
         self.nz = len(grid.depth)
         self.ny = len(grid.ypos)
         self.tc = int(tc)
+        self._device_id = int(device_id)
         self.shape = (self.tc, self.nz, self.ny)
         self.nreg = 1
         desc = _lib.Desc()
@@ -243,6 +244,22 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_vec_download(self._ctx, vec.ptr, _dp(host)))
         return host
 
+    def vec_tensor(self, vec):
+        """zero-copy torch tensor over the HBM of a state vector (flat, the library's packed column layout): for collectives
+        that are elementwise over whole vectors (dist.ColumnComm).  The caller orders the engine's stream against torch's."""
+        import torch
+
+        nv = self.tc * self.ny * ((self.nz + 63) // 64) * 64
+
+        class _Holder:
+            pass
+
+        holder = _Holder()
+        holder.__cuda_array_interface__ = {"shape": (nv,), "typestr": "<f8", "data": (int(vec.ptr.value), False),
+                                           "version": 2, "strides": None}
+        holder._keep = vec
+        return torch.as_tensor(holder, device=torch.device("cuda", self._device_id))
+
     def set_option(self, name, value):
         self._chk(self._lib.nk2d_set_option(self._ctx, name.encode(), float(value)))
         if name == "device_ctl":
@@ -339,6 +356,12 @@ class ModuleEngine:
         """how many frozen years of this engine were resumed from a checkpoint with one more Newton iteration so far"""
         n = ctypes.c_int64(0)
         self._chk(self._lib.nk2d_frozen_resumes(self._ctx, ctypes.byref(n)))
+        return n.value
+
+    def counter(self, name):
+        """library counters by name: frozen_persistent_years, frozen_cache_builds, frozen_fallbacks, frozen_resumes"""
+        n = ctypes.c_int64(0)
+        self._chk(self._lib.nk2d_get_counter(self._ctx, name.encode(), ctypes.byref(n)))
         return n.value
 
     def schedule_fingerprint(self):

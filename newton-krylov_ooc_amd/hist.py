@@ -15,6 +15,10 @@ from . import ncio
 from .grid import BLDEPTH_MIN, bldepth_time_knots
 
 
+def hist_stamp():
+    return ncio.history_stamp(f"{__name__}._gen_hist")
+
+
 def time_mean_weights(ntime):
     """trapezoid in time: t = 0 and t = end are both in the file"""
     weights = np.full(ntime, 1.0 / (ntime - 1))
@@ -127,16 +131,136 @@ def units_conversion_factor(units_from, units_to):
     return src[0] / dst[0]
 
 
-def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):
+def tracer_var_attrs(attrs, tname, label="", unit=None):
+    """attributes of a tracer-like history variable, in the order the file holds them"""
+    var_attrs = dict(attrs)
+    var_attrs["long_name"] = attrs.get("long_name", tname) + label
+    var_attrs["units"] = attrs.get("units", "1") if unit is None else unit
+    return var_attrs
+
+
+class HistWriter:
+    """History files are written on a background thread: a file is 423 MB at 416 x 416 (the 61 samples of every tracer,
+    their anomalies, the mixing coefficient), a second of reductions and big-endian conversion that nothing on the Newton
+    level waits for -- what the solvers need from a history (its time axis for the preconditioner file, the tracer samples
+    for the statistics) is served from the record kept in memory.  Everything that touches a history file BY NAME goes
+    through here: `wait` before reading, `remove` / `rename` instead of os.remove / os.rename."""
+
+    KEEP = 3      # records kept in memory (about 170 MB each at 416 x 416 with two tracers)
+
+    def __init__(self):
+        self._pool = None
+        self._pending = {}
+        self._records = {}
+
+    def submit(self, fname, grid, time, module_hists, vmix_samples, stamp, background=True):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        key = os.path.abspath(fname)
+        self.wait(fname)
+        self._records.pop(key, None)
+        self._records[key] = {"time": np.array(time), "module_hists": module_hists, "stamp": stamp}
+        while len(self._records) > self.KEEP:
+            self._records.pop(next(iter(self._records)))
+        if not background:
+            write_hist_file(fname, grid, time, module_hists, vmix_samples, stamp)
+            return
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="nk2d-hist")
+        # at most two files in flight: a third submit waits for the oldest (bounds the host memory held by the queue)
+        while len(self._pending) >= 2:
+            self.wait(next(iter(self._pending)))
+        self._pending[key] = self._pool.submit(write_hist_file, fname, grid, time, module_hists, vmix_samples, stamp)
+
+    def wait(self, fname=None):
+        import os
+
+        keys = list(self._pending) if fname is None else [os.path.abspath(fname)]
+        for key in keys:
+            fut = self._pending.pop(key, None)
+            if fut is not None:
+                fut.result()
+
+    def record(self, fname):
+        import os
+
+        return self._records.get(os.path.abspath(fname)) if fname is not None else None
+
+    def tracer_samples(self, fname, names):
+        """{tracer name: (samples [ntime, nz, ny], attributes as the file holds them)} of a history kept in memory, or None"""
+        rec = self.record(fname)
+        if rec is None:
+            return None
+        out = {}
+        for tracers, hist in rec["module_hists"]:
+            for ind, (tname, attrs) in enumerate(tracers.items()):
+                if tname in names:
+                    var_attrs = tracer_var_attrs(attrs, tname)
+                    var_attrs["cell_methods"] = "time: point"
+                    out[tname] = (hist[:, ind], var_attrs)
+        return out if len(out) == len(names) else None
+
+    def _queue(self, key, job):
+        """a file operation behind whatever the writer's thread still has to do (one thread: jobs run in the order given)"""
+        if self._pool is None or not self._pending:
+            job()
+        else:
+            self._pending.pop(key, None)
+            self._pending[key] = self._pool.submit(job)
+
+    def remove(self, fname):
+        import os
+
+        key = os.path.abspath(fname)
+        self._records.pop(key, None)
+
+        def job():
+            if os.path.exists(fname):
+                os.remove(fname)
+
+        self._queue(key, job)
+
+    def rename(self, src, dst):
+        """src -> dst once src is written (queued behind it: the caller does not wait for a file it only renames)"""
+        import os
+
+        ksrc, kdst = os.path.abspath(src), os.path.abspath(dst)
+        rec = self._records.pop(ksrc, None)
+        self._records.pop(kdst, None)
+        if rec is not None:
+            self._records[kdst] = rec
+        was_pending = ksrc in self._pending
+
+        def job():
+            if os.path.exists(src):
+                os.rename(src, dst)
+
+        if was_pending:
+            # whoever waits for src or dst now waits for the rename
+            self._pending.pop(ksrc, None)
+            self._pending.pop(kdst, None)
+            self._pending[kdst] = self._pool.submit(job)
+        else:
+            self.wait(dst)
+            job()
+
+    def forget(self):
+        self.wait()
+        self._records.clear()
+
+
+def write_hist_file(fname, grid, time, module_hists, vmix_coeff, stamp=None):
     """module_hists: list of (tracer metadata dict name -> attrs, hist [ntime, tc, nz, ny]);
-    vmix_coeff_fcn(t) -> (nz-1, ny) mixing coefficient / dz_mid"""
+    vmix_coeff: the (nz-1, ny) mixing coefficient / dz_mid at every time [ntime, nz-1, ny], or a function of t returning one;
+    stamp: the history attribute (made by the caller when the file is written later than it is asked for)"""
     depth, ypos = grid.depth, grid.ypos
     dname, yname = depth.axisname, ypos.axisname
     dedge, yedge = depth.dump_names["edges"], ypos.dump_names["edges"]
     ntime = len(time)
     weights = time_mean_weights(ntime)
     with netcdf_file(fname, "w", version=2) as fptr:
-        fptr.history = ncio.history_stamp(f"{__name__}._gen_hist")
+        fptr.history = stamp if stamp is not None else hist_stamp()
         fptr.createDimension("time", None)
         for axis in (depth, ypos):
             for dimname, dimlen in axis.dump_dimensions().items():
@@ -178,10 +302,7 @@ def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):
                     ("_depth_ypos_int", ("time",), ", depth-ypos integral",
                      _units_product(units, depth.units, ypos.units)),
                 ):
-                    var_attrs = dict(attrs)
-                    var_attrs["long_name"] = attrs.get("long_name", tname) + label
-                    var_attrs["units"] = unit
-                    defvar(tname + suffix, dims, var_attrs)
+                    defvar(tname + suffix, dims, tracer_var_attrs(attrs, tname, label, unit))
 
         # ---- values
         fptr.variables["time"][:] = time
@@ -200,7 +321,8 @@ def write_hist_file(fname, grid, time, module_hists, vmix_coeff_fcn):
         fptr.variables["bldepth"][:] = bld
         vmix = np.empty((ntime, len(depth) + 1, len(ypos)))
         for ind, t in enumerate(time):
-            vmix[ind, 1:-1, :] = vmix_coeff_fcn(t) * depth.delta_mid[:, np.newaxis]
+            coeff = vmix_coeff(t) if callable(vmix_coeff) else vmix_coeff[ind]
+            vmix[ind, 1:-1, :] = coeff * depth.delta_mid[:, np.newaxis]
         vmix[:, 0, :] = vmix[:, 1, :]
         vmix[:, -1, :] = vmix[:, -2, :]
         fptr.variables["vert_mixing_coeff"][:] = vmix

@@ -212,12 +212,22 @@ class ModelState:
                             # without the files on disk (write_files=False: a dropped name cannot be re-opened)
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
     _precond_state = {}     # precond file -> {module name: linearisation field}
+    hist_writer = hist_mod.HistWriter()      # history files are written on a background thread (hist.HistWriter)
+    # off: comp_fcn returns with its history file on disk (the reference's contract, for callers that open the file
+    # themselves); the driver mirror and the set-up, which reach history files only through this class, switch it on
+    async_hist = os.environ.get("NK2D_ASYNC_HIST", "0") == "1"
     last_stats = None       # stats of the most recent comp_fcn, per module
     last_jvp_mode = None    # "frozen" / "free_running": how the most recent finite-difference product ran its perturbed year
 
     # ---- class-level set-up (py_driver_2d/model_state.py:44-65) -----------------------
     @classmethod
+    def flush_files(cls):
+        """every history file asked for so far is on disk when this returns"""
+        cls.hist_writer.wait()
+
+    @classmethod
     def reset_class(cls):
+        cls.hist_writer.forget()
         if cls._engines:
             for eng in cls._engines.values():
                 eng.close()
@@ -530,8 +540,12 @@ class ModelState:
             if frozen is None:
                 scheds[tms.name] = tms.eng.last_schedule()
         if hist_fname is not None and self.write_files:
-            hist_mod.write_hist_file(hist_fname, self._grid, t_eval, hists,
-                                     self.tracer_modules[0].eng.vmix_coeff)
+            # the mixing coefficient samples come from the engine (not thread safe): here; the file itself -- reductions,
+            # byte order, 423 MB at 416 x 416 -- on the writer's thread, with the stamp of now
+            eng0 = self.tracer_modules[0].eng
+            vmix_samples = np.stack([eng0.vmix_coeff(t) for t in t_eval])
+            self.hist_writer.submit(hist_fname, self._grid, t_eval, hists, vmix_samples, hist_mod.hist_stamp(),
+                                    background=self.async_hist)
         type(self).last_stats = stats
         res_ms = self._new(mods)
         res_ms._sched = scheds if frozen is None else None
@@ -551,6 +565,7 @@ class ModelState:
             solver_state.log_step(fcn_complete_step)
             modelinfo = self.model_config_obj.modelinfo
             if _strtobool(modelinfo.get("reinvoke", "False")):
+                self.flush_files()        # the process that resumes reads what this one wrote
                 cmd = [modelinfo["invoker_script_fname"], "--resume"]
                 logger.info('cmd="%s"', " ".join(cmd))
                 subprocess.Popen(cmd)
@@ -593,7 +608,15 @@ class ModelState:
             time_attrs = {"long_name": "time", "units": "seconds since 0001-01-01", "calendar": "noleap"}
             dims, variables = {}, {}
             history = ncio.history_stamp(f"{_class_name(self)}.gen_precond_jacobian")
-            if hist_fname is not None and os.path.exists(hist_fname):
+            rec = self.hist_writer.record(hist_fname)
+            wanted = self.hist_vars_for_precond_list() if hist_fname is not None else []
+            if rec is not None and wanted == ["time"]:
+                # all the preconditioner file takes from this history is its time axis: from the record in memory, with
+                # the attributes the history file gives it (the file itself may still be on its way to the disk)
+                dims["time"] = len(rec["time"])
+                variables["time"] = (("time",), ">f8", time_attrs, rec["time"])
+                history = "\n".join([history, rec.get("stamp", "")]) if rec.get("stamp") else history
+            elif hist_fname is not None and (self.hist_writer.wait(hist_fname) or os.path.exists(hist_fname)):
                 wanted = self.hist_vars_for_precond_list()
                 data, attrs = ncio.read_file(hist_fname, [name.partition(":")[0] for name in wanted])
                 if "history" in attrs:
@@ -760,9 +783,13 @@ class ModelState:
         for axis in (self.depth, self.ypos):
             dims.update(axis.dump_dimensions())
             vars_metadata.update(axis.dump_vars_metadata())
+        names = [tname for tms in self.tracer_modules for tname in tms.tracer_names]
+        mem = self.hist_writer.tracer_samples(hist_fname, names)
+        if mem is None:
+            self.hist_writer.wait(hist_fname)
         for tms in self.tracer_modules:
             for tname in tms.tracer_names:
-                attrs = ncio.read_var_attrs(hist_fname, tname)
+                attrs = dict(mem[tname][1]) if mem is not None else ncio.read_var_attrs(hist_fname, tname)
                 attrs.pop("cell_methods", None)
                 vars_metadata[tname] = {
                     "dimensions": ("iteration", self.depth.axisname, self.ypos.axisname), "attrs": attrs}
@@ -789,7 +816,12 @@ class ModelState:
         if solver_state is not None and solver_state.step_logged(step):
             return
         names = [tname for tms in self.tracer_modules for tname in tms.tracer_names]
-        data, _ = ncio.read_file(hist_fname, names)
+        mem = self.hist_writer.tracer_samples(hist_fname, names)
+        if mem is not None:
+            data = {tname: vals for tname, (vals, _) in mem.items()}     # the samples the file is being written from
+        else:
+            self.hist_writer.wait(hist_fname)
+            data, _ = ncio.read_file(hist_fname, names)
         weights = hist_mod.time_mean_weights(next(iter(data.values())).shape[0])
         ypos_weights = self.ypos.delta / self.ypos.delta.sum()
         vals = {}

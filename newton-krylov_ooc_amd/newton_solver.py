@@ -80,9 +80,21 @@ class _Ledger:
         self._st.set_value_saved_state(key=key, value=value)
 
 
-def _drop(fname):
-    if os.path.exists(fname):
+def _drop(fname, state_cls=None):
+    """remove a history file; one that is still being written (the state class's background writer) first completes"""
+    writer = getattr(state_cls, "hist_writer", None)
+    if writer is not None:
+        writer.remove(fname)
+    elif os.path.exists(fname):
         os.remove(fname)
+
+
+def _rename(src, dst, state_cls=None):
+    writer = getattr(state_cls, "hist_writer", None)
+    if writer is not None:
+        writer.rename(src, dst)         # (behind the write of src, if that is still on its way)
+    elif os.path.exists(src):
+        os.rename(src, dst)
 
 
 def _stats_entry(category, long_name, units, **extra):
@@ -200,7 +212,7 @@ class NewtonSolver(SolverBase):
             cand.dump(cand_fname, f"{self._who}._comp_next_iterate")
             cand_fcn = cand.comp_fcn(fcn_fname, self._solver_state, hist_fname)
             if ind > 0:
-                _drop(files.line_search(ind - 1)[2])      # only the latest line-search history is kept
+                _drop(files.line_search(ind - 1)[2], state_cls)      # only the latest line-search history is kept
             logger.info("Armijo_ind=%d", ind)
             cand_norm = cand_fcn.norm()
             increment.log_vals(["ArmijoFactor", "fcn_norm", "prov_fcn_norm"],
@@ -234,12 +246,11 @@ class NewtonSolver(SolverBase):
         line_hist = files.line_search(book.recall("armijo_ind"))[2]
         if cand.shadow_tracers_on():
             cand_fcn = cand.comp_fcn(fp_fcn_fname, self._solver_state, fp_hist_fname)
-            _drop(line_hist)
+            _drop(line_hist, type(cand))
         else:
             # the accepted line-search evaluation IS the first fixed-point evaluation
             cand_fcn.dump(fp_fcn_fname, caller)
-            if os.path.exists(line_hist):
-                os.rename(line_hist, fp_hist_fname)
+            _rename(line_hist, fp_hist_fname, type(cand))
         book.mark(MARK_FP_STARTED)
         return cand, cand_fcn
 

@@ -55,7 +55,24 @@ def run(config, resume=False, rewind=False, model_state_class=ModelState):
         raise SystemExit
     model_state_class.reset_class()
     model_state_class.model_config_obj = ModelConfig(config["modelinfo"])
-    solver = NewtonSolver(model_state_class, solverinfo=config["solverinfo"], resume=resume, rewind=rewind)
+    # history files on a background thread while the driver runs (every access to them goes through the state class);
+    # NK2D_ASYNC_HIST=0 keeps them synchronous
+    was_async = getattr(model_state_class, "async_hist", None)
+    if was_async is not None:
+        model_state_class.async_hist = os.environ.get("NK2D_ASYNC_HIST", "1") != "0"
+    try:
+        solver = NewtonSolver(model_state_class, solverinfo=config["solverinfo"], resume=resume, rewind=rewind)
+        return _iterate(solver, model_state_class, logger)
+    finally:
+        # also on an exception (or the SystemExit of a reinvoked run): no history file is left half written
+        flush = getattr(model_state_class, "flush_files", None)
+        if flush is not None:
+            flush()
+        if was_async is not None:
+            model_state_class.async_hist = was_async
+
+
+def _iterate(solver, model_state_class, logger):
     while True:
         if solver.converged().all():
             logger.info("Newton convergence criterion satisfied")

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from nk_ooc_amd.dist import partition_modules
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,3 +63,25 @@ def test_sharded_module_reductions_gloo(tmp_path):
     assert out[0]["dot_err"] < 1e-14 and out[0]["h_err"] < 1e-12 and out[0]["ortho"] < 1e-14
     assert out[0]["allreduces"] == 1 + 2 + 1     # dot, CGS-2 (two passes), final check
     assert out[0]["gmres_resid_drop"] < 0.5 and out[0]["gmres_allreduces_per_iter"] <= 6.0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_sharded_gmres_gloo(tmp_path, world):
+    """SURVEY.md section 8(e) level 3 on the CPU (BASELINE configs[4]): the Krylov basis columns dealt round-robin to 2 and 4
+    ranks -- broadcast of the product, gathered projections, all-reduced partial sums -- against the same loop on one rank"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29535 + world),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "columns"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = [json.load(open(tmp_path / f"columns{r}.json")) for r in range(world)]
+    for rank, o in enumerate(out):
+        assert o["iters"] == 6 and o["alone_collectives"] == 0
+        # basis columns 0..5 (the last product's direction is never stored) round-robin
+        assert o["columns_here"] == [i for i in range(6) if i % world == rank]
+        assert o["h_err"] < 1e-12 and o["resid_err"] < 1e-12 and o["inc_err"] < 1e-11
+        assert o["resid_drop"] < 0.2
+        # per Krylov iteration: 2 small all-reduces (CGS-2 projections) and 1 broadcast + 3 all-reduces of whole vectors
+        assert o["small_allreduces_per_iter"] == 2.0 and o["vector_collectives_per_iter"] == 4.0
+    assert all(o["h_err"] == out[0]["h_err"] for o in out)

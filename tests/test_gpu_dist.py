@@ -46,6 +46,24 @@ def _check_two_rank_line(stdout, backend, check_shard=True):
     for key in ("roofline", "metric", "unit", "ms_per_step", "dtype", "end_to_end"):
         assert key in out
     assert "cpu_baseline" not in out and "ladder" not in out   # rank 0 of single-GPU runs only
+    # both products as top-level figures (round-2 ADVICE): frozen years (the default, = value) and the reference's two
+    # free-running years, measured in the same run
+    assert out["value_frozen"] == out["value"] and 0.0 < out["value_reference_semantic"] < out["value"] * 1.5
+    assert "frozen" in out["metric"] and "roofline_year" in out
+    # BASELINE.json configs[3]: the three-module mix on one GPU and dealt round-robin to the two ranks
+    mix = out["config4_mix"]
+    assert mix["modules"] == ["iage", "phosphorus", "forced_dye"] and mix["one_gpu"]["ms_per_krylov_iteration"] > 0.0
+    assert mix["distributed"]["ranks_used"] == 2
+    assert mix["distributed"]["layout"] == {"rank0": ["iage", "forced_dye"], "rank1": ["phosphorus"]}
+    assert out["strong_scaling"]["n_gpus_used"] == 2 and out["strong_scaling"]["speedup"] > 0.0
+    for counters in mix["one_gpu"]["counters"].values():
+        assert counters["frozen_years_rejected"] == 0
+    # BASELINE.json configs[4]: phosphorus with its Krylov basis columns on the two ranks
+    e3 = out["shard_e3"]
+    assert e3["sharded"]["ranks"] == 2 and e3["sharded"]["ms_per_jvp"] > 0.0 and e3["one_gpu"]["ms_per_jvp"] > 0.0
+    # per Krylov iteration one broadcast and three all-reduces of whole vectors (+ one for the iterate at the end), two small ones
+    assert 4.0 <= e3["sharded"]["vector_collectives_per_jvp"] <= 5.0 and e3["sharded"]["small_allreduces_per_jvp"] == 2.0
+    assert e3["frozen_years_rejected"] == 0
     # SURVEY.md section 8(e) level 2, measured in the same run: ONE module, tracer per rank
     if check_shard:
         shard = out["shard_e2"]

@@ -1,0 +1,159 @@
+"""The frozen year of a small grid as ONE launch on a schedule cache (k_frozen_persistent): the same
+device functions as the launch-per-phase path, so the same bits -- for the recorded state (the recorded year again) and for
+a perturbed one; the cache is built once per schedule; modules it is not made for, larger grids and years that do not pass
+their check take the launch-per-phase path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _iage(n, ny=None):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = iage_engine(Grid2d.default(n, ny or n))
+    eng.set_option("device_ctl", 0)
+    return eng
+
+
+def _state(eng, seed=3):
+    rng = np.random.default_rng(seed)
+    tc, nz, ny = eng.shape
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * tc) + 0.01 * rng.standard_normal(eng.shape)
+    return x0, eng.upload(x0), eng.upload(x0 * (1.0 + 1.0e-4 * rng.standard_normal(x0.shape)))
+
+
+@pytest.mark.parametrize("n", [26, 52, 104])
+@pytest.mark.parametrize("mode", ["default", "scipy_decisions"])
+def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
+    eng = _iage(n)
+    if mode == "scipy_decisions":
+        # SciPy's Jacobian reuse: rows that keep the Jacobian (and the factorisation) of an earlier step, Jacobian times at
+        # step starts -- the cache rebuilds both per row from (t_jac, h_lu)
+        eng.set_option("jac_stage", -1)
+        eng.set_option("jac_fresh", 0)
+    _, x, xp = _state(eng)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    want = eng.download(fx)
+    eng.set_option("frozen_persistent", 0)
+    fx_l, st_l = eng.comp_fcn_frozen(x, sched)
+    fxp_l, _ = eng.comp_fcn_frozen(xp, sched)
+    assert np.array_equal(eng.download(fx_l), want) and eng.counter("frozen_persistent_years") == 0
+    eng.set_option("frozen_persistent", 1)
+    fx_p, st_p = eng.comp_fcn_frozen(x, sched)
+    assert eng.counter("frozen_persistent_years") == 1 and eng.counter("frozen_cache_builds") == 1
+    assert np.array_equal(eng.download(fx_p), want)                          # the recorded year, bit for bit
+    fxp_p, st_pp = eng.comp_fcn_frozen(xp, sched)
+    assert np.array_equal(eng.download(fxp_p), eng.download(fxp_l))          # and the launch-per-phase year of another state
+    assert eng.counter("frozen_persistent_years") == 2 and eng.counter("frozen_cache_builds") == 1   # one cache per schedule
+    for key in ("nsteps", "nnewton", "nsweeps"):
+        assert st_p[key] == st_l[key], key
+    # (the launch-per-phase year also evaluates the error estimate of every 32nd step -- a tendency and a solve each;
+    # the one-launch year checks the Newton convergence of every step only)
+    assert st_l["nerr_checked"] > 0 and st_p["nerr_checked"] == 0 and st_l["nfev"] > st_p["nfev"]
+    assert st_p["nlaunch"] < 20 < st_l["nlaunch"]
+    assert st_pp["seconds"] < st_l["seconds"]
+    # a new schedule (another state's year): a new cache
+    fx2, _, sched2 = eng.comp_fcn(xp, record=True)
+    fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
+    assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
+    eng.close()
+
+
+def test_products_and_gmres_run_on_it():
+    """nk2d_jvp / nk2d_gmres_solve with a schedule installed: the same numbers with and without the one-launch year"""
+    n = 26
+    eng = _iage(n)
+    eng.set_region(np.ones((n, n), dtype=np.int32), np.outer(eng.grid.depth.delta, eng.grid.ypos.delta))
+    _, x, _ = _state(eng)
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    out = {}
+    for flag in (0, 1):
+        eng.set_option("frozen_persistent", flag)
+        inc, info = eng.gmres_solve(x, fx, 0.0, 0, 3, sched=sched)
+        out[flag] = (eng.download(inc), info["h_mat"].copy(), info["beta"].copy())
+    assert eng.counter("frozen_persistent_years") == 3
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    eng.close()
+
+
+def test_forced_modules_and_column_grids():
+    """the decay variant of forced (one tracer), a forced module with forcing files (its planes carry the forcing bundle), and
+    a grid without lateral processes (20 x 3 columns)"""
+    from nk_ooc_amd.engine import ModuleEngine, forced_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    rng = np.random.default_rng(8)
+    cases = []
+    eng = forced_engine(Grid2d.default(22, 9), {"forced_surf_restore_opt": "none", "forced_sms_opt": "decay",
+                                                 "forced_sms_decay_rate": "1.0e-8"})
+    cases.append((eng, 1.0 + 0.2 * rng.standard_normal((1, 22, 9))))
+    nz, ny = 100, 11
+    times = np.array([-10.0, 40.0, 95.0, 200.0, 300.0]) * 86400.0
+    eng = ModuleEngine(Grid2d.default(nz, ny), tc=1, surf_rate=(24.0 / 86400.0,), module_kind=2,
+                       restore_series=(times, 1.0 + 0.2 * rng.standard_normal((5, ny))),
+                       sms_series=(times, 3.0e-8 * rng.standard_normal((5, nz, ny))), time_range=(0.0, 40.0 * 86400.0))
+    cases.append((eng, 0.6 + 0.2 * rng.standard_normal((1, nz, ny))))
+    from nk_ooc_amd.engine import iage_engine
+
+    eng = iage_engine(Grid2d.default(20, 3, 0.0, 0.0))
+    cases.append((eng, 1.0 + 0.1 * rng.standard_normal((2, 20, 3))))
+    for eng, x0 in cases:
+        eng.set_option("device_ctl", 0)
+        x = eng.upload(x0)
+        fx, st, sched = eng.comp_fcn(x, record=True)
+        fx_p, st_p = eng.comp_fcn_frozen(x, sched)
+        assert eng.counter("frozen_persistent_years") == 1, eng.shape
+        assert np.array_equal(eng.download(fx_p), eng.download(fx))
+        xp = eng.upload(x0 * (1.0 + 1.0e-5 * rng.standard_normal(x0.shape)))
+        fx_pp, _ = eng.comp_fcn_frozen(xp, sched)
+        eng.set_option("frozen_persistent", 0)
+        fx_lp, _ = eng.comp_fcn_frozen(xp, sched)
+        assert np.array_equal(eng.download(fx_pp), eng.download(fx_lp))
+        eng.close()
+
+
+def test_what_it_is_not_for_takes_the_other_path():
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    # a Jacobian that reads the state
+    ph = phosphorus_engine(Grid2d.default(30, 12))
+    rng = np.random.default_rng(8)
+    x0 = np.stack([2.0 + 0.1 * rng.standard_normal((30, 12)), 0.05 + 0.005 * rng.standard_normal((30, 12)),
+                   0.01 + 0.001 * rng.standard_normal((30, 12))])
+    x = ph.upload(x0)
+    fx, _, sched = ph.comp_fcn(x, record=True)
+    fx2, _ = ph.comp_fcn_frozen(x, sched)
+    assert np.array_equal(ph.download(fx2), ph.download(fx)) and ph.counter("frozen_persistent_years") == 0
+    ph.close()
+    # more levels per lane than the option admits; a cache larger than allowed
+    eng = _iage(130, 9)
+    _, x, _ = _state(eng)
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    eng.comp_fcn_frozen(x, sched)
+    assert eng.counter("frozen_persistent_years") == 0
+    eng.set_option("frozen_persistent_max_e", 3)
+    fx3, _ = eng.comp_fcn_frozen(x, sched)
+    assert eng.counter("frozen_persistent_years") == 1 and np.array_equal(eng.download(fx3), eng.download(fx))
+    eng.set_option("frozen_cache_gb", 1.0e-3)
+    eng.comp_fcn_frozen(x, sched)
+    assert eng.counter("frozen_persistent_years") == 1
+    eng.close()
+    # a year that does not pass its check goes back to the launch-per-phase path, which resumes it from a checkpoint
+    eng = _iage(26)
+    _, x, _ = _state(eng)
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    bad = sched.copy()
+    k = next(i for i in range(200, len(bad)) if bad[i, 3] >= 4)
+    bad[k, 3] -= 3
+    fx4, st4 = eng.comp_fcn_frozen(x, bad)
+    assert eng.counter("frozen_persistent_years") == 0 and st4["nresumed"] >= 1 and eng.frozen_fallbacks() == 0
+    assert np.allclose(eng.download(fx4), eng.download(fx), rtol=0.0, atol=1e-6 * np.max(np.abs(eng.download(fx))))
+    # and a barrier that times out hands the year over as well
+    eng.set_option("barrier_timeout_ms", 0.0)
+    fx5, st5 = eng.comp_fcn_frozen(x, sched)
+    assert st5["nbarrier_timeouts"] >= 1 and np.array_equal(eng.download(fx5), eng.download(fx))
+    eng.close()

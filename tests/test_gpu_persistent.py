@@ -148,3 +148,33 @@ def test_persistent_mode_falls_back_where_it_does_not_apply():
     y0 = np.stack([np.broadcast_to(p[:, None], (22, 9)) for p in prof]).copy()
     _, st, _ = ph.comp_fcn(ph.upload(y0))
     assert st["nlaunch"] > 1000
+
+
+def test_barrier_timeout_reruns_the_year_under_host_control():
+    """a grid barrier that waits longer than "barrier_timeout_ms" (a co-tenant holding the chip, say) does not fail the year:
+    it is run again from x under host control, and counted (round-2 ADVICE); with the limit at zero every year takes that way"""
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    n = 26
+    eng = iage_engine(Grid2d.default(n, n))
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
+    eng.set_option("device_ctl", 0)
+    fx_host, st_host, sched_host = eng.comp_fcn(x, record=True)
+    eng.set_option("device_ctl", 3)
+    fx_dev, st_dev, _ = eng.comp_fcn(x)
+    assert st_dev["nbarrier_timeouts"] == 0 and st_dev["nlaunch"] < 50
+    eng.set_option("barrier_timeout_ms", 0.0)
+    fx_to, st_to, sched_to = eng.comp_fcn(x, record=True)
+    assert st_to["nbarrier_timeouts"] == 1
+    assert np.array_equal(eng.download(fx_to), eng.download(fx_host))          # the host-controlled year, bit for bit
+    assert np.array_equal(sched_to, sched_host) and st_to["nsteps"] == st_host["nsteps"]
+    eng.set_option("barrier_timeout_ms", 2000.0)
+    # validation mode of the barrier: agent-scope release / acquire fences around every grid barrier on top of the
+    # write-through stores and L1-bypassing loads -- an array missed by those accessors would show as a difference
+    eng.set_option("year_fences", 1)
+    fx_f, st_f, _ = eng.comp_fcn(x)
+    assert st_f["nbarrier_timeouts"] == 0
+    assert np.array_equal(eng.download(fx_f), eng.download(fx_dev))
+    eng.close()
