@@ -47,6 +47,16 @@ LADDER_SIZES = (26, 52, 104, 208)
 YEAR = 365.0 * 86400.0
 
 
+def progress(msg):
+    """a line on stderr per leg (a long run shows that it is alive; the JSON line on stdout stays the only stdout output)"""
+    rank = os.environ.get("RANK", "0")
+    sys.stderr.write(f"[bench rank {rank} +{time.perf_counter() - _T0:.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child
     processes (nothing in this process has touched the GPU) and relay what rank 0 prints"""
@@ -206,13 +216,18 @@ class MixWorkload:
         self.base_stats = {tms.name: st for tms, st in zip(self.iterate.tracer_modules, ModelState.last_stats)}
 
     def krylov(self, k_iters, tag, device, group=None):
+        """group None: all modules are here, no collective at all (rank 0's one-GPU baseline runs while the others wait)"""
         from nk_ooc_amd import dist as nkdist
+        from nk_ooc_amd.krylov_solver import KrylovSolver
 
         solverinfo = dict(self.cfg["solverinfo"])
         solverinfo["krylov_workdir"] = os.path.join(self.workdir, tag)
         solverinfo["krylov_max_iter"] = str(k_iters)
-        solver = nkdist.DistributedKrylovSolver(self.iterate, solverinfo, resume=False, rewind=False,
-                                                hist_fname=self.hist_fname, device=device, group=group)
+        if group is None:
+            solver = KrylovSolver(self.iterate, solverinfo, False, False, self.hist_fname)
+        else:
+            solver = nkdist.DistributedKrylovSolver(self.iterate, solverinfo, resume=False, rewind=False,
+                                                    hist_fname=self.hist_fname, device=device, group=group)
         solver.solve(os.path.join(self.workdir, f"increment_{tag}.nc"), self.fcn)
         return solver
 
@@ -371,6 +386,23 @@ def roofline_of(eng, n):
     # the years of the timed region are frozen years (host-launched replays of the base year's steps) unless
     # NK2D_JVP_FROZEN=0 leaves them to the engine's own mode, which may be the persistent kernel
     persistent = getattr(eng, "device_ctl", 0) == 3 and os.environ.get("NK2D_JVP_FROZEN", "1") == "0"
+    if not persistent and eng.counter("frozen_persistent_years") > 0:
+        # small grids: every frozen year of the timed region was ONE launch on the schedule cache (k_frozen_persistent): its
+        # phases' algorithmic bytes over the wall time of the year around that launch
+        from nk_ooc_amd.model_state import ModelState
+
+        totals = eng.profile_totals()
+        year_s = ModelState.last_stats[0]["seconds"]
+        years = max(totals["launches"], 1)
+        nbytes = totals["bytes"] / years
+        achieved = nbytes / year_s / 1e9
+        return {"bound": "hbm", "kernel": f"k_frozen_persistent<{(eng.nz + 63) // 64}, 0, xcd> (a whole frozen year in one launch: "
+                                          "one simplified-Newton iteration per phase, grid barriers between them)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": 1.0e6 * year_s, "timing": "host wall clock of the nk2d_comp_fcn_frozen call around the one launch",
+                "launches": totals["launches"], "algorithmic_bytes_per_launch": nbytes,
+                "phases_per_launch": ModelState.last_stats[0]["nsweeps"],
+                "one_launch_years": eng.counter("frozen_persistent_years"), "xcd_local_years": eng.counter("frozen_xcd_years")}
     windows = {
         "what": "HIP event pairs around the launches of single Newton iterations inside the timed region",
         "avg_launch_us_event_cost_included": raw_us,
@@ -591,6 +623,11 @@ def main():
                     help="only start the ranks, all-reduce their ranks over gloo and print the world size "
                          "(CPU check of the self-launch path, tests/test_dist.py)")
     args = ap.parse_args()
+    if os.environ.get("NK2D_BENCH_DEBUG"):
+        # stacks of every thread on stderr should a leg hang (seconds)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["NK2D_BENCH_DEBUG"]), exit=False)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's invocation: no launcher around us.  Nothing above has touched the GPU.
@@ -625,8 +662,10 @@ def main():
     n = args.grid
     wl = None
     try:
+        progress(f"set-up of iage {n}x{n}")
         wl = Workload(n, local_rank, f"r{rank}", write_files=not args.no_files)
         eng = wl.eng
+        progress("warm-up and timed Krylov iterations")
         if args.warmup > 0:
             wl.krylov(args.warmup, "krylov_warm", device)
         eng.profile_reset(1)
@@ -729,6 +768,7 @@ def main():
                 t_g = time.perf_counter() - t_g
                 out["gmres_solve_in_hbm"] = {"what": "nk2d_gmres_solve: the same Krylov iterations in one C call, no files",
                                              "jvps_per_s": args.steps / t_g, "ms_per_jvp": 1000.0 * t_g / args.steps}
+        progress("reference-semantic products (two free-running years)")
         if os.environ.get("NK2D_JVP_FROZEN", "1") != "0":
             # the reference's own product, two free-running years, through the same solver on every rank: what `value`
             # is without the frozen controller (measured, two Krylov iterations, same barriers and MAX over ranks)
@@ -768,12 +808,14 @@ def main():
         wl.close()
         wl = None
         if world >= 2 and not args.no_shard:
+            progress("shard_e2: one module, tracer per rank")
             base = wl_base_stats
             hint = base["nnewton"] + 2 * (base["nsteps"] + base["nrejected"]) + 10
             shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
             if rank == 0:
                 out["shard_e2"] = shard
         if not args.no_mix:
+            progress("config4_mix: iage + phosphorus + forced")
             mix = run_config4_mix(args, rank, local_rank, world, device)
             if rank == 0:
                 out["config4_mix"] = mix
@@ -785,12 +827,14 @@ def main():
                         "speedup": mix["distributed"]["speedup_over_one_gpu"],
                         "one_gpu_ms_per_krylov_iteration": mix["one_gpu"]["ms_per_krylov_iteration"],
                         "ms_per_krylov_iteration": mix["distributed"]["ms_per_krylov_iteration"]}
-        if not args.no_shard3:
+        if not args.no_shard3 and world >= 2:
+            progress("shard_e3: phosphorus, Krylov basis columns over the ranks")
             shard3 = run_shard_e3(args, rank, local_rank, world, backend)
             if rank == 0:
                 out["shard_e3"] = shard3
         if rank == 0:
             if world == 1 and not args.no_ladder:
+                progress("ladder 26 .. 208")
                 out["ladder"] = run_ladder(local_rank, device, args)
                 out["ladder"].append({"grid": n, "jvps_per_s": out["value"], "ms_per_jvp": out["ms_per_step"],
                                       "forward_year_s": jvp_stats["seconds"], "nsteps": jvp_stats["nsteps"],
@@ -798,11 +842,17 @@ def main():
                                       "avg_launch_us": out["roofline"]["avg_launch_us"],
                                       "algorithmic_bytes_per_launch": out["roofline"]["algorithmic_bytes_per_launch"]})
             if world == 1 and args.cpu_baseline_seconds > 0:
+                progress("CPU baseline (oracle, one host thread)")
                 out["cpu_baseline"] = cpu_baseline(n, faithful_attempts, args.cpu_baseline_seconds)
                 out["cpu_baseline"]["host_cpus"] = os.cpu_count()
                 if "ladder" in out:
                     out["ladder"][-1]["cpu_oracle"] = {
                         "seconds_per_year": 1.0 / out["cpu_baseline"]["value"], "full_year": False, "cores": 1}
+            if world == 1 and not args.no_shard3:
+                # (last: after this leg's phosphorus solve the launch-bound years of this process run 2.7 times slower --
+                # measured on the ladder, cause not found; nothing is timed behind it)
+                progress("shard_e3 (one rank): phosphorus through the column-sharded loop")
+                out["shard_e3"] = run_shard_e3(args, rank, local_rank, world, backend)
             print(json.dumps(out), flush=True)
     finally:
         if wl is not None:

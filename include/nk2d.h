@@ -196,8 +196,8 @@ int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n
    Where the recorded count is not enough for the state given, the year is RESUMED from the checkpoint before the first
    such step (the state is kept every 128 steps) with one more Newton iteration there, at most twice; a year that still
    fails -- or a step already at SciPy's six iterations -- makes nk2d_comp_fcn_frozen return -7, and nk2d_jvp then runs a
-   free-running year instead.  Option "frozen_err_check" k > 0 (default 32) also evaluates SciPy's error estimate on
-   every k-th step of a frozen year (one launch each, plus the tendency at the step start): a step whose estimate
+   free-running year instead.  Option "frozen_err_check" k > 0 (default 128: the steps that open a checkpoint interval) also evaluates SciPy's
+   error estimate on every k-th step of a frozen year (one launch each, plus the tendency at the step start): a step whose estimate
    exceeds 1.5 * max(1, recorded estimate) returns -7 as well.  A schedule whose fingerprint is not this context's
    (other options, grid or library build) is refused with -8 before anything runs.
    nk2d_frozen_fallbacks: how often a frozen year was given up (-7) on this context; nk2d_frozen_resumes: how often one was
@@ -331,7 +331,10 @@ int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis,
 typedef double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares);
 int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double global_n);
 
-/* run-time options: "lin_tol" (relative accuracy of the inner line-relaxation solves),
+/* run-time options.  ONE set of defaults since round 3: a context is created in the mode the engines, the tests of the
+   benchmarked path and bench.py run -- "jac_fresh" 1, "jac_stage" 1 (and desc.lin_tol = 3e-2 is what they pass);
+   SciPy's decisions step for step are "jac_fresh" 0 + "jac_stage" -1 (what the counter-parity tests set).
+   "lin_tol" (relative accuracy of the inner line-relaxation solves),
    "device_ctl" (1: take the Newton convergence decisions on the device and read back once
    per step attempt instead of once per Newton iteration), "jac_fresh" (1: re-evaluate the
    Jacobian at every step start instead of SciPy's reuse heuristic; same ODE, same error
@@ -346,7 +349,7 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    "jac_stage" (0, 1 or 2, with "jac_fresh" 1 and host-side or persistent control: the Jacobian of a step attempt is
    taken at the time of that stage of the attempt, t + c_i h, instead of the step start -- the simplified Newton
    iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
-   the launch that computes the stage's mixing plane derives the Jacobian planes from it.  -1, the library default:
+   the launch that computes the stage's mixing plane derives the Jacobian planes from it.  1 is the default; -1:
    the step start, as SciPy.  Modules whose Jacobian also reads the state take the mixing plane of that time and the
    state of the step start, in a launch of their own -- option "jac_stage_state" 1, the default; 0: step start for both),
    "team" (launch shape of the Newton-iteration launches: 0 one wave per column; 1 one workgroup of four waves per
@@ -354,7 +357,15 @@ int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double g
    real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
    context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto), "xcd_map" (1: workgroup -> column mapping that gives every XCD a contiguous range of columns;
    0 default -- no measurable gain at 416 x 416), "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs),
-   "sweep_wpb" */
+   "sweep_wpb",
+   "prefactor" (1: in a frozen year the next step's planes ride on the first non-factorising launch of the step and its line
+   factorisation on the step-ending launch; 0 default -- measured neutral, profiles/r03_prefactor),
+   "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
+   "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
+   grids, see nk2d_get_counter), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
+   then the year is rerun launch by launch), "year_fences" (1: release / acquire fences around those barriers, validation),
+   "pc_fp32" (1: the preconditioner's Schur inverses stored in single precision -- half the HBM -- and every apply refined
+   "pc_refine" times, default 1, against the exact block tridiagonal operator; set before nk2d_precond_setup) */
 int nk2d_set_option(nk2d_ctx* ctx, const char* name, double value);
 
 /* block until every operation queued on the context's stream has finished */

@@ -131,6 +131,12 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "pc_fp32") { c->pc_fp32 = value != 0.0; return 0; }
+    if (key == "pc_refine") {
+        if (!(value >= 0.0 && value <= 4.0)) return nk2d_fail(c, "nk2d_set_option: pc_refine must be 0 .. 4");
+        c->pc_refine = (int)value;
+        return 0;
+    }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
     if (key == "prefactor") { c->prefactor = value != 0.0; return 0; }
     if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
@@ -427,7 +433,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->min_sweeps = 1;
     c->team = nk2d_team_auto(c);
     c->xcd_map = 0;
-    c->jac_stage = -1;
+    c->jac_stage = 1;     // ONE set of defaults (round 3): the mode the engines and bench.py run; -1 = SciPy's step start
     c->final_fuse = 1;
     c->jac_stage_state = 1;
     c->part_cur = nullptr;
@@ -471,13 +477,13 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_cache = nullptr;
     c->frozen_persistent = 1;
     c->frozen_persistent_max_e = 2;
-    c->frozen_cache_max_gb = 8.0;
+    c->frozen_cache_max_gb = 16.0;
     c->frozen_cache_builds = c->frozen_persistent_years = c->frozen_xcd_years = 0;
     c->frozen_xcd = 1;
     c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;
-    c->frozen_err_check = 32;
+    c->frozen_err_check = NK2D_CKPT_EVERY;   // the rows that start a checkpoint interval: the step before ends in a launch of its own anyway
     c->STEP_PART = nullptr;
     c->step_part_rows = 0;
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
@@ -488,7 +494,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     for (int i = 0; i < 8; ++i) NK2D_CHECK(c, hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming));
     c->cur_guard = nullptr;
     c->device_ctl = 0;
-    c->jac_fresh = 0;
+    c->jac_fresh = 1;     // (0 = SciPy's reuse heuristic)
     c->growth_cap = 0.0;
     c->hist_n = 0;
     c->hist_next = 0;
@@ -579,6 +585,8 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->stage_elems = 0;
     c->precond = nullptr;
     c->pc_valu = 0;
+    c->pc_fp32 = 0;
+    c->pc_refine = 1;
     c->st = nk2d_stats();
     c->prof_every = 0;
     c->hSNAP = nullptr;

@@ -179,6 +179,8 @@ struct nk2d_ctx {
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
     int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
+    int pc_fp32;   // 1: Schur inverses of the linear modules' preconditioner stored in single precision (option "pc_fp32")
+    int pc_refine; // ... with this many refinement steps per apply against the exact operator (option "pc_refine", default 1)
 
     // optional dense-output sampling of the running comp_fcn (history files)
     int hist_n, hist_next;

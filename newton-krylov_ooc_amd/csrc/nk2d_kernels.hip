@@ -3050,7 +3050,9 @@ struct GridBarrier {
                     (lane == 0) ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
                 // bounded by TIME (a slow co-tenant must not fail a year that is merely waiting), and by a spin count as a
                 // last resort should the clock not advance
-                const bool late = (++spins & 63) == 0 && (long long)__builtin_amdgcn_s_memrealtime() - t_begin > spin_ticks;
+                // (the clock is read every 64th poll; a limit of zero -- tests -- gives up at the first poll that has to wait)
+                const bool late = ((++spins & 63) == 0 || spin_ticks == 0) &&
+                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > spin_ticks;
                 if (late || spins > 4000LL * NK2D_SPIN_LIMIT || ab != 0) {
                     if (lane == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     good = 0;
@@ -4216,12 +4218,17 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     }
     if ((int)o[2]) std::swap(c->Y, c->YOLD);
     if ((int)o[3]) std::swap(c->Z, c->ZN);
-    // counters of the year, as the launch-per-phase path books them
+    // counters of the year, as the launch-per-phase path books them, and the algorithmic bytes of its phases (the formula of
+    // the launches they replace; nothing of the schedule cache's one-off construction)
     for (int64_t i = 0; i < n; ++i) {
         const FrozenRow& F = fc->frows[(size_t)i];
         c->st.nnewton += F.n_iter; c->st.nfev += 3 * (int64_t)F.n_iter; c->st.nsolve += 2 * (int64_t)F.n_iter;
         c->st.nsweeps += (int64_t)F.n_iter * F.m;
+        double words = 0.0;
+        for (int it = 0; it < F.m; ++it) words += fused_words(c, it == 0, it == 0, it == F.m - 1, F.m == 2, false);
+        c->fused_bytes_all += 8.0 * words * F.n_iter;
     }
+    c->sweep_launches += 1;
     c->st.nsteps += n - 1;      // the last row's commit is the caller's
     c->st.njev += n; c->st.nlu += 2 * n;
     c->st.nlaunch += 1;

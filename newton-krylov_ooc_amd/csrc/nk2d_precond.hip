@@ -37,6 +37,15 @@ struct Precond {
     double scale, sigma[NK2D_MAX_SHIFTS];
     double* PJ;    // Jacobian planes, natural layout [nt][6][nz][ny]  (L, S, C, N, U, d uptake / d po4)
     double* SINV;  // [tc][nb][m][m]
+    // option "pc_fp32": the explicit inverses are KEPT in single precision (half the HBM: 832 x 832 fits an MI355X); the
+    // elimination itself stays in double precision -- the inverse of the column before is held once more in PREV -- and an
+    // apply is refined once against the exact block tridiagonal operator (k_pc_residual), which brings it back to the
+    // accuracy of the double precision inverses
+    float* SINV32; // [tc][nb][m][m]
+    double* PREV;  // [tc][m][m] Schur inverse of the column before, double precision
+    double* RV;    // right-hand sides kept for the residual [tc][nb][m]
+    double* X0;    // first solution [tc][nb][m]
+    int fp32;
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
     double* ROWS;  // scaled pivot rows    [tc][NB][m]
     double* YV;    // forward-sweep vectors [tc][nb][m]
@@ -103,7 +112,8 @@ __device__ __forceinline__ double shifted_entry(const PcDev& P, int sys, int j, 
 }
 
 // S_j = D_j - diag(l_j) Sinv_{j-1} diag(u_{j-1});  one thread per entry (r, c)
-__global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev, double* __restrict__ out) {
+__global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev, size_t prev_sys_stride,
+                           double* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     const int tr = blockIdx.z;
@@ -131,7 +141,7 @@ __global__ void k_pc_schur(PcDev P, int j, const double* __restrict__ sinv_prev,
         // l_j[r] = -dt JS[tau][k][j] (coupling to column j-1), u_{j-1}[c] = -dt JN[tc_][kc][j-1]
         const double l = lat_l(P, tau, k, j);
         const double u = lat_u(P, tc_, kc, j - 1);
-        val = val - (l * sinv_prev[((size_t)tr * P.nb * P.m + r) * P.m + c]) * u;
+        val = val - (l * sinv_prev[(size_t)tr * prev_sys_stride + (size_t)r * P.m + c]) * u;
     }
     out[((size_t)tr * P.m + r) * P.m + c] = val;
 }
@@ -466,6 +476,76 @@ __global__ void __launch_bounds__(256) k_pc_gemv(PcDev P, int mode, int j, const
     }
 }
 
+// the same mat-vec on single precision matrices (option "pc_fp32"): 4-byte loads widened in registers, double precision
+// accumulation -- half the bytes of the stream that bounds an apply
+__global__ void __launch_bounds__(256) k_pc_gemv32(PcDev P, int mode, int j, const float* __restrict__ M,
+                                                   size_t m_tr_stride, const double* __restrict__ a,
+                                                   const double* __restrict__ rhs, size_t v_tr_stride,
+                                                   double* __restrict__ out, double* __restrict__ prev) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tr = blockIdx.y;
+    if (r >= P.m) return;
+    const float* row = M + (size_t)tr * m_tr_stride + (size_t)r * P.m;
+    const double* av = a + (size_t)tr * v_tr_stride;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = lane; c0 < P.m; c0 += 1024) {
+        float mv[16];
+        double xv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = c0 + 64 * q;
+            const bool in = c < P.m;
+            mv[q] = in ? row[c] : 0.0f;
+            xv[q] = in ? av[c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_fma((double)mv[q], xv[q], acc[q & 3]);
+    }
+    const double sum = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane == 0) {
+        const int slot = r / P.nz, k = r - slot * P.nz;
+        const size_t at = (size_t)tr * v_tr_stride + r;
+        if (mode == 0) {
+            out[at] = rhs[at] - lat_l(P, slot, k, j) * sum;
+        } else {
+            out[at] = sum;
+            if (prev) prev[at] = prev[at] - lat_u(P, slot, k, j - 1) * sum;
+        }
+    }
+}
+
+__global__ void k_pc_to_f32(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+// res = rhs - A x for the time-periodic block system of mode 0 (the rows of k_pc_schur without the Schur term, and the
+// diagonal couplings to the neighbouring columns); one thread per unknown (tracer, column, (time level, depth level))
+__global__ void k_pc_residual(PcDev P, const double* __restrict__ rhs, const double* __restrict__ x, double* __restrict__ res) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y, tr = blockIdx.z;
+    if (r >= P.m) return;
+    const int tau = r / P.nz, k = r - tau * P.nz;
+    const size_t base = ((size_t)tr * P.nb + j) * P.m;
+    const double* xj = x + base;
+    double jc = pj(P, tau, PL_C, k, j) - P.decay[tr];
+    if (k == 0) jc = jc - P.surf[tr];
+    if (P.kind == 2) jc = jc - pj(P, tau, PL_UPR, k, j);
+    double ax = (1.0 - P.dt * jc) * xj[r];
+    if (k > 0) ax -= (P.dt * pj(P, tau, PL_L, k, j)) * xj[r - 1];
+    if (k < P.nz - 1) ax -= (P.dt * pj(P, tau, PL_U, k, j)) * xj[r + 1];
+    ax -= xj[((tau + P.nt - 1) % P.nt) * P.nz + k];
+    if (j > 0) ax += lat_l(P, tau, k, j) * x[base - P.m + r];
+    if (j < P.nb - 1) ax += lat_u(P, tau, k, j) * x[base + P.m + r];
+    res[base + r] = rhs[base + r] - ax;
+}
+
+__global__ void k_pc_add(double* __restrict__ x, const double* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + y[i];
+}
+
 // packed state v -> right-hand sides [tc][nb][m] (time level 0 rows = v, others 0)
 template <int E>
 __global__ void k_pc_rhs(int ncol, int ny, int nz, int m, const double* __restrict__ v, double* __restrict__ rhs) {
@@ -555,9 +635,10 @@ PcDev make_pcdev(const nk2d_ctx* c, const Precond* pc) {
 void nk2d_precond_free(nk2d_ctx* c) {
     Precond* pc = (Precond*)c->precond;
     if (!pc) return;
-    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->ROWS};
+    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->ROWS, pc->PREV, pc->RV, pc->X0};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
+    if (pc->SINV32) (void)hipFree(pc->SINV32);
     delete pc;
     c->precond = nullptr;
 }
@@ -572,12 +653,16 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
     const int m = nslot * c->nz;
     // gigabytes of Schur inverses: keep the allocation when the next factorisation fits in it (the
     // phosphorus preconditioner factorises three shifted systems per Newton iteration)
-    const bool reuse = pc && pc->mode == mode && pc->nt == nt && pc->m == m && pc->nb == c->ny && pc->cap_sys >= nsys;
+    const int want32 = (c->pc_fp32 && mode == 0) ? 1 : 0;
+    const bool reuse = pc && pc->mode == mode && pc->nt == nt && pc->m == m && pc->nb == c->ny && pc->cap_sys >= nsys &&
+                       pc->fp32 == want32;
     if (!reuse) {
         nk2d_precond_free(c);
         pc = new Precond();
         c->precond = pc;
-        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->ROWS = nullptr;
+        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->ROWS = pc->PREV = pc->RV = pc->X0 = nullptr;
+        pc->SINV32 = nullptr;
+        pc->fp32 = want32;
         pc->cap_sys = std::max(nsys, mode == 1 ? 2 : nsys);
     }
     pc->mode = mode;
@@ -594,7 +679,14 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
     if (!reuse) {
         const size_t cap = (size_t)pc->cap_sys;
         NK2D_CHECK(c, hipMalloc((void**)&pc->PJ, sizeof(double) * pc->nt * PL_COUNT * P));
-        NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * cap * pc->nb * mm));
+        if (pc->fp32) {
+            NK2D_CHECK(c, hipMalloc((void**)&pc->SINV32, sizeof(float) * cap * pc->nb * mm));
+            NK2D_CHECK(c, hipMalloc((void**)&pc->PREV, sizeof(double) * cap * mm));
+            NK2D_CHECK(c, hipMalloc((void**)&pc->RV, sizeof(double) * cap * pc->nb * pc->m));
+            NK2D_CHECK(c, hipMalloc((void**)&pc->X0, sizeof(double) * cap * pc->nb * pc->m));
+        } else {
+            NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * cap * pc->nb * mm));
+        }
         NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * cap * mm));
         NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * cap * PC_NB * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * cap * pc->nb * pc->m));
@@ -620,9 +712,10 @@ int precond_eliminate(nk2d_ctx* c) {
     const int m = pc->m;
     const dim3 blk(256), grd((m + 255) / 256, m, nsys);
     for (int j = 0; j < pc->nb; ++j) {
-        const double* prev = (j > 0) ? pc->SINV + (size_t)(j - 1) * mm : nullptr;
-        // SINV is [nsys][nb][m][m]: the kernel adds the system stride itself
-        hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, c->stream, D, j, prev, pc->BUF);
+        // the Schur inverse of the column before: inside SINV ([nsys][nb][m][m]), or -- single precision storage -- the
+        // double precision copy kept of that one column ([nsys][m][m])
+        const double* prev = (j > 0) ? (pc->fp32 ? pc->PREV : pc->SINV + (size_t)(j - 1) * mm) : nullptr;
+        hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, c->stream, D, j, prev, pc->fp32 ? mm : (size_t)pc->nb * mm, pc->BUF);
         int src = 0;
         for (int p0 = 0; p0 < m; p0 += PC_NB) {
             const int nbk = std::min(PC_NB, m - p0);
@@ -638,10 +731,17 @@ int precond_eliminate(nk2d_ctx* c) {
                                    m, p0, nbk, from, pc->ROWS, to);
             src = 1 - src;
         }
-        for (int sys = 0; sys < nsys; ++sys)
-            NK2D_CHECK(c, hipMemcpyAsync(pc->SINV + ((size_t)sys * pc->nb + j) * mm,
-                                         pc->BUF + ((size_t)src * nsys + sys) * mm, sizeof(double) * mm,
-                                         hipMemcpyDeviceToDevice, c->stream));
+        for (int sys = 0; sys < nsys; ++sys) {
+            const double* inv = pc->BUF + ((size_t)src * nsys + sys) * mm;
+            if (pc->fp32) {
+                hipLaunchKernelGGL(k_pc_to_f32, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, c->stream, inv,
+                                   pc->SINV32 + ((size_t)sys * pc->nb + j) * mm, mm);
+                NK2D_CHECK(c, hipMemcpyAsync(pc->PREV + (size_t)sys * mm, inv, sizeof(double) * mm, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                NK2D_CHECK(c, hipMemcpyAsync(pc->SINV + ((size_t)sys * pc->nb + j) * mm, inv, sizeof(double) * mm,
+                                             hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
         NK2D_CHECK(c, hipGetLastError());
         // bounded queue depth: a column is ~80 launches, and the whole elimination used to be queued (33 000
         // launches at 416 x 416) before the first synchronisation.  Under `rocprofv3 --pmc` that crashed the
@@ -663,7 +763,8 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     const size_t mm = (size_t)m * m;
     const size_t mstride = (size_t)nb * mm;      // system stride inside SINV
     const size_t vstride = (size_t)nb * m;       // system stride inside YV / XV
-    const double* sinv = pc->SINV + (size_t)sys0 * mstride;
+    const double* sinv = pc->fp32 ? nullptr : pc->SINV + (size_t)sys0 * mstride;
+    const float* sinv32 = pc->fp32 ? pc->SINV32 + (size_t)sys0 * mstride : nullptr;
     double* yv = pc->YV + (size_t)sys0 * vstride;
     double* xv = pc->XV + (size_t)sys0 * vstride;
     const dim3 blk(256), grd((m + 3) / 4, nsys);
@@ -674,7 +775,11 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
         NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
                                      hipMemcpyDeviceToDevice, c->stream));
     for (int j = 1; j < nb; ++j) {
-        if (wide)
+        if (pc->fp32)
+            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, c->stream, D, 0, j, sinv32 + (size_t)(j - 1) * mm, mstride,
+                               yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
+                               (double*)nullptr);
+        else if (wide)
             hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
                                yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
                                (double*)nullptr);
@@ -685,7 +790,11 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     }
     // backward: x_j = Sinv_j (y_j - U_j x_{j+1}); each launch leaves y_{j-1} - U_{j-1} x_j behind for the next
     for (int j = nb - 1; j >= 0; --j) {
-        if (wide)
+        if (pc->fp32)
+            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, c->stream, D, 1, j, sinv32 + (size_t)j * mm, mstride,
+                               yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
+                               (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
+        else if (wide)
             hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
                                yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
                                (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
@@ -767,7 +876,23 @@ extern "C" int nk2d_precond_apply(nk2d_ctx* c, nk2d_vec v, nk2d_vec out) {
     // right-hand sides into XV (used as r_j), forward sweep writes YV
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
                                               c->ny, c->nz, m, (const double*)v, pc->XV));
-    NK2D_TRY(precond_substitute(c, 0, pc->nsys));
+    if (pc->fp32) {
+        // single precision inverses: x0 = S32^-1 rhs, then "pc_refine" corrections x += S32^-1 (rhs - A x) against the exact
+        // operator -- each multiplies the error by that of the single precision inverses
+        const size_t nvec = (size_t)pc->nsys * pc->nb * m;
+        PcDev D = make_pcdev(c, pc);
+        NK2D_CHECK(c, hipMemcpyAsync(pc->RV, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, c->stream));
+        NK2D_TRY(precond_substitute(c, 0, pc->nsys));
+        for (int it = 0; it < c->pc_refine; ++it) {
+            NK2D_CHECK(c, hipMemcpyAsync(pc->X0, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_pc_residual, dim3((m + 255) / 256, pc->nb, pc->nsys), dim3(256), 0, c->stream, D, pc->RV,
+                               pc->X0, pc->XV);
+            NK2D_TRY(precond_substitute(c, 0, pc->nsys));
+            hipLaunchKernelGGL(k_pc_add, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, c->stream, pc->XV, pc->X0, nvec);
+        }
+    } else {
+        NK2D_TRY(precond_substitute(c, 0, pc->nsys));
+    }
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
                                               c->ncol, c->ny, c->nz, m, (const double*)v, pc->XV, (double*)out));
     NK2D_CHECK(c, hipGetLastError());

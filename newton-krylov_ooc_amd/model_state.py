@@ -51,6 +51,12 @@ SCHED_SUFFIX = ".sched.npz"
 _CRC_PREFIX = "__crc__"
 
 
+def sched_path(fname):
+    """where the schedule of the result file `fname` is kept for a resumed run: a hidden directory beside it, so that the
+    work directory's own file set is the reference's"""
+    return os.path.join(os.path.dirname(os.path.abspath(fname)), ".nk2d", os.path.basename(fname) + SCHED_SUFFIX)
+
+
 def _crc(host):
     """checksum of a module's values as they are written to / read from the state file"""
     import zlib
@@ -284,8 +290,8 @@ class ModelState:
         side = None
         if isinstance(fname, str):
             self._sched = self._sched_by_name.get(os.path.abspath(fname))
-            if self._sched is None and cached is None and os.path.exists(fname + SCHED_SUFFIX):
-                with np.load(fname + SCHED_SUFFIX) as data:
+            if self._sched is None and cached is None and os.path.exists(sched_path(fname)):
+                with np.load(sched_path(fname)) as data:
                     side = {key: data[key] for key in data.files}
         for ind, name in enumerate(names):
             module_def = cfg.tracer_module_defs[name]
@@ -353,8 +359,8 @@ class ModelState:
         cache = self._resident
         # whatever schedule was known under this name belonged to the values it held before
         self._sched_by_name.pop(os.path.abspath(fname), None)
-        if self.write_files and os.path.exists(fname + SCHED_SUFFIX):
-            os.remove(fname + SCHED_SUFFIX)
+        if self.write_files and os.path.exists(sched_path(fname)):
+            os.remove(sched_path(fname))
         cache.pop(os.path.abspath(fname), None)
         cache[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
         while len(cache) > self.RESIDENT_MAX:
@@ -560,7 +566,8 @@ class ModelState:
                 by_name.pop(next(iter(by_name)))
             if self.write_files:
                 crcs = {_CRC_PREFIX + tms.name: np.int64(_crc(tms.get_tracer_vals_all())) for tms in res_ms.tracer_modules}
-                np.savez(res_fname + SCHED_SUFFIX[:-4], **res_ms._sched, **crcs)
+                os.makedirs(os.path.dirname(sched_path(res_fname)), exist_ok=True)
+                np.savez(sched_path(res_fname)[:-4], **res_ms._sched, **crcs)
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
             modelinfo = self.model_config_obj.modelinfo

@@ -108,6 +108,22 @@ def test_comp_fcn_replay_is_affine_fullsize(eng):
     assert np.max(np.abs((f2 - f0) - 0.25 * (f1 - f0))) <= 1e-10 * np.max(np.abs(f1 - f0))
 
 
+def test_precond_single_precision_storage_fullsize(eng):
+    """416 x 416: the preconditioner with single precision storage of its Schur inverses (5.2 GB instead of 10.4 GB) against
+    the one with double precision storage, refined once: the same to 1e-9"""
+    from nk_ooc_amd.engine import iage_engine
+
+    rng = np.random.default_rng(11)
+    v = eng.upload(rng.standard_normal(eng.shape))
+    want = eng.download(eng.precond_apply(v))
+    eng32 = iage_engine(eng.grid)
+    eng32.set_option("pc_fp32", 1)
+    got = eng32.download(eng32.precond_apply(eng32.upload(eng.download(v))))
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err < 1e-9, err
+    eng32.close()
+
+
 def test_krylov_arnoldi_identities_fullsize(tmp_path):
     """three GMRES iterations at 416x416 through the solver mirror: orthonormal basis, and the
     explicitly formed preconditioned residual equals the least-squares residual of the

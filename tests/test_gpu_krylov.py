@@ -36,6 +36,29 @@ def test_precond_apply(nz, ny, vv, kh):
     assert rel_err(got, want) < 1e-9, rel_err(got, want)
 
 
+@pytest.mark.parametrize("nz,ny,vv,kh", [(26, 26, 0.1, 1000.0), (20, 3, 0.0, 0.0), (70, 40, 0.1, 1000.0), (130, 9, 0.1, 1000.0)])
+def test_precond_single_precision_storage(nz, ny, vv, kh):
+    """option "pc_fp32": the Schur inverses are kept in single precision (half the HBM: tc ny (3 nz)^2 x 4 bytes, 83 GB
+    instead of 166 GB at 832 x 832) and an apply is refined once against the exact block tridiagonal operator -- the same
+    1e-9 against the oracle's stable form as with double precision storage; without the refinement the single precision
+    shows"""
+    _, tm = oracle_iage(nz, ny, vv, kh)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(2 * nz * ny)
+    want = apply_precond_stable(tm, v)
+    eng = make_engine(nz, ny, vv, kh)
+    eng.set_option("pc_fp32", 1)
+    got = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert rel_err(got, want) < 1e-9, rel_err(got, want)
+    eng.set_option("pc_refine", 0)
+    raw = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert 1e-9 < rel_err(raw, want) < 1e-3, rel_err(raw, want)
+    eng.set_option("pc_refine", 2)
+    twice = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    assert rel_err(twice, want) < 1e-9
+    eng.close()
+
+
 def test_precond_golden_within_reference_noise(golden_dir):
     """against the reference formula's output: agreement is bounded by the reference's own
     roundoff sensitivity (tests/test_oracle_precond.py), i.e. the CI tolerance 2e-3"""
