@@ -455,15 +455,15 @@ def roofline_of(eng, n):
         out["event_windows_over_timed_region"] = windows
     if shapes_out:
         out["launch_shapes"] = shapes_out
-    pmc_fname = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{n}.json")
-    if not os.path.exists(pmc_fname):
-        pmc_fname = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{n}.json")
+    pmc_fname = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02}_pmc_traffic_{n}.json") for r in (3, 2, 1))
+                      if os.path.exists(f)), "")
     if os.path.exists(pmc_fname):
         pmc = json.load(open(pmc_fname))
         out["traffic"] = pmc["traffic_bytes_per_launch_upper"]
         out["traffic_source"] = ("static profile file " + os.path.relpath(pmc_fname, ROOT) +
                                  " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not collected in this run)")
-    stats_fname = os.path.join(ROOT, "profiles", f"r02_rocprof_bench{n}", "kernel_stats.csv")
+    stats_fname = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02}_rocprof_bench{n}", "kernel_stats.csv") for r in (3, 2))
+                        if os.path.exists(f)), "")
     if os.path.exists(stats_fname):
         for line in open(stats_fname):
             if not persistent and line.startswith('"void ' + out["kernel"]):
