@@ -114,6 +114,10 @@ def test_replay_schedule_is_validated():
     # solves the stage systems to 1e-3, the free run took single-sweep solves on its short steps)
     fx, _, _ = eng.comp_fcn(x, replay=sched)
     fy, _, _ = eng.comp_fcn(x)
+    # primary: the year frozen on its own steps (the recorded year's own inner tolerance) is the recorded year bit for bit;
+    # the step-replay mode solves the stage systems tighter than the free run did and agrees to SciPy's Newton tolerance
+    fz, _ = eng.comp_fcn_frozen(x, sched)
+    assert np.array_equal(eng.download(fz), eng.download(fy))
     assert np.allclose(eng.download(fx), eng.download(fy), rtol=1e-6, atol=1e-8)
 
 
