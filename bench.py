@@ -816,7 +816,10 @@ def main():
                 out["shard_e2"] = shard
         if not args.no_mix:
             progress("config4_mix: iage + phosphorus + forced")
-            mix = run_config4_mix(args, rank, local_rank, world, device)
+            try:
+                mix = run_config4_mix(args, rank, local_rank, world, device)
+            except Exception as exc:           # an auxiliary leg must not cost the line (same failure on every rank)
+                mix = {"error": f"{type(exc).__name__}: {exc}"}
             if rank == 0:
                 out["config4_mix"] = mix
                 if "distributed" in mix:
@@ -829,7 +832,10 @@ def main():
                         "ms_per_krylov_iteration": mix["distributed"]["ms_per_krylov_iteration"]}
         if not args.no_shard3 and world >= 2:
             progress("shard_e3: phosphorus, Krylov basis columns over the ranks")
-            shard3 = run_shard_e3(args, rank, local_rank, world, backend)
+            try:
+                shard3 = run_shard_e3(args, rank, local_rank, world, backend)
+            except Exception as exc:
+                shard3 = {"error": f"{type(exc).__name__}: {exc}"}
             if rank == 0:
                 out["shard_e3"] = shard3
         if rank == 0:
@@ -852,7 +858,10 @@ def main():
                 # (last: after this leg's phosphorus solve the launch-bound years of this process run 2.7 times slower --
                 # measured on the ladder, cause not found; nothing is timed behind it)
                 progress("shard_e3 (one rank): phosphorus through the column-sharded loop")
-                out["shard_e3"] = run_shard_e3(args, rank, local_rank, world, backend)
+                try:
+                    out["shard_e3"] = run_shard_e3(args, rank, local_rank, world, backend)
+                except Exception as exc:       # an auxiliary leg must not cost the line
+                    out["shard_e3"] = {"error": f"{type(exc).__name__}: {exc}"}
             print(json.dumps(out), flush=True)
     finally:
         if wl is not None:

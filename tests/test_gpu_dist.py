@@ -112,3 +112,46 @@ def test_bench_two_ranks_rccl():
                          env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     _check_two_rank_line(res.stdout, "nccl")
+
+
+def test_vector_collectives_work_in_place_on_engine_memory():
+    """the zero-copy path of dist.ColumnComm (BASELINE configs[4] over RCCL): a torch view of an engine vector's HBM
+    (`ModuleEngine.vec_tensor`), collectives of a one-rank nccl (= RCCL) group on it, results seen by the engine"""
+    import torch
+    import torch.distributed as tdist
+
+    from nk_ooc_amd import dist as nkdist
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = iage_engine(Grid2d.default(70, 12))
+    rng = np.random.default_rng(4)
+    host = rng.standard_normal(eng.shape)
+    vec = eng.upload(host)
+    view = eng.vec_tensor(vec)
+    assert view.is_cuda and view.dtype == torch.float64 and view.numel() == 2 * 12 * 2 * 64     # packed columns, zero padded
+    eng.sync()
+    assert abs(float(view.sum().item()) - host.sum()) < 1e-9 * np.abs(host).sum()
+    view.mul_(2.0)                                                  # in place, on torch's stream
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.download(vec), 2.0 * host)
+    started = False
+    if not tdist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        tdist.init_process_group("nccl", rank=0, world_size=1)
+        started = True
+    try:
+        tdist.all_reduce(view)
+        tdist.broadcast(view, src=0)
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.download(vec), 2.0 * host)
+        # the communicator itself, device flavour: staging through the pinned buffer, vectors in place
+        comm = nkdist.ColumnComm(0, 1, torch.device("cuda", 0))
+        assert np.array_equal(comm.allreduce(np.arange(6.0).reshape(3, 2)), np.arange(6.0).reshape(3, 2))
+        small = nkdist.ShardComm(torch.device("cuda", 0))
+        assert small.allreduce_scalar(3.5) == 3.5
+    finally:
+        if started:
+            tdist.destroy_process_group()
+    eng.close()
