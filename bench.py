@@ -579,9 +579,12 @@ def run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, allreduces_
             col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
             x = eng.upload(np.broadcast_to(col[:, None], (1, n, n)).copy())
             calls_base = comm.calls
-            fx, _, _ = eng.comp_fcn(x)                      # F(x): a coupled year, untimed
+            fx, st_c, _ = eng.comp_fcn(x)                   # F(x): a coupled year, untimed
             sched = eng.last_schedule()
             result["allreduces_of_the_coupled_year"] = comm.calls - calls_base
+            # (the vector norm hook pairs a Newton norm with the next one or with the error estimate: fewer collectives
+            # than norms read)
+            result["norms_read_by_the_controller_in_that_year"] = st_c["nnewton"] + st_c["nsteps"] + st_c["nrejected"] + 3
             eng.precond_setup()
             eng.sync()
             calls0 = comm.calls

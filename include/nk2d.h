@@ -330,6 +330,14 @@ int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis,
    (option "device_ctl" 0). */
 typedef double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares);
 int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double global_n);
+/* The same with several sums per call (1 <= n <= 4; replaced in place by the module-wide sums): the controller then
+   BATCHES what it can -- the norm of a Newton iteration with those of up to two iterations queued speculatively behind it
+   (option "hook_spec_depth", default 2; 1 = one) and with the error estimate queued behind the iteration expected to be the
+   last -- and a coupled year takes well under half the collectives of the scalar hook (measured: tools/probe_pairing.py,
+   bench.py's shard_e2 leg); the decisions and their order are the scalar hook's, the schedules identical.  Unwanted
+   iterations and estimates are dropped.  A context has one hook: installing either kind removes the other. */
+typedef void (*nk2d_norm_hook_vec_fn)(void* user, double* sums, int32_t n);
+int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, double global_n);
 
 /* run-time options.  ONE set of defaults since round 3: a context is created in the mode the engines, the tests of the
    benchmarked path and bench.py run -- "jac_fresh" 1, "jac_stage" 1 (and desc.lin_tol = 3e-2 is what they pass);

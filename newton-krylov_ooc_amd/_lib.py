@@ -145,6 +145,7 @@ SIGNATURES = {
     "nk2d_multi_dot": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p]),
     "nk2d_multi_axpy": (_ci, [_vp, _vp, _i32, ctypes.POINTER(_vp), c_double_p, _d]),
     "nk2d_set_norm_hook": (_ci, [_vp, _vp, _vp, _d]),
+    "nk2d_set_norm_hook_vec": (_ci, [_vp, _vp, _vp, _d]),
     "nk2d_set_option": (_ci, [_vp, ctypes.c_char_p, _d]),
     "nk2d_sync": (_ci, [_vp]),
     "nk2d_stream": (_vp, [_vp]),
@@ -152,6 +153,8 @@ SIGNATURES = {
 
 # double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares)
 NORM_HOOK = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double)
+# void (*nk2d_norm_hook_vec_fn)(void* user, double* sums, int32_t n)
+NORM_HOOK_VEC = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32)
 
 _lib = None
 
@@ -166,6 +169,29 @@ def build(force=False):
     return LIB_PATH
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm ships its own HIP/HSA runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7, which its libraries
+    ask for by FILE name).  Loaded after torch, libnk2d.so resolves `libamdhip64.so.7` to that copy and the process has one
+    runtime; loaded BEFORE torch it would pull in /opt/rocm's copy, torch would add its own beside it, and the second
+    runtime of the process finds no GPU ("No HIP GPUs are available" from a later torch.cuda call -- dist.ShardComm's
+    device buffers, ModuleEngine.vec_tensor).  So: where torch is installed and not imported yet, its copy is loaded
+    first, without importing torch, and both orders end with the same single runtime."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """load libnk2d.so and bind every declared symbol; raises when unavailable"""
     global _lib
@@ -176,6 +202,7 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built (run "
             "`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback"
         )
+    _one_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -130,6 +130,11 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "speculate") { c->speculate = value != 0.0; return 0; }
+    if (key == "hook_spec_depth") {
+        if (!(value == 1.0 || value == 2.0)) return nk2d_fail(c, "nk2d_set_option: hook_spec_depth is 1 or 2");
+        c->hook_spec_depth = (int)value;
+        return 0;
+    }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
     if (key == "pc_fp32") { c->pc_fp32 = value != 0.0; return 0; }
     if (key == "pc_refine") {
@@ -282,7 +287,31 @@ extern "C" int nk2d_set_norm_hook(nk2d_ctx* c, nk2d_norm_hook_fn fn, void* user,
     if (fn && !(global_n >= (double)c->tc * c->nz * c->ny))
         return nk2d_fail(c, "nk2d_set_norm_hook: global_n must be at least this context's tc * nz * ny");
     c->norm_hook = fn;
+    c->norm_hook_vec = nullptr;
     c->norm_hook_user = fn ? user : nullptr;
+    c->global_n = fn ? global_n : 0.0;
+    return 0;
+}
+
+// the scalar hook of a context that has a vector hook: one sum through the vector call
+static double norm_hook_through_vec(void* user, double local_sum) {
+    nk2d_ctx* c = (nk2d_ctx*)user;
+    double v = local_sum;
+    c->norm_hook_vec(c->norm_hook_vec_user, &v, 1);
+    return v;
+}
+
+extern "C" int nk2d_set_norm_hook_vec(nk2d_ctx* c, nk2d_norm_hook_vec_fn fn, void* user, double global_n) {
+    if (fn && !(global_n >= (double)c->tc * c->nz * c->ny))
+        return nk2d_fail(c, "nk2d_set_norm_hook_vec: global_n must be at least this context's tc * nz * ny");
+    if (fn && !c->ZS) {
+        NK2D_CHECK(c, hipSetDevice(c->dev));
+        NK2D_TRY(dev_alloc(c, &c->ZS, 3 * c->nv));
+    }
+    c->norm_hook_vec = fn;
+    c->norm_hook_vec_user = fn ? user : nullptr;
+    c->norm_hook = fn ? norm_hook_through_vec : nullptr;
+    c->norm_hook_user = fn ? (void*)c : nullptr;
     c->global_n = fn ? global_n : 0.0;
     return 0;
 }
@@ -505,8 +534,10 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART, sizeof(double) * c->ncol));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPART2, sizeof(double) * c->ncol));
     NK2D_CHECK(c, hipHostMalloc((void**)&c->hPARTB, sizeof(double) * c->ncol));
+    NK2D_CHECK(c, hipHostMalloc((void**)&c->hPARTC, sizeof(double) * c->ncol));
     c->part_on_host = 0;
     c->speculate = 1;
+    c->hook_spec_depth = 2;
     c->factor_pending = 0;
     c->lu_cre = c->lu_ccr = c->lu_cci = 0.0;
     c->rcoef_elems = 0;
@@ -603,6 +634,8 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->fused_bytes_all = 0.0;
     c->norm_hook = nullptr;
     c->norm_hook_user = nullptr;
+    c->norm_hook_vec = nullptr;
+    c->norm_hook_vec_user = nullptr;
     c->global_n = 0.0;
     c->timer_ready = 0;
     c->YR_PART = c->YR_OUT = c->hYR_OUT = c->YR_REC = nullptr;
@@ -621,7 +654,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
                       c->JL, c->JU, c->JS, c->JN, c->JC, c->KV[0], c->KV[1], c->KV[2], c->KV[3], c->KV[4], c->KVN[0], c->KVN[1], c->KVN[2], c->JB[0], c->JB[1],
                       c->JB[2], c->JB[3], c->JB[4], c->Y,
-                      c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
+                      c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->ZS, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->STEP_PART, c->RED, c->STAGE, c->RCOEF,
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI,
                       c->FB_INV, c->FCB_INVR, c->FCB_INVI, c->FB_TAB, c->FCB_TABR, c->FCB_TABI, c->LIGHT, c->UPR, c->YLIN,
@@ -648,6 +681,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->hPART) (void)hipHostFree(c->hPART);
     if (c->hPART2) (void)hipHostFree(c->hPART2);
     if (c->hPARTB) (void)hipHostFree(c->hPARTB);
+    if (c->hPARTC) (void)hipHostFree(c->hPARTC);
     if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
     if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
     if (c->hCTL) (void)hipHostFree(c->hCTL);

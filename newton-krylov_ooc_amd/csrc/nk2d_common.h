@@ -96,6 +96,7 @@ struct nk2d_ctx {
     int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
     int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
     int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
+    int swap_updates;  // 1: ... and so do the update launches of several-sweep iterations (vector norm hook)
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP, *TMP2;
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
     double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
@@ -154,6 +155,9 @@ struct nk2d_ctx {
     double* hPART;   // pinned, device-visible per-column partials [ncol] (host-controlled integrator)
     double* hPART2;  // same, for an error estimate queued behind a Newton iteration not yet judged
     double* hPARTB;  // same, second buffer for Newton iterations queued one ahead of the one being judged
+    double* hPARTC;  // ... and two ahead (vector norm hook)
+    double* ZS /*3nv*/;   // second spare set of stage values, allocated with a vector norm hook: iterations queued TWO ahead
+    int hook_spec_depth;  // option "hook_spec_depth": whole iterations a hooked controller queues ahead of a verdict (1 or 2)
     double* part_cur;  // where the next fused launch with the update puts its partials (null: hPART / PART)
     int part_on_host;
     int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch
@@ -195,6 +199,8 @@ struct nk2d_ctx {
     // norm_hook (an all-reduce supplied by the caller) and n_total is the module's size, not the shard's
     nk2d_norm_hook_fn norm_hook;
     void* norm_hook_user;
+    nk2d_norm_hook_vec_fn norm_hook_vec;   // several sums per call (nk2d_set_norm_hook_vec); norm_hook then wraps it
+    void* norm_hook_vec_user;
     double global_n;
     // persistent whole-year kernel (device_ctl 3, nk2d_kernels.hip): norm partials [2][ncol], result block,
     // barrier counter + abort flag, sweeps-per-shift table, schedule record, timing events

@@ -2652,7 +2652,9 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
     fill_fused_args(c, A, do_stage, first, do_update, mreal, mcr, mci, src, delta);
     // stage and update in ONE launch (single-sweep solve): the update must not overwrite stage values the
     // neighbouring columns are still reading -- it writes the spare buffer, the buffers swap after the launch
-    const bool swap_z = do_stage && do_update && c->single_swap;
+    // (a hooked controller that queues whole iterations ahead of a verdict, option "hook_spec_depth": the update of a
+    // several-sweep iteration goes the same way, so that it can be dropped)
+    const bool swap_z = do_update && (do_stage ? c->single_swap != 0 : c->swap_updates != 0);
     A.st.zout = swap_z ? c->ZN : c->Z;
     A.part = c->part_on_host ? (c->part_cur ? c->part_cur : c->hPART) : (c->part_cur ? c->part_cur : c->PART);
     // pivots / PCR tables of a new (h, J): computed inside the first launch that uses them

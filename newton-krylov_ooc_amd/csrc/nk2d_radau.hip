@@ -54,6 +54,7 @@ struct Ctl {
     double pre_t, pre_h;
     double fingerprint;  // nk2d_fingerprint of the context at the start of the year (recorded with every step)
     bool no_persistent = false;   // the one-launch frozen year was tried and given up for this year
+    int n_iter_prev = 0;          // Newton iterations of the last solve that converged (0: none yet)
 };
 
 double rms_from_sum(double s, double count) { return std::sqrt(s) / std::sqrt(count); }
@@ -212,8 +213,15 @@ int newton_back(Ctl& s, double mreal, double mcr, double mci) {
 // err_buf != nullptr: when the known contraction rate predicts that the iteration in flight is the
 // last one, the error estimate is queued right behind it (partials into hPART2); *err_buf >= 0 on
 // return then names the ping-pong buffer holding it, and the caller only has to wait for snap_ev[1].
+//
+// A vector norm hook (nk2d_set_norm_hook_vec: a tracer module sharded over contexts, every norm the controller reads an
+// all-reduce): the sum of the iteration being judged travels in ONE call with the sums of up to two iterations queued whole
+// behind it, and with the error estimate queued behind the last of them when that one is expected to end the step (from
+// the contraction rate once it is known, from the iteration count of the step before until then).  The later values
+// are kept for the turns of the loop -- or the caller -- that would have asked for them.  Same sums, same tests, same order:
+// an iteration or an estimate that turns out unwanted is dropped (its stage values sit in spare buffers).
 int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, double* rate_out, bool* have_rate,
-           int* err_buf = nullptr) {
+           int* err_buf = nullptr, double* err_sum_coupled = nullptr, bool* err_sum_is_coupled = nullptr) {
     nk2d_ctx* c = s.c;
     const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
     const bool single = std::max(s.m_real, s.m_cplx) == 1;   // the whole iteration is ONE launch
@@ -222,17 +230,27 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     *converged = false;
     const int kmax = force_iters >= 0 ? force_iters : NEWTON_MAXITER;
     const bool speculate = c->part_on_host && force_iters < 0 && c->speculate;
+    const bool pairing = c->norm_hook_vec != nullptr && speculate;
+    const int max_depth = (pairing && c->ZS) ? std::max(1, std::min(2, c->hook_spec_depth)) : 1;
+    const bool whole = single || (pairing && c->swap_updates);   // an iteration can be queued whole, and dropped
     // work queued ahead of the verdict on the iteration before: the launches before the last one (several sweeps),
-    // or the whole next iteration (single launch: its update goes to the spare stage buffer and to the other
-    // partial buffer, so an unwanted one is dropped by swapping the stage buffers back)
-    bool front_queued = false, whole_queued = false;
+    // or whole iterations (single launch: the update goes to a spare stage buffer and to a partial buffer of its own,
+    // so an unwanted one is dropped by swapping the stage buffers back)
+    bool front_queued = false;
+    int launched = -1;        // the last iteration queued whole
+    double held[2] = {0.0, 0.0};   // module-wide sums of iterations held_from, held_from + 1 (they came with an earlier one)
+    int held_from = 0, held_n = 0;
+    double held_err = 0.0;
+    bool have_held_err = false;
+    int err_behind = -1;      // the iteration the queued error estimate follows
     if (err_buf) *err_buf = -1;
+    if (err_sum_is_coupled) *err_sum_is_coupled = false;
     int k = -1;
-    auto part_of = [&](int it) { return (single && (it & 1)) ? c->hPARTB : c->hPART; };
-    auto event_of = [&](int it) { return single ? c->snap_ev[2 + (it & 1)] : c->snap_ev[0]; };
+    auto part_of = [&](int it) { return !whole ? c->hPART : (it % 3 == 0 ? c->hPART : (it % 3 == 1 ? c->hPARTB : c->hPARTC)); };
+    auto event_of = [&](int it) { return whole ? c->snap_ev[2 + it % 3] : c->snap_ev[0]; };
     for (k = 0; k < kmax; ++k) {
-        if (err_buf) *err_buf = -1;   // an estimate queued behind a non-final iteration is void
-        if (!whole_queued) {
+        if (err_buf && err_behind != k) *err_buf = -1;   // an estimate queued behind a non-final iteration is void
+        if (k > launched) {
             const bool timed = !front_queued;   // front and back launches are queued back to back
             if (timed) {
                 NK2D_TRY(nk2d_prof_window_begin(c));
@@ -243,41 +261,77 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             NK2D_TRY(newton_back(s, mreal, mcr, mci));
             if (timed) NK2D_TRY(nk2d_prof_window_end(c));
             if (speculate) NK2D_CHECK(c, hipEventRecord(event_of(k), c->stream));
+            launched = k;
         }
-        whole_queued = false;
         c->st.nfev += 3;
         c->st.nnewton++;
         if (force_iters >= 0) continue;
         double sum = 0.0;
-        bool spec_whole = false;
-        if (speculate) {
-            // queue the next iteration unless the last known contraction rate says that the iteration now in
-            // flight will pass SciPy's convergence test
-            bool likely_last = false;
+        bool coupled = false;
+        if (held_n > 0 && k >= held_from && k < held_from + held_n) {
+            // came with the iteration that queued this one: nothing is queued ahead of the verdict on this one
+            sum = held[k - held_from];
+            coupled = true;
+        } else if (speculate) {
+            held_n = 0;
+            have_held_err = false;
+            // which iteration is expected to pass SciPy's convergence test?  (far: none in sight)
+            const int far = k + 8;
+            int last_pred = far;
             if (has_rate && rate < 1.0) {
-                const double next_norm = rate * dW_norm_old;
-                likely_last = rate / (1.0 - rate) * next_norm < s.newton_tol;
+                double next_norm = rate * dW_norm_old;
+                for (int j = 0; j <= 2; ++j, next_norm *= rate)
+                    if (rate / (1.0 - rate) * next_norm < s.newton_tol) { last_pred = k + j; break; }
+            } else if (pairing && !has_rate) {
+                last_pred = s.n_iter_prev > 0 ? std::max(k, s.n_iter_prev - 1) : k + 1;
             }
-            if (k + 1 < kmax && !likely_last) {
-                if (single) {
-                    c->part_cur = part_of(k + 1);
-                    NK2D_TRY(newton_back(s, mreal, mcr, mci));
-                    NK2D_CHECK(c, hipEventRecord(event_of(k + 1), c->stream));
-                    spec_whole = true;
-                } else {
-                    NK2D_TRY(newton_front(s, mreal, mcr, mci));
-                    front_queued = true;
-                }
-            } else if (likely_last && err_buf && s.m_real <= 2) {
+            int depth = 0;
+            bool want_err = false;
+            if (pairing) {
+                if (whole) depth = std::max(0, std::min(std::min(max_depth, last_pred - k), kmax - 1 - k));
+                want_err = err_buf && err_sum_coupled && s.m_real <= 2 && k + depth == last_pred;
+            } else {
+                if (single && last_pred > k && k + 1 < kmax) depth = 1;
+                want_err = err_buf && s.m_real <= 2 && last_pred == k;
+            }
+            for (int j = k + 1; j <= k + depth; ++j) {
+                if (j - k == 2) std::swap(c->ZN, c->ZS);     // keep the stage values of iteration k
+                if (!single) NK2D_TRY(newton_front(s, mreal, mcr, mci));
+                c->part_cur = part_of(j);
+                NK2D_TRY(newton_back(s, mreal, mcr, mci));
+                NK2D_CHECK(c, hipEventRecord(event_of(j), c->stream));
+                launched = j;
+            }
+            if (!whole && last_pred > k && k + 1 < kmax) {
+                NK2D_TRY(newton_front(s, mreal, mcr, mci));
+                front_queued = true;
+            }
+            if (want_err) {
                 NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, c->hPART2));
                 NK2D_CHECK(c, hipEventRecord(c->snap_ev[1], c->stream));
+                err_behind = k + depth;
             }
-            NK2D_CHECK(c, hipEventSynchronize(event_of(k)));
-            NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, part_of(k)));
+            if (pairing && (depth > 0 || want_err)) {
+                double v[4];
+                int n = 0;
+                NK2D_CHECK(c, hipEventSynchronize(want_err ? c->snap_ev[1] : event_of(k + depth)));
+                for (int j = 0; j <= depth; ++j) NK2D_TRY(nk2d_part_sum(c, c->ncol, &v[n++], part_of(k + j)));
+                if (want_err) NK2D_TRY(nk2d_part_sum(c, c->ncol, &v[n++], c->hPART2));
+                c->norm_hook_vec(c->norm_hook_vec_user, v, n);
+                sum = v[0];
+                held_from = k + 1;
+                held_n = depth;
+                for (int j = 0; j < depth; ++j) held[j] = v[1 + j];
+                if (want_err) { held_err = v[n - 1]; have_held_err = true; }
+                coupled = true;
+            } else {
+                NK2D_CHECK(c, hipEventSynchronize(event_of(k)));
+                NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, part_of(k)));
+            }
         } else {
             NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
         }
-        couple(c, &sum);
+        if (!coupled) couple(c, &sum);
         const double dW_norm = rms_from_sum(sum, 3.0 * s.n_total);
         bool stop = false;
         if (!(dW_norm == dW_norm)) stop = true;  // NaN: treat as divergence
@@ -290,20 +344,27 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             stop = true;
         }
         if (stop) {
-            if (spec_whole) {
-                // the iteration queued ahead is not wanted: its stage values sit in the spare buffer, swap back
-                std::swap(c->Z, c->ZN);
-                c->st.nsolve -= 2;
+            // iterations queued ahead are not wanted: the stage values of this one sit in a spare buffer, swap back
+            const int unwind = launched - k;
+            if (unwind == 1) std::swap(c->Z, c->ZN);
+            else if (unwind == 2) std::swap(c->Z, c->ZS);
+            c->st.nsolve -= 2 * unwind;
+            if (err_buf && err_behind != k) {
+                *err_buf = -1;    // ... nor is an estimate behind them
+            } else if (*converged && err_buf && err_behind == k && have_held_err) {
+                // the estimate queued behind this iteration came with the norms: the caller has nothing to wait for
+                *err_sum_coupled = held_err;
+                *err_sum_is_coupled = true;
             }
             break;
         }
-        whole_queued = spec_whole;
         dW_norm_old = dW_norm;
         has_old = true;
     }
     c->part_cur = nullptr;
     if (force_iters >= 0) { *converged = true; *n_iter = force_iters; }
     else *n_iter = k + 1;
+    if (*converged && force_iters < 0) s.n_iter_prev = k + 1;
     *rate_out = rate;
     *have_rate = has_rate;
     return 0;
@@ -513,6 +574,8 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             double err_sum = 0.0;
             int buf = 0;
             int queued_err = -1;   // >= 0: the error estimate is already queued, in XR[queued_err]
+            double err_coupled = 0.0;      // ... and (vector norm hook) its module-wide sum came with the last Newton norm
+            bool err_is_coupled = false;
             while (!converged) {
                 if (!s.have_lu) NK2D_TRY(set_lu(s, h));
                 if (s.device_ctl == 1) {
@@ -522,7 +585,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 } else {
                     if (!predicted) NK2D_TRY(predict(s, t, h));
                     predicted = false;
-                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate, &queued_err));
+                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate, &queued_err, &err_coupled, &err_is_coupled));
                 }
                 if (!converged) {
                     if (s.current_jac) break;
@@ -541,10 +604,16 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             // error estimate (radau.py:477-487); with device control its first pass was queued
             // together with the attempt
             double sum = err_sum;
+            bool sum_coupled = false;
             if (s.device_ctl == 0 && queued_err >= 0) {
                 buf = queued_err;
-                NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[1]));
-                NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, c->hPART2));
+                if (err_is_coupled) {
+                    sum = err_coupled;
+                    sum_coupled = true;
+                } else {
+                    NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[1]));
+                    NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, c->hPART2));
+                }
             } else if (s.device_ctl != 1) {
                 if (s.m_real <= 2) {
                     NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf, nullptr));
@@ -555,7 +624,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 }
                 NK2D_TRY(nk2d_k_reduce(c, c->ncol, 1, &sum));
             }
-            couple(c, &sum);
+            if (!sum_coupled) couple(c, &sum);
             err = rms_from_sum(sum, s.n_total);
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             if (rejected && err > 1) {
@@ -1077,9 +1146,10 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     // step replay only
     struct SwapGuard {
         nk2d_ctx* c;
-        ~SwapGuard() { c->single_swap = 0; c->part_cur = nullptr; }
+        ~SwapGuard() { c->single_swap = 0; c->swap_updates = 0; c->part_cur = nullptr; }
     } swap_guard{c};
     c->single_swap = (s.device_ctl == 0) ? 1 : 0;
+    c->swap_updates = (s.device_ctl == 0 && c->norm_hook_vec && c->ZS) ? 1 : 0;
     // A free-running year checks the convergence of every simplified Newton iteration on the iterates
     // themselves, inexact inner solves included.  A replayed schedule dictates the iteration counts of an
     // integrator with direct solves, so there the inner solves must not be what limits the accuracy.

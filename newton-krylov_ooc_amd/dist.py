@@ -140,7 +140,7 @@ class ShardComm:
         return float(self._stage_np[0])
 
 
-def iage_shard_engine(grid, shard, comm, device_id=0, **kwargs):
+def iage_shard_engine(grid, shard, comm, device_id=0, **kwargs):  # noqa: D401
     """engine of ONE tracer of the iage module (shard 0: iage, 1: iage_slow_rest; iage.py:12-41) whose
     Radau controller is coupled with the other shard's through `comm`"""
     from .engine import ModuleEngine
@@ -150,7 +150,8 @@ def iage_shard_engine(grid, shard, comm, device_id=0, **kwargs):
     eng = ModuleEngine(grid, tc=1, surf_rate=(rates[shard],), const_src=1.0 / (365.0 * 86400.0),
                        device_id=device_id, **kwargs)
     eng.set_option("device_ctl", 0)
-    eng.set_norm_hook(comm.allreduce_scalar, 2.0 * len(grid.depth) * len(grid.ypos))
+    # the vector hook: the controller pairs what it can into one all-reduce (norm + next norm, norm + error estimate)
+    eng.set_norm_hook(comm.allreduce, 2.0 * len(grid.depth) * len(grid.ypos), vector=True)
     return eng
 
 

@@ -485,12 +485,23 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_multi_axpy(self._ctx, w.ptr, len(basis), ptrs, _dp(h), float(fill)))
         return w
 
-    def set_norm_hook(self, fcn, global_n):
+    def set_norm_hook(self, fcn, global_n, vector=False):
         """couple the integrator's scalar norms with other contexts holding tracers of the same module
-        (dist.TracerShardedModule): `fcn(local_sum_of_squares) -> global sum`; None removes the hook"""
+        (dist.TracerShardedModule): `fcn(local_sum_of_squares) -> global sum`; None removes the hook.
+        vector=True: `fcn(ndarray of local sums) -> ndarray of global sums` -- the controller then pairs the norm of a
+        Newton iteration with that of the iteration (or error estimate) queued behind it in one call"""
         if fcn is None:
             self._norm_hook = None
             self._chk(self._lib.nk2d_set_norm_hook(self._ctx, None, None, 0.0))
+            return
+        if vector:
+            def thunk(user, ptr, n):
+                vals = np.ctypeslib.as_array(ptr, shape=(n,))
+                vals[:] = fcn(vals.copy())
+
+            self._norm_hook = _lib.NORM_HOOK_VEC(thunk)     # keep the thunk alive
+            self._chk(self._lib.nk2d_set_norm_hook_vec(
+                self._ctx, ctypes.cast(self._norm_hook, ctypes.c_void_p), None, float(global_n)))
             return
         self._norm_hook = _lib.NORM_HOOK(lambda user, val: float(fcn(val)))   # keep the thunk alive
         self._chk(self._lib.nk2d_set_norm_hook(
