@@ -212,6 +212,20 @@ def test_norm_hook_couples_two_single_tracer_engines():
     for rank in range(2):
         assert np.array_equal(out[rank][2][:, :7], paired[rank][2][:, :7])      # identical schedules
         assert np.array_equal(out[rank][0], paired[rank][0])                      # identical years, bit for bit
+    # ... and with ONE iteration queued ahead instead of two (option "hook_spec_depth"): more collectives, the same year
+    scalar_calls, comm.calls = comm.calls, 0
+    for rank, eng in enumerate(shards):
+        eng.set_norm_hook(comm.bind(rank).allreduce, 2.0 * nz * ny, vector=True)
+        eng.set_option("hook_spec_depth", 1)
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert paired_calls < comm.calls < scalar_calls
+    for rank in range(2):
+        assert np.array_equal(out[rank][2][:, :7], paired[rank][2][:, :7])
+        assert np.array_equal(out[rank][0], paired[rank][0])
     sharded = np.concatenate([out[0][0], out[1][0]])
     whole = iage_engine(grid, lin_tol=1.0e-3)
     whole.set_option("device_ctl", 0)       # host control, as a hooked engine runs (the hook lives on the host)
