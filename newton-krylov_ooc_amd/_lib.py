@@ -179,7 +179,7 @@ def _one_hip_runtime():
     import importlib.util
     import sys
 
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("NK2D_HIP_RUNTIME", "") == "system":
         return
     try:
         spec = importlib.util.find_spec("torch")

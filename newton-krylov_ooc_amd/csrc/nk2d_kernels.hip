@@ -6,6 +6,7 @@
 // kernels keep the reference's operation order (nk_ooc/py_driver_2d/advection.py:51-76,
 // horiz_mix.py:50-71, vert_mix.py:24-87, iage.py:22-41); fused multiply-adds are
 // written out explicitly only inside the tridiagonal solves.
+#include <mutex>
 #include "nk2d_common.h"
 #include "nk2d_hostmath.h"
 
@@ -3553,6 +3554,15 @@ finish:
 #undef YEAR_PART
 }
 
+// Cooperative launches of one process go through ONE queue of the HIP runtime, created on first use: contexts driven from
+// several host threads (the tracer modules of a ModelState run their years in a thread pool) enqueue on it one at a time --
+// two threads inside hipLaunchCooperativeKernel at once left the runtime with a queue it crashed on when the process ended
+// (rocr::AMD::AqlQueue::~AqlQueue under hsa_shut_down; tools/probe_exit2.py).  Held for the enqueue only.
+static std::mutex& coop_launch_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 // host side: run the stepping loop of a forward year in the persistent kernel.  The caller has done SciPy's
 // prologue (f0 in F, initial step size, Jacobian at t0 with the plane of t0 in KV[3]).  Returns 1 when the
 // launch is not possible (grid not fully resident): the caller then steps under host control.
@@ -3614,8 +3624,11 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     void* args[2] = {&P, &A};
     hipError_t rc = hipErrorInvalidValue;
     NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
-    NK2D_DISPATCH_E(c->E, rc = hipLaunchCooperativeKernel((const void*)k_year_persistent<EE, 0>, dim3(nblk), dim3(NK2D_BLOCK),
-                                                           args, 0, c->stream));
+    {
+        std::lock_guard<std::mutex> coop(coop_launch_mutex());
+        NK2D_DISPATCH_E(c->E, rc = hipLaunchCooperativeKernel((const void*)k_year_persistent<EE, 0>, dim3(nblk), dim3(NK2D_BLOCK),
+                                                               args, 0, c->stream));
+    }
     if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
     NK2D_CHECK(c, rc);
     NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
@@ -4207,10 +4220,13 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     if (!ran) {
         A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
         hipError_t rc = hipErrorInvalidValue;
-        if (c->kind == 2) {
-            NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 2, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
-        } else {
-            NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 0, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
+        {
+            std::lock_guard<std::mutex> coop(coop_launch_mutex());
+            if (c->kind == 2) {
+                NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 2, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
+            } else {
+                NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 0, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
+            }
         }
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);

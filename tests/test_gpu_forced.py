@@ -107,14 +107,33 @@ def test_two_module_krylov(tmp_path, monkeypatch):
     want = trace["h_mat"][-1]
     assert rel_err(h_mat[0], want[0]) < 5e-2
     assert abs(h_mat[1, 0, 0, 0] - want[1, 0, 0, 0]) < 5e-2 * abs(want[1, 0, 0, 0])
-    if abs(h_mat[1, 1, 0, 0]) > 1.0e-4 * abs(h_mat[1, 0, 0, 0]):
-        assert rel_err(h_mat[1], want[1]) < 5e-2
+    # the breakdown itself is asserted (round-2 advice: no conditional skip): with products on frozen years h[1, 0] of the
+    # forced module is below 1e-4 of h[0, 0] -- the oracle's, from two free-running years, sits at its noise level instead
+    print("forced module: h[1,0]/h[0,0] =", abs(h_mat[1, 1, 0, 0]) / abs(h_mat[1, 0, 0, 0]),
+          "oracle:", abs(want[1, 1, 0, 0]) / abs(want[1, 0, 0, 0]))
+    assert abs(h_mat[1, 1, 0, 0]) < 1.0e-4 * abs(h_mat[1, 0, 0, 0])
     # the saved-state file holds both modules' tracers
     from nk_ooc_amd import ncio
 
     data, _ = ncio.read_file(os.path.join(str(tmp_path), "increment_00.nc"))
     assert {"iage", "iage_slow_rest", "dye"} <= set(data)
     ModelState.reset_class()
+
+
+def test_two_module_process_ends_cleanly():
+    """two modules whose years run from two host threads, Krylov solve, engines closed -- and, second run, left open: the
+    process must END with status 0.  (Two threads inside hipLaunchCooperativeKernel at once used to leave the HIP runtime
+    with a queue its tear-down crashed on, after every result was written: exit status 139.  The library now enqueues
+    cooperative launches one at a time.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("solve", "fcn_noreset"):
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "probe_exit2.py"), mode],
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, (mode, res.returncode, res.stdout[-500:], res.stderr[-1500:])
+        assert f"{mode} " in res.stdout and "done" in res.stdout
 
 
 FILE_TAGS = ["file_restore_sms_22x9", "file_sink_thres_22x9", "file_restore_decay_70x5"]
