@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libnk2d.so")
+LIB_PATH = os.environ.get("NK2D_LIB_PATH") or os.path.join(CSRC, "libnk2d.so")   # (the override: A/B builds of tools/)
 
 MAX_TRACERS = 4
 SCHED_WIDTH = 8
