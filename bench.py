@@ -57,6 +57,35 @@ def progress(msg):
 _T0 = time.perf_counter()
 
 
+class AuxDeadline:
+    """N > 1 only.  The auxiliary legs (shard_e2, config4_mix, shard_e3) run collectives that no box of this pool could
+    rehearse over RCCL -- the one-GPU boxes run them over gloo -- and a rank that fails inside one of them leaves the others
+    waiting in a collective that RCCL never gives up on: the headline measured before them would be lost with the job.  So
+    the legs get a wall-clock budget (--aux-budget), started on all ranks behind a barrier: when it runs out rank 0 prints
+    the line with what it has (the leg that was running named in `aux_legs_timed_out`) and every rank leaves with status 0."""
+
+    def __init__(self, seconds, rank, out):
+        import threading
+
+        self.rank, self.out, self.leg, self.seconds = rank, out, None, seconds
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _fire(self):
+        try:
+            if self.rank == 0 and self.out is not None:
+                line = dict(self.out)
+                line["aux_legs_timed_out"] = {"running": self.leg, "budget_s": self.seconds}
+                print(json.dumps(line), flush=True)
+            progress(f"auxiliary legs over their budget of {self.seconds:.0f} s in {self.leg}: leaving")
+        finally:
+            os._exit(0)
+
+    def cancel(self):
+        self._timer.cancel()
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child
     processes (nothing in this process has touched the GPU) and relay what rank 0 prints"""
@@ -622,6 +651,8 @@ def main():
     ap.add_argument("--mix-steps", type=int, default=3, help="Krylov iterations timed in the three-module leg")
     ap.add_argument("--shard-budget", type=float, default=120.0,
                     help="skip the sharded-module leg when its expected wall time exceeds this many seconds")
+    ap.add_argument("--aux-budget", type=float, default=600.0,
+                    help="N > 1: seconds the auxiliary legs may take before rank 0 prints the line without them (0: no limit)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, all-reduce their ranks over gloo and print the world size "
                          "(CPU check of the self-launch path, tests/test_dist.py)")
@@ -664,6 +695,7 @@ def main():
     device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     n = args.grid
     wl = None
+    deadline = None
     try:
         progress(f"set-up of iage {n}x{n}")
         wl = Workload(n, local_rank, f"r{rank}", write_files=not args.no_files)
@@ -810,15 +842,25 @@ def main():
             faithful_attempts = st_f["nsteps"] + st_f["nrejected"]
         wl.close()
         wl = None
+        if world > 1 and args.aux_budget > 0:
+            torch.distributed.barrier()
+            deadline = AuxDeadline(args.aux_budget, rank, out)
         if world >= 2 and not args.no_shard:
             progress("shard_e2: one module, tracer per rank")
             base = wl_base_stats
             hint = base["nnewton"] + 2 * (base["nsteps"] + base["nrejected"]) + 10
-            shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
+            if deadline:
+                deadline.leg = "shard_e2"
+            try:
+                shard = run_shard_e2(args, rank, local_rank, world, backend, one_gpu_ms, hint)
+            except Exception as exc:           # an auxiliary leg must not cost the line
+                shard = {"error": f"{type(exc).__name__}: {exc}"}
             if rank == 0:
                 out["shard_e2"] = shard
         if not args.no_mix:
             progress("config4_mix: iage + phosphorus + forced")
+            if deadline:
+                deadline.leg = "config4_mix"
             try:
                 mix = run_config4_mix(args, rank, local_rank, world, device)
             except Exception as exc:           # an auxiliary leg must not cost the line (same failure on every rank)
@@ -835,12 +877,16 @@ def main():
                         "ms_per_krylov_iteration": mix["distributed"]["ms_per_krylov_iteration"]}
         if not args.no_shard3 and world >= 2:
             progress("shard_e3: phosphorus, Krylov basis columns over the ranks")
+            if deadline:
+                deadline.leg = "shard_e3"
             try:
                 shard3 = run_shard_e3(args, rank, local_rank, world, backend)
             except Exception as exc:
                 shard3 = {"error": f"{type(exc).__name__}: {exc}"}
             if rank == 0:
                 out["shard_e3"] = shard3
+        if deadline:
+            deadline.cancel()
         if rank == 0:
             if world == 1 and not args.no_ladder:
                 progress("ladder 26 .. 208")
@@ -867,6 +913,8 @@ def main():
                     out["shard_e3"] = {"error": f"{type(exc).__name__}: {exc}"}
             print(json.dumps(out), flush=True)
     finally:
+        if deadline:
+            deadline.cancel()
         if wl is not None:
             wl.close()
         if world > 1:

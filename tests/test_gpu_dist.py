@@ -88,6 +88,18 @@ def test_bench_two_ranks():
     assert "skipped" not in out["shard_e2"] and out["shard_e2"]["grid"] == [12, 12]
 
 
+def test_bench_two_ranks_keeps_its_line_when_the_auxiliary_legs_run_out_of_time():
+    """--aux-budget: the legs behind the headline get a wall-clock budget on all ranks; when it runs out (here at once) rank 0
+    prints the line without them and every rank leaves with status 0 -- a leg stuck in a collective cannot cost the record"""
+    res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "26",
+                   "--cpu-baseline-seconds", "0", "--shard-grid", "12", "--aux-budget", "0.05"], 29543)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0.0 and out["value_reference_semantic"] > 0.0
+    assert out["aux_legs_timed_out"]["budget_s"] == 0.05 and "shard_e3" not in out
+
+
 def test_bench_starts_its_own_ranks_on_the_gpu_box():
     """the driver's invocation: `python bench.py --gpus 2`, no launcher, no WORLD_SIZE"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
