@@ -949,6 +949,10 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
     else if (key == "frozen_resumes") v = c->frozen_resumes;
+    else if (key == "spec_launches_dropped") v = c->cnt_spec_dropped;
+    else if (key == "spec_front_launches_dropped") v = c->cnt_front_dropped;
+    else if (key == "err_estimates_queued") v = c->cnt_err_queued;
+    else if (key == "err_estimates_dropped") v = c->cnt_err_void;
     else return nk2d_fail(c, "nk2d_get_counter: unknown counter " + key);
     if (out) *out = v;
     return 0;

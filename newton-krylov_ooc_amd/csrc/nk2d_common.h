@@ -158,6 +158,8 @@ struct nk2d_ctx {
     double* hPARTC;  // ... and two ahead (vector norm hook)
     double* ZS /*3nv*/;   // second spare set of stage values, allocated with a vector norm hook: iterations queued TWO ahead
     int hook_spec_depth;  // option "hook_spec_depth": whole iterations a hooked controller queues ahead of a verdict (1 or 2)
+    // what the host-side controller queued ahead of a verdict and had to drop (nk2d_get_counter)
+    int64_t cnt_spec_dropped, cnt_front_dropped, cnt_err_void, cnt_err_queued;
     double* part_cur;  // where the next fused launch with the update puts its partials (null: hPART / PART)
     int part_on_host;
     int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch

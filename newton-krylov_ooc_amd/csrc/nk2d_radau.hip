@@ -249,7 +249,10 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     auto part_of = [&](int it) { return !whole ? c->hPART : (it % 3 == 0 ? c->hPART : (it % 3 == 1 ? c->hPARTB : c->hPARTC)); };
     auto event_of = [&](int it) { return whole ? c->snap_ev[2 + it % 3] : c->snap_ev[0]; };
     for (k = 0; k < kmax; ++k) {
-        if (err_buf && err_behind != k) *err_buf = -1;   // an estimate queued behind a non-final iteration is void
+        if (err_buf && err_behind != k) {   // an estimate queued behind a non-final iteration is void
+            if (*err_buf >= 0) c->cnt_err_void++;
+            *err_buf = -1;
+        }
         if (k > launched) {
             const bool timed = !front_queued;   // front and back launches are queued back to back
             if (timed) {
@@ -307,6 +310,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
                 front_queued = true;
             }
             if (want_err) {
+                c->cnt_err_queued++;
                 NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, c->hPART2));
                 NK2D_CHECK(c, hipEventRecord(c->snap_ev[1], c->stream));
                 err_behind = k + depth;
@@ -349,7 +353,10 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             if (unwind == 1) std::swap(c->Z, c->ZN);
             else if (unwind == 2) std::swap(c->Z, c->ZS);
             c->st.nsolve -= 2 * unwind;
+            c->cnt_spec_dropped += (int64_t)unwind * std::max(s.m_real, s.m_cplx);
+            if (front_queued) c->cnt_front_dropped += std::max(s.m_real, s.m_cplx) - 1;
             if (err_buf && err_behind != k) {
+                if (*err_buf >= 0) c->cnt_err_void++;
                 *err_buf = -1;    // ... nor is an estimate behind them
             } else if (*converged && err_buf && err_behind == k && have_held_err) {
                 // the estimate queued behind this iteration came with the norms: the caller has nothing to wait for
@@ -667,11 +674,13 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         const double h_abs_next = h_abs * factor;
         // One launch for the whole boundary where nothing in between needs the host: the commit, the Jacobian at
         // t_new when one is due (SciPy's recompute_jac, or the engines' Jacobian at every step start) and the set-up
-        // of the next step's first attempt, whose step size is known now.  History sampling and the device-side
-        // controllers keep the separate launches.
+        // of the next step's first attempt, whose step size is known now.  Steps with a history sample and the
+        // device-side controllers keep the separate launches.
         const bool jac_due = recompute_jac || c->jac_fresh;
         const bool jac_needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
-        bool fused = s.device_ctl == 0 && c->hist_n == 0 && t + h == t_new && t_new < s.t1;
+        // (a year with history samples: only the steps that hold a sample time keep the separate launches)
+        const bool sample_due = c->hist_n > 0 && c->hist_next < c->hist_n && c->hist_t[c->hist_next] <= t_new;
+        bool fused = s.device_ctl == 0 && !sample_due && t + h == t_new && t_new < s.t1;
         double h2 = 0.0;
         if (fused) {
             // the next step's first attempt, as the top of this loop will compute it

@@ -14,6 +14,7 @@ import functools
 import json
 import logging
 import os
+import pickle
 
 import numpy as np
 
@@ -65,8 +66,26 @@ class SolverState:
             return json.load(fptr, object_hook=_from_json)
 
     def _store(self):
+        """the text json.dump(self._data, fptr, indent=2, default=_to_json) writes, byte for byte -- put together from the
+        encoded text of every top-level value, re-encoded only when the value changed: the file is rewritten after every
+        change and an indented dump runs in json's pure-Python encoder, over a Hessenberg that grows with every Krylov
+        iteration (6 dumps per iteration: 2 ms of a 15 ms Krylov iteration at 26 x 26)"""
+        cache = self.__dict__.setdefault("_text_cache", {})
+        parts = []
+        for key, value in self._data.items():
+            if isinstance(value, np.ndarray):
+                snap = (value.shape, value.dtype.str, value.tobytes())
+            else:
+                snap = pickle.dumps(value, protocol=pickle.HIGHEST_PROTOCOL)
+            hit = cache.get(key)
+            if hit is None or hit[0] != snap:
+                text = json.dumps(value, indent=2, default=_to_json).replace("\n", "\n  ")
+                hit = cache[key] = (snap, text)
+            parts.append(f"  {json.dumps(key)}: {hit[1]}")
+        for key in [k for k in cache if k not in self._data]:
+            del cache[key]
         with open(self._path, mode="w") as fptr:
-            json.dump(self._data, fptr, indent=2, default=_to_json)
+            fptr.write("{\n" + ",\n".join(parts) + "\n}" if parts else "{}")
 
     def _announce(self):
         LOG.info('"%s" iteration now %d', self._name, self._data["iteration"])

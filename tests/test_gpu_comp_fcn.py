@@ -227,3 +227,40 @@ def test_frozen_product_against_the_oracle(nz, ny, vv, kh):
         f0, f1 = job0.result(), job1.result()
     w_oracle = (f1 - f0) / sigma[0]
     assert rel_err(eng.download(w).reshape(-1), w_oracle) < 2e-3
+
+
+def test_year_with_history_samples_is_the_same_year():
+    """nk2d_comp_fcn_hist (the year that gives F(x) AND the 61 samples of hist_NN.nc, scipy ivp.py:707-723): the samples cost
+    the steps that hold one their separate launches and nothing else -- the same decisions, the same F(x) bit for bit, the
+    first sample the start, the last one the end of the year; an interior one against the CPU oracle's dense output"""
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    n = 52
+    eng = iage_engine(Grid2d.default(n, n))
+    eng.set_option("device_ctl", 0)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
+    x = eng.upload(y0)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    t_eval = np.linspace(0.0, 365.0 * 86400.0, 61)
+    fxh, sth, hist = eng.comp_fcn_hist(x, t_eval)
+    assert np.array_equal(eng.download(fx), eng.download(fxh))
+    for key in ("nsteps", "nrejected", "nnewton", "nfev"):
+        assert st[key] == sth[key], key
+    # (njev / nlu count launches that evaluate or factorise: the unfused boundary of a sample step books a Jacobian the
+    # fused one shares with the next attempt -- a handful per year)
+    assert abs(st["njev"] - sth["njev"]) <= 61 and abs(st["nlu"] - sth["nlu"]) <= 122
+    # at most the 61 steps with a sample went without the fused boundary (a handful of launches each)
+    assert st["nlaunch"] <= sth["nlaunch"] <= st["nlaunch"] + 61 * 12
+    assert np.array_equal(hist[0], y0)
+    # F(x) of iage is the end state minus the start state (iage.py / model_state.py comp_fcn)
+    assert np.allclose(hist[-1] - y0, eng.download(fx), rtol=0.0, atol=1e-12 * np.abs(hist[-1]).max())
+    # monotone ageing in the interior: every sample lies between its neighbours' extremes (a swapped or stale buffer would not)
+    mid = hist[1:-1]
+    assert np.all(np.isfinite(hist)) and np.all(mid.max(axis=(1, 2, 3)) <= hist[-1].max() * (1 + 1e-9) + 1e-12)
+    # a sample is the dense output of the accepted step that holds it: the state a replayed year reaches at the end of that
+    # step and at the end of the one before bracket it
+    k = 30
+    row = np.searchsorted(sched[:, 1], t_eval[k])
+    assert sched[row, 0] < t_eval[k] <= sched[row, 1]

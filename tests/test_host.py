@@ -278,3 +278,39 @@ def test_host_arithmetic_under_address_sanitizer():
     res = subprocess.run(["make", "-C", csrc, "asan-host"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "hostmath ok" in res.stdout
+
+
+def test_solver_state_file_is_what_json_dump_writes(tmp_path):
+    """the state file is put together from cached per-value text (an indented dump runs in json's pure-Python encoder, six
+    times per Krylov iteration): byte for byte what json.dump(data, indent=2) writes, after every kind of change"""
+    import io
+    import json
+
+    from nk_ooc_amd.solver_state import _to_json
+
+    st = SolverState("Krylov", str(tmp_path / "wd"))
+    rng = np.random.default_rng(0)
+
+    def check():
+        want = io.StringIO()
+        json.dump(st._data, want, indent=2, default=_to_json)
+        with open(st._path) as fptr:
+            assert fptr.read() == want.getvalue()
+
+    check()
+    for it in range(5):
+        st.inc_iteration()
+        check()
+        st.log_step('a "step"\nwith a newline')
+        check()
+        st.set_value_saved_state("h_mat", rng.standard_normal((2, it + 2, it + 1, 1)))
+        check()
+        st.set_value_saved_state("beta", rng.standard_normal((2, 1)))     # same key, same shape, new values
+        check()
+        st.set_value_saved_state("flag", bool(it % 2))
+        st.set_value_saved_state("name", f'x"y{it}')
+        st.set_value_saved_state("lst", [1, 2.5, "a", [3, 4, it]])
+        st.set_value_saved_state("empty", [])
+        check()
+    again = SolverState("Krylov", str(tmp_path / "wd"), resume=True)
+    assert np.array_equal(again.get_value_saved_state("h_mat"), st.get_value_saved_state("h_mat"))
