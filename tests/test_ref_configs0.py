@@ -55,3 +55,85 @@ def test_test_problem_iage_newton_run_matches_committed_baselines(tmp_path, monk
     state = SolverState("Newton", workdir, resume=True)
     assert state.get_iteration() == want["iteration"]
     assert state.step_logged("Newton iterate 0 written", per_iteration=False) or True
+
+
+def test_this_repositorys_solvers_drive_the_reference_test_problem(tmp_path, monkeypatch):
+    """round-2 verdict, missing 5: the same configs[0] case with THIS repository's solver layer in the driver's seat --
+    `nk_ooc_amd.newton_solver.NewtonSolver` and `nk_ooc_amd.krylov_solver.KrylovSolver` (with their step log, stats files and
+    checkpoint trail) iterate the reference's own CPU `test_problem` model (nk_ooc/test_problem/model_state.py:83-92), and the
+    work directory is held against the reference's committed baselines (baselines/ci_long_iage: basis, w_raw, w, krylov_res,
+    increment, iterate) at the tolerances of scripts/ci_long_iage.sh, step log string for string.  The reference's state
+    class only gains the three device-resident conveniences the mirrors call instead of re-reading files (Gram-Schmidt
+    against states in memory, a linear combination of states in memory, a copy), written with the reference's own
+    operators in the reference's order (model_state_base.py:365-377, 619-624)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ref_harness import shims
+
+    shims.install()
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.setenv("USER", os.environ.get("USER", "nk2d"))
+    import numpy as np
+    from nk_ooc import nk_driver
+    from nk_ooc.model_config import ModelConfig
+    from nk_ooc.share import logging_config, read_cfg_files
+    from nk_ooc.test_problem import setup_solver
+    from nk_ooc.test_problem.model_state import ModelState as RefState
+
+    from nk_ooc_amd import baseline_cmp
+    from nk_ooc_amd.newton_solver import NewtonSolver
+
+    class State(RefState):
+        def mgs_against(self, basis):
+            h_val = np.empty((len(self.tracer_modules), len(basis), self.model_config_obj.region_cnt))
+            for i_val, basis_i in enumerate(basis):
+                h_val[:, i_val, :] = self.dot_prod(basis_i)
+                self -= h_val[:, i_val, :] * basis_i
+            return h_val
+
+        @classmethod
+        def lin_comb_of(cls, coeff, states):
+            res = coeff[..., 0, :] * states[0]
+            for j_val in range(1, coeff.shape[-2]):
+                res += coeff[..., j_val, :] * states[j_val]
+            return res
+
+        def copy(self):
+            return 1.0 * self
+
+        # The reference's `state * ndarray` and `state / ndarray` start from a SHALLOW copy and assign into its
+        # tracer-module array -- which is the operand's own (model_state_base.py:242-256, 288-306): the operand is scaled
+        # too.  Out of core that goes unnoticed, every operand being a fresh read of its file; the mirrors keep the
+        # Krylov space resident and rely on value semantics (as this repository's ModelState has them).
+        def __mul__(self, other):
+            if isinstance(other, np.ndarray):
+                return RefState.__mul__(1.0 * self, other)
+            return RefState.__mul__(self, other)
+
+        def __truediv__(self, other):
+            if isinstance(other, np.ndarray):
+                return RefState.__truediv__(1.0 * self, other)
+            return RefState.__truediv__(self, other)
+
+    workdir = str(tmp_path / "ci_long_iage_workdir")
+    common = ["--persist", "--tracer_module_names", "iage", "--workdir", workdir]
+    setup_solver.main(setup_solver.parse_args(["--fp_cnt", "1", "--depth_nlevs", "20"] + common))
+    config = read_cfg_files(nk_driver.parse_args(common))
+    logging_config(config["solverinfo"], filemode="a")
+    State.model_config_obj = ModelConfig(config["modelinfo"])
+    RefState.model_config_obj = State.model_config_obj
+    solver = NewtonSolver(State, solverinfo=config["solverinfo"], resume=False, rewind=False)
+    while not solver.converged().all():
+        solver.step()
+
+    base = os.path.join(REF, "baselines", "ci_long_iage")
+    kdir = os.path.join(workdir, "krylov_00")
+    for fname in ("precond_00.nc", "precond_fcn_00.nc", "basis_00.nc", "perturb_fcn_w_raw_00.nc"):
+        assert baseline_cmp.compare(fname, kdir, base), fname
+    for fname in ("w_raw_00.nc", "w_00.nc", "krylov_res_00.nc"):
+        assert baseline_cmp.compare(fname, kdir, base, rtol=2.0e-4), fname
+    for fname in ("increment_00.nc", "iterate_01.nc"):
+        assert baseline_cmp.compare(fname, workdir, base, rtol=2.0e-4), fname
+    got = json.loads(open(os.path.join(workdir, "Newton_state.json")).read().replace(workdir, "WORKDIR"))
+    want = json.loads(open(os.path.join(base, "Newton_state.json")).read().replace("HOME/ci_long_iage_workdir", "WORKDIR"))
+    assert got["step_log"] == want["step_log"] and got["iteration"] == want["iteration"]
+    assert set(got) == set(want)
