@@ -163,6 +163,25 @@ def test_vector_collectives_work_in_place_on_engine_memory():
         assert np.array_equal(comm.allreduce(np.arange(6.0).reshape(3, 2)), np.arange(6.0).reshape(3, 2))
         small = nkdist.ShardComm(torch.device("cuda", 0))
         assert small.allreduce_scalar(3.5) == 3.5
+        # every other collective bench.py and dist.py issue on the RCCL branch, on this one-rank communicator: the
+        # barrier, the MAX of the elapsed times (float64), the AND of the convergence flags (MIN over int32) on the
+        # world group and on a sub-group, the sum of a small float64 array through the device staging path
+        tdist.barrier()
+        el = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
+        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+        assert float(el.item()) == 1.25
+        sub = tdist.new_group([0])
+        for group in (None, sub):
+            flag = nkdist._AllFlag(np.array([True, True]), torch.zeros(1, dtype=torch.int32, device="cuda:0"), group)
+            # (a one-rank group answers locally; the collective itself, as _AllFlag issues it for more ranks:)
+            assert flag.all() is True
+            buf = torch.ones(1, dtype=torch.int32, device="cuda:0")
+            tdist.all_reduce(buf, op=tdist.ReduceOp.MIN, group=group)
+            assert int(buf.item()) == 1
+        arr = small._buf[:3]
+        arr.copy_(torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64))
+        tdist.all_reduce(arr, op=tdist.ReduceOp.SUM, group=sub)
+        assert arr.cpu().tolist() == [1.0, 2.0, 3.0]
     finally:
         if started:
             tdist.destroy_process_group()
