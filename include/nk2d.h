@@ -210,7 +210,9 @@ int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
    "frozen_cache_gb").  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
-   "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes". */
+   "frozen_xcd_years" (of them: all workgroups on one XCD), "frozen_team_years" (of them: a four-wave team per column),
+   "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes"; of the host-side controller: "spec_launches_dropped",
+   "spec_front_launches_dropped", "err_estimates_queued", "err_estimates_dropped" (work queued ahead of a verdict). */
 int nk2d_get_counter(nk2d_ctx* ctx, const char* name, int64_t* out);
 /* hash of everything a recorded schedule depends on besides the state: grid, module description, tolerances, the
    controller options (jac_fresh, jac_stage, lin_tol, min_sweeps, growth_cap, factor storage) and the library version;
@@ -370,7 +372,9 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    factorisation on the step-ending launch; 0 default -- measured neutral, profiles/r03_prefactor),
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
-   grids, see nk2d_get_counter), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
+   grids, see nk2d_get_counter), "frozen_team" (a four-wave team per column inside that launch -- 1, default: where it pays,
+   grids of more than 32 and at most 128 levels; 2: wherever it exists; 0: a wave per column),
+   "hook_spec_depth" (1 or 2, default 2: whole Newton iterations a controller with a vector norm hook queues ahead of a verdict), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
    then the year is rerun launch by launch), "year_fences" (1: release / acquire fences around those barriers, validation),
    "pc_fp32" (1: the preconditioner's Schur inverses stored in single precision -- half the HBM -- and every apply refined
    "pc_refine" times, default 1, against the exact block tridiagonal operator; set before nk2d_precond_setup) */

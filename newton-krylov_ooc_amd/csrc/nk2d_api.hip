@@ -147,6 +147,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
     if (key == "frozen_persistent") { c->frozen_persistent = value != 0.0; return 0; }
     if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
+    if (key == "frozen_team") { c->frozen_team = (int)value; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
     if (key == "frozen_cache_gb") { c->frozen_cache_max_gb = value; return 0; }
     if (key == "barrier_timeout_ms") {
@@ -509,6 +510,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_cache_max_gb = 16.0;
     c->frozen_cache_builds = c->frozen_persistent_years = c->frozen_xcd_years = 0;
     c->frozen_xcd = 1;
+    c->frozen_team = 1;
     c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;
@@ -947,6 +949,7 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     if (key == "frozen_persistent_years") v = c->frozen_persistent_years;
     else if (key == "frozen_cache_builds") v = c->frozen_cache_builds;
     else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
+    else if (key == "frozen_team_years") v = c->frozen_team_years;
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
     else if (key == "frozen_resumes") v = c->frozen_resumes;
     else if (key == "spec_launches_dropped") v = c->cnt_spec_dropped;

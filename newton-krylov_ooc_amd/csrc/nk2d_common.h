@@ -143,6 +143,8 @@ struct nk2d_ctx {
     double frozen_cache_max_gb;     // ... whose schedule cache stays below this size (option "frozen_cache_gb")
     int64_t frozen_cache_builds, frozen_persistent_years, frozen_xcd_years;
     int frozen_xcd, frozen_xcd_failed;   // option "frozen_xcd": the year's workgroups on one XCD; set once the placement failed
+    int frozen_team;      // option "frozen_team": a four-wave team per column inside the one-launch frozen year (grids of at most two levels per lane)
+    int64_t frozen_team_years;
     double barrier_timeout_ms;  // longest wait at a grid barrier of the persistent year (option "barrier_timeout_ms")
     int year_fences;            // 1: release / acquire fences around its grid barriers (option "year_fences", validation)
     int64_t frozen_resumes;     // ... and resumed from a checkpoint with one more Newton iteration (nk2d_frozen_resumes)

@@ -1674,7 +1674,9 @@ __device__ __forceinline__ void lds_get(const double* s, int lane, double (&v)[E
 // one after the other, wave 1 the complex system -- for modules with more columns than four-wave teams fit the chip
 // at once (iage 416^2: 832 columns = 1 664 pair waves of <= 256 VGPRs, one round).  FIN (pairs only): the launch also
 // ends a frozen step (FinalArgs; the plane workgroups follow the nblk_cols column workgroups, as in k_newton_final).
-template <int E, int KIND, int FACTOR, int STAGE, int NW, int FIN>
+// MP: the accessors of a persistent kernel (1: write-through stores, L1-bypassing loads; 2: plain stores, L1-bypassing loads)
+// for everything that another wave reads in a later phase.
+template <int E, int KIND, int FACTOR, int STAGE, int NW, int FIN, int MP = 0>
 __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs& A, TeamLds<E, (NW == 4 ? 3 : 0)>& S, int task, int w, int lane,
                                                  const FinalArgs* fin) {
     constexpr int CW = NW - 1;      // the complex wave
@@ -1709,7 +1711,7 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                 load_col<E>(A.sw.fr_inv, task, lane, rinv);
                 load_tab<E>(A.sw.fr_tab, task, lane, rtab);
             }
-            if constexpr (NW == 4) load_col<E>(A.st.w, task, lane, w0);
+            if constexpr (NW == 4) load_col<E, MP>(A.st.w, task, lane, w0);
             lds_put<E>(S.a, lane, a);
             lds_put<E>(S.c, lane, cc);
             lds_put<E>(S.inv, lane, rinv);
@@ -1742,8 +1744,8 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
         double fcr[E], fci[E];
         if (stage) {
             double w1[E], w2[E];
-            load_col<E>(A.st.w + A.st.nv, task, lane, w1);
-            load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+            load_col<E, MP>(A.st.w + A.st.nv, task, lane, w1);
+            load_col<E, MP>(A.st.w + 2 * A.st.nv, task, lane, w2);
             if constexpr (NW == 4) {
                 lds_put<E>(S.W[1], lane, w1);
                 lds_put<E>(S.W[2], lane, w2);
@@ -1763,26 +1765,26 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                 fci[e] = si - (A.st.mcr * w2[e] + A.st.mci * w1[e]);
             }
             if (!A.do_update && !A.delta) {  // later sweeps read the right-hand sides back
-                store_col<E>(A.st.bcr, task, lane, fcr);
-                store_col<E>(A.st.bci, task, lane, fci);
+                store_col<E, MP>(A.st.bcr, task, lane, fcr);
+                store_col<E, MP>(A.st.bci, task, lane, fci);
             }
         } else if (A.delta) {
 #pragma unroll
             for (int e = 0; e < E; ++e) { fcr[e] = 0.0; fci[e] = 0.0; }
         } else {
-            load_col<E>(A.sw.bcr, task, lane, fcr);
-            load_col<E>(A.sw.bci, task, lane, fci);
+            load_col<E, MP>(A.sw.bcr, task, lane, fcr);
+            load_col<E, MP>(A.sw.bci, task, lane, fci);
         }
         if (!A.sw.first) {
             double js[E], jn[E], xs[E], xn[E];
             load_col<E>(A.sw.JS, j, lane, js);
             load_col<E>(A.sw.JN, j, lane, jn);
-            load_col<E>(A.sw.xcr_old, cs_col, lane, xs);
-            load_col<E>(A.sw.xcr_old, cn_col, lane, xn);
+            load_col<E, MP>(A.sw.xcr_old, cs_col, lane, xs);
+            load_col<E, MP>(A.sw.xcr_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) fcr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fcr[e]));
-            load_col<E>(A.sw.xci_old, cs_col, lane, xs);
-            load_col<E>(A.sw.xci_old, cn_col, lane, xn);
+            load_col<E, MP>(A.sw.xci_old, cs_col, lane, xs);
+            load_col<E, MP>(A.sw.xci_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) fci[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fci[e]));
             if constexpr (KIND == 1) {
@@ -1825,16 +1827,16 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
         for (int e = 0; e < E; ++e) { fcr[e] = r[e].re; fci[e] = r[e].im; }
         if (!A.do_stage && A.delta) {  // correction of the first sweep's solution
             double x1[E];
-            load_col<E>(A.sw.xcr_old, task, lane, x1);
+            load_col<E, MP>(A.sw.xcr_old, task, lane, x1);
 #pragma unroll
             for (int e = 0; e < E; ++e) fcr[e] = x1[e] + fcr[e];
-            load_col<E>(A.sw.xci_old, task, lane, x1);
+            load_col<E, MP>(A.sw.xci_old, task, lane, x1);
 #pragma unroll
             for (int e = 0; e < E; ++e) fci[e] = x1[e] + fci[e];
         }
         if (!A.do_update) {
-            store_col<E>(A.sw.xcr_new, task, lane, fcr);
-            store_col<E>(A.sw.xci_new, task, lane, fci);
+            store_col<E, MP>(A.sw.xcr_new, task, lane, fcr);
+            store_col<E, MP>(A.sw.xci_new, task, lane, fci);
             return;
         }
         lds_put<E>(S.D[1], lane, fcr);
@@ -1845,7 +1847,7 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
 #pragma unroll
         for (int e = 0; e < E; ++e) acc += (S.F[0][e * 64 + lane] + S.F[1][e * 64 + lane]) + S.F[2][e * 64 + lane];
         acc = wave_sum(acc);
-        if (lane == 0) A.part[task] = acc;
+        if (lane == 0) st_mp<MP>(A.part + task, acc);
         return;
     }
 
@@ -1853,22 +1855,22 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
     double yy[E];
     double wpre[E];      // pairs: W_0 of the real right-hand side, fetched before the stages
     if constexpr (NW == 2) {
-        if (stage) load_col<E>(A.st.w, task, lane, wpre);
+        if (stage) load_col<E, MP>(A.st.w, task, lane, wpre);
     }
     if (STAGE && A.do_stage) {
         ColCoef<E> cf;
         load_coef<E>(P, j, lane, cf);
         double ys[E], yn[E];
-        load_col<E>(A.st.y, task, lane, yy);
-        load_col<E>(A.st.y, cs_col, lane, ys);
-        load_col<E>(A.st.y, cn_col, lane, yn);
+        load_col<E, MP>(A.st.y, task, lane, yy);
+        load_col<E, MP>(A.st.y, cs_col, lane, ys);
+        load_col<E, MP>(A.st.y, cn_col, lane, yn);
         for (int i = w; i < 3; i += NS) {
             const double* __restrict__ zi = A.st.z + (size_t)i * A.st.nv;
             const double* __restrict__ kvi = (i == 0) ? A.st.kv[0] : ((i == 1) ? A.st.kv[1] : A.st.kv[2]);
             double c[E], cs[E], cn[E], kv[E], f[E];
-            load_col<E>(zi, task, lane, c);
-            load_col<E>(zi, cs_col, lane, cs);
-            load_col<E>(zi, cn_col, lane, cn);
+            load_col<E, MP>(zi, task, lane, c);
+            load_col<E, MP>(zi, cs_col, lane, cs);
+            load_col<E, MP>(zi, cn_col, lane, cn);
             load_col<E>(kvi, j, lane, kv);
 #pragma unroll
             for (int e = 0; e < E; ++e) { c[e] = yy[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
@@ -1895,10 +1897,10 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
             }
         }
         if (NW == 2 || !stage) {
-            if (!stage) load_col<E>(A.st.y, task, lane, yy);
-            load_col<E>(A.st.w, task, lane, w0);
-            load_col<E>(A.st.w + A.st.nv, task, lane, w1);
-            load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+            if (!stage) load_col<E, MP>(A.st.y, task, lane, yy);
+            load_col<E, MP>(A.st.w, task, lane, w0);
+            load_col<E, MP>(A.st.w + A.st.nv, task, lane, w1);
+            load_col<E, MP>(A.st.w + 2 * A.st.nv, task, lane, w2);
         }
     }
     if (w == 0) {
@@ -1926,7 +1928,7 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                 s = s + S.F[2][e * 64 + lane] * cTI[0][2];
                 fr[e] = s - A.st.mreal * wr0[e];
             }
-            if (!A.do_update && !A.delta) store_col<E>(A.st.br, task, lane, fr);
+            if (!A.do_update && !A.delta) store_col<E, MP>(A.st.br, task, lane, fr);
         } else {
             double jl[E], ju[E];
             load_col<E>(A.sw.JL, j, lane, jl);
@@ -1943,15 +1945,15 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
 #pragma unroll
                 for (int e = 0; e < E; ++e) fr[e] = 0.0;
             } else {
-                load_col<E>(A.sw.br, task, lane, fr);
+                load_col<E, MP>(A.sw.br, task, lane, fr);
             }
         }
         if (!A.sw.first) {
             double js[E], jn[E], xs[E], xn[E];
             load_col<E>(A.sw.JS, j, lane, js);
             load_col<E>(A.sw.JN, j, lane, jn);
-            load_col<E>(A.sw.xr_old, cs_col, lane, xs);
-            load_col<E>(A.sw.xr_old, cn_col, lane, xn);
+            load_col<E, MP>(A.sw.xr_old, cs_col, lane, xs);
+            load_col<E, MP>(A.sw.xr_old, cn_col, lane, xn);
 #pragma unroll
             for (int e = 0; e < E; ++e) fr[e] = __builtin_fma(jn[e], xn[e], __builtin_fma(js[e], xs[e], fr[e]));
             if constexpr (KIND == 1) {
@@ -1979,11 +1981,11 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
         tridiag_apply<E, double>(a, cc, rinv, rtab, fr, lane);
         if (!A.do_stage && A.delta) {
             double x1[E];
-            load_col<E>(A.sw.xr_old, task, lane, x1);
+            load_col<E, MP>(A.sw.xr_old, task, lane, x1);
 #pragma unroll
             for (int e = 0; e < E; ++e) fr[e] = x1[e] + fr[e];
         }
-        if (!A.do_update) store_col<E>(A.sw.xr_new, task, lane, fr);
+        if (!A.do_update) store_col<E, MP>(A.sw.xr_new, task, lane, fr);
         else lds_put<E>(S.D[0], lane, fr);
     }
     if (!A.do_update) return;
@@ -2021,7 +2023,8 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                 z2[e] = (cT[2][0] * w0[e] + cT[2][1] * w1[e]) + cT[2][2] * w2[e];
                 yn[e] = yy[e] + z2[e];
             }
-            store_col<E>(fin->ynew, task, lane, yn);
+            if (w == 0) store_col<E, MP>(fin->ynew, task, lane, yn);     // (a four-wave team: every stage wave holds all of this;
+                                                                         //  wave r stores row r)
             const double xs[3] = {fin->x0, fin->x1, fin->x2};
             double o[3][E];
 #pragma unroll
@@ -2038,13 +2041,15 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) store_col<E>(fin->znext + i * A.st.nv, task, lane, o[i]);
+            for (int i = 0; i < 3; ++i)
+                if (i % NS == w) store_col<E, MP>(fin->znext + i * A.st.nv, task, lane, o[i]);
             double wv[E];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
+                if (r % NS != w) continue;
 #pragma unroll
                 for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
-                store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wv);
+                store_col<E, MP>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wv);
             }
         } else {
             for (int r = w; r < 3; r += NS) {
@@ -2054,8 +2059,8 @@ __device__ __forceinline__ void newton_team_body(const DevP& P, const FusedArgs&
                     wr[e] = (r == 0) ? w0[e] : ((r == 1) ? w1[e] : w2[e]);
                     zz[e] = (cT[r][0] * w0[e] + cT[r][1] * w1[e]) + cT[r][2] * w2[e];
                 }
-                store_col<E>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wr);
-                store_col<E>(A.st.zout + (size_t)r * A.st.nv, task, lane, zz);
+                store_col<E, MP>(const_cast<double*>(A.st.w) + (size_t)r * A.st.nv, task, lane, wr);
+                store_col<E, MP>(A.st.zout + (size_t)r * A.st.nv, task, lane, zz);
             }
         }
     }
@@ -3914,10 +3919,15 @@ struct FrozenArgs {
 // -- a barrier costs 1.0-1.5 us instead of 2.1 us and a neighbour's column comes from L2 instead of the fabric
 // (tools/proto_xcd_barrier.hip, profiles/r03_xcd_barrier.log).  HIP promises no placement: if XCD 0 does not get its nwg
 // workgroups the barrier times out, the abort flag is raised and the caller runs the cooperative flavour (XCD = 0).
-template <int E, int KIND, int XCD>
+// TEAM = 1: a workgroup is ONE column, its four waves the team of newton_team_body (a stage tendency each on three of them,
+// the complex system on the fourth, exchanges through LDS): the phase of a small grid is the dependent arithmetic of one
+// column's Newton iteration, and the team cuts that chain (three tendencies one after the other, then the real and the
+// complex solve one after the other -> one tendency, then both solves side by side).  Same arithmetic, same bits.
+template <int E, int KIND, int XCD, int TEAM = 0>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, FrozenArgs A) {
     __shared__ int lds_ok;
     __shared__ int lds_id;
+    __shared__ double team_lds[TEAM ? sizeof(TeamLds<E, 3>) / sizeof(double) : 1];
     constexpr int MPX = XCD ? 2 : 1;
     const int lane = threadIdx.x & 63;
     int wg = (int)blockIdx.x;
@@ -3936,7 +3946,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         wg = lds_id;
         if (wg < 0) return;
     }
-    const int wave = uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+    const int tw = uni_i((int)(threadIdx.x >> 6));                      // TEAM: the wave's place in its team
+    const int wave = TEAM ? uni_i(wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // the column
     const bool col_wave = wave < P.ncol;
     GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
     const size_t nv = A.C.nv;
@@ -3948,14 +3959,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
 #define FZ_SYNC() \
     if (!bar.sync()) { status = 1; goto finish; }
     // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
-    if (col_wave) {
+    if (col_wave && (!TEAM || tw == 0)) {
         double zero[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) zero[e] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             store_col<E, MPX>(FZ_Z + i * nv, wave, lane, zero);
-            store_col<E>(A.W + i * nv, wave, lane, zero);
+            store_col<E, (TEAM ? MPX : 0)>(A.W + i * nv, wave, lane, zero);
         }
     }
     FZ_SYNC()
@@ -3997,7 +4008,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                     Fin.znext = do_stage ? FZ_ZN : FZ_Z;
                     Fin.x0 = R.x0; Fin.x1 = R.x1; Fin.x2 = R.x2;
                     Fin.nblk_cols = 0;
-                    if (col_wave) {
+                    if constexpr (TEAM) {
+                        if (col_wave)
+                            newton_team_body<E, KIND, 0, 1, 4, 1, MPX>(P, FA, *reinterpret_cast<TeamLds<E, 3>*>(team_lds), wave, tw, lane, &Fin);
+                    } else if (col_wave) {
                         bool taken = false;
                         if constexpr (KIND == 0 && E <= 2) {
                             if (m == 1) { newton_single_body<E, MPX, 1>(P, FA, wave, lane, &Fin); taken = true; }
@@ -4007,7 +4021,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                     swapY ^= 1;
                     if (do_stage) swapZ ^= 1;
                 } else {
-                    if (col_wave) {
+                    if constexpr (TEAM) {
+                        if (col_wave)
+                            newton_team_body<E, KIND, 0, 1, 4, 0, MPX>(P, FA, *reinterpret_cast<TeamLds<E, 3>*>(team_lds), wave, tw, lane, nullptr);
+                    } else if (col_wave) {
                         bool taken = false;
                         if constexpr (KIND == 0 && E <= 2) {
                             if (m == 1) { newton_single_body<E, MPX, 0>(P, FA, wave, lane); taken = true; }
@@ -4023,7 +4040,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         done = i + 1;
     }
 finish:
-    if (wave == 0 && lane == 0) {
+    if (wave == 0 && lane == 0 && (!TEAM || tw == 0)) {
         A.out[0] = (double)status; A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ;
         A.out[4] = (double)bar.epoch;
     }
@@ -4068,6 +4085,37 @@ void nk2d_frozen_cache_free(nk2d_ctx* c) {
 // 0: the year ran in one launch (buffers in their roles after the last-but-one row's end; the last row's Newton iterations
 //    done, its commit left to the caller);  1: not for this context / schedule (the launch-per-phase path runs);
 // 2: a grid barrier timed out (the same);  < 0: error
+// the instantiation for (levels per lane, module kind, flavour); the team flavour exists for one and two levels per lane
+template <int E, int KIND, int XCD, int TEAM>
+static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
+    if (coop) {
+        void* args[2] = {&P, &A};
+        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
+    }
+    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A);
+    return hipGetLastError();
+}
+template <int KIND, int XCD, int TEAM>
+static hipError_t launch_frozen_e(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
+    switch (c->E) {
+        case 1: return launch_frozen_one<1, KIND, XCD, TEAM>(c, coop, grid, P, A);
+        case 2: return launch_frozen_one<2, KIND, XCD, TEAM>(c, coop, grid, P, A);
+        case 3: if constexpr (!TEAM) return launch_frozen_one<3, KIND, XCD, 0>(c, coop, grid, P, A); else break;
+        case 4: if constexpr (!TEAM) return launch_frozen_one<4, KIND, XCD, 0>(c, coop, grid, P, A); else break;
+        default: break;
+    }
+    return hipErrorInvalidValue;
+}
+static hipError_t launch_frozen(nk2d_ctx* c, bool xcd, bool team, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
+    const bool forced = c->kind == 2;
+    if (xcd) {
+        if (team) return forced ? launch_frozen_e<2, 1, 1>(c, coop, grid, P, A) : launch_frozen_e<0, 1, 1>(c, coop, grid, P, A);
+        return forced ? launch_frozen_e<2, 1, 0>(c, coop, grid, P, A) : launch_frozen_e<0, 1, 0>(c, coop, grid, P, A);
+    }
+    if (team) return forced ? launch_frozen_e<2, 0, 1>(c, coop, grid, P, A) : launch_frozen_e<0, 0, 1>(c, coop, grid, P, A);
+    return forced ? launch_frozen_e<2, 0, 0>(c, coop, grid, P, A) : launch_frozen_e<0, 0, 0>(c, coop, grid, P, A);
+}
+
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
     if (!c->frozen_persistent || needs_state || c->hist_n != 0 || c->norm_hook || n < 1) return 1;
@@ -4187,24 +4235,25 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     A.out = c->YR_OUT;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
-    void* args[2] = {&P, &A};
-    const int nblk = nk2d_grid(c->ncol);
+    // option "frozen_team" (1: where it pays; 2: wherever it exists): a workgroup per column (four waves: newton_team_body)
+    // instead of a wave per column.  Measured (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want
+    // a CU each -- crowded onto one XCD they lose what they gain -- so they run in the cooperative flavour, and against the
+    // wave-per-column year on one XCD that pays from about 40 levels on (26^2 11.4 against 11.8 ms: left alone; 40^2 15.5 /
+    // 16.1, 52^2 18.5 / 20.1, 104^2 36.5 / 40.9).
+    const bool team = c->E <= 2 && (c->frozen_team >= 2 || (c->frozen_team == 1 && c->nz > 32));
+    const int nblk = team ? c->ncol : nk2d_grid(c->ncol);
     A.tickets = (unsigned*)((char*)c->YR_SYNC + 6144);
     A.nwg = nblk;
     const double* o = c->hYR_OUT;
     bool ran = false;
     // ---- all of the year's workgroups on ONE XCD (option "frozen_xcd"; at most what an XCD's 32 CUs hold at once)
     // (one workgroup per CU is what the kernel's registers admit at two levels per lane: an XCD holds 32 of them at once)
-    if (c->frozen_xcd && !c->frozen_xcd_failed && nblk <= 28) {
+    if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28) {
         // a workgroup that does not get its partners gives up after 20 ms (the year itself takes less than that per phase)
         A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
         const dim3 grid(8 * nblk + 64);
-        if (c->kind == 2) {
-            NK2D_DISPATCH_E4(c->E, hipLaunchKernelGGL((k_frozen_persistent<EE, 2, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A));
-        } else {
-            NK2D_DISPATCH_E4(c->E, hipLaunchKernelGGL((k_frozen_persistent<EE, 0, 1>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A));
-        }
+        NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
         NK2D_CHECK(c, hipGetLastError());
         NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
@@ -4222,11 +4271,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         hipError_t rc = hipErrorInvalidValue;
         {
             std::lock_guard<std::mutex> coop(coop_launch_mutex());
-            if (c->kind == 2) {
-                NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 2, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
-            } else {
-                NK2D_DISPATCH_E4(c->E, rc = hipLaunchCooperativeKernel((const void*)k_frozen_persistent<EE, 0, 0>, dim3(nblk), dim3(NK2D_BLOCK), args, 0, c->stream));
-            }
+            rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
         }
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);
@@ -4234,6 +4279,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
         if ((int)o[0] != 0 || (int64_t)o[1] != n) return 2;
     }
+    if (team) c->frozen_team_years++;
     if ((int)o[2]) std::swap(c->Y, c->YOLD);
     if ((int)o[3]) std::swap(c->Z, c->ZN);
     // counters of the year, as the launch-per-phase path books them, and the algorithmic bytes of its phases (the formula of

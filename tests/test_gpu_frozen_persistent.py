@@ -48,6 +48,10 @@ def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
     fxp_p, st_pp = eng.comp_fcn_frozen(xp, sched)
     assert np.array_equal(eng.download(fxp_p), eng.download(fxp_l))          # and the launch-per-phase year of another state
     assert eng.counter("frozen_persistent_years") == 2 and eng.counter("frozen_cache_builds") == 1   # one cache per schedule
+    # which flavour ran: up to 32 levels a wave per column with all workgroups on one XCD, beyond a four-wave team per column
+    # (cooperative launch), option "frozen_team"
+    assert eng.counter("frozen_team_years") == (0 if n <= 32 else 2)
+    assert eng.counter("frozen_xcd_years") == (2 if n <= 32 else 0)
     for key in ("nsteps", "nnewton"):
         assert st_p[key] == st_l[key], key
     # (the launch-per-phase year also evaluates the error estimate of every 128th step -- a tendency and a solve each;
@@ -113,6 +117,44 @@ def test_forced_modules_and_column_grids():
         fx_lp, _ = eng.comp_fcn_frozen(xp, sched)
         assert np.array_equal(eng.download(fx_pp), eng.download(fx_lp))
         eng.close()
+
+
+@pytest.mark.parametrize("case", ["iage_26", "iage_52_two_sweeps", "forced_decay_22x9"])
+def test_team_and_wave_per_column_flavours_agree(case):
+    """the four-wave team inside the one-launch year (option "frozen_team" 2: wherever it exists) against the wave per column
+    (0), each against the launch-per-phase year: the recorded and a perturbed state, bit for bit -- also with two-sweep solves
+    (inner tolerance 1e-3), whose second launch of an iteration has no stage part"""
+    from nk_ooc_amd.engine import forced_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    rng = np.random.default_rng(11)
+    if case == "forced_decay_22x9":
+        eng = forced_engine(Grid2d.default(22, 9), {"forced_surf_restore_opt": "none", "forced_sms_opt": "decay",
+                                                     "forced_sms_decay_rate": "1.0e-8"})
+        x0 = 1.0 + 0.2 * rng.standard_normal((1, 22, 9))
+    else:
+        n = 26 if case == "iage_26" else 52
+        eng = _iage(n)
+        if case == "iage_52_two_sweeps":
+            eng.set_option("lin_tol", 1.0e-3)
+        x0, _, _ = _state(eng)
+    eng.set_option("device_ctl", 0)
+    x = eng.upload(x0)
+    xp = eng.upload(x0 * (1.0 + 1.0e-4 * rng.standard_normal(x0.shape)))
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    if case == "iage_52_two_sweeps":
+        assert st["nsweeps"] > 1.5 * st["nnewton"]
+    eng.set_option("frozen_persistent", 0)
+    want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    assert np.array_equal(want[0], eng.download(fx))
+    eng.set_option("frozen_persistent", 1)
+    for team, years in ((2, 2), (0, 2), (2, 4)):
+        eng.set_option("frozen_team", team)
+        got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team)
+        assert eng.counter("frozen_team_years") == years
+    assert eng.counter("frozen_persistent_years") == 6 and eng.frozen_fallbacks() == 0
+    eng.close()
 
 
 def test_what_it_is_not_for_takes_the_other_path():
