@@ -147,7 +147,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
     if (key == "frozen_persistent") { c->frozen_persistent = value != 0.0; return 0; }
     if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
-    if (key == "frozen_team") { c->frozen_team = (int)value; return 0; }
+    if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
     if (key == "frozen_cache_gb") { c->frozen_cache_max_gb = value; return 0; }
     if (key == "barrier_timeout_ms") {

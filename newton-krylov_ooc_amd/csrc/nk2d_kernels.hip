@@ -4235,12 +4235,12 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     A.out = c->YR_OUT;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
-    // option "frozen_team" (1: where it pays; 2: wherever it exists): a workgroup per column (four waves: newton_team_body)
-    // instead of a wave per column.  Measured (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want
-    // a CU each -- crowded onto one XCD they lose what they gain -- so they run in the cooperative flavour, and against the
-    // wave-per-column year on one XCD that pays from about 40 levels on (26^2 11.4 against 11.8 ms: left alone; 40^2 15.5 /
-    // 16.1, 52^2 18.5 / 20.1, 104^2 36.5 / 40.9).
-    const bool team = c->E <= 2 && (c->frozen_team >= 2 || (c->frozen_team == 1 && c->nz > 32));
+    // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column.  Measured
+    // (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want a CU each -- on one XCD, two to four
+    // workgroups to a CU, they lose more than they gain (26^2: 13.3 ms, 16.1 ms when LDS padding forces exactly two per CU) --
+    // so they run in the cooperative flavour, where they beat the wave-per-column year on one XCD at every size: 26^2 11.4
+    // against 11.8 - 12.6 ms, 30^2 12.6 / 14.2, 40^2 15.5 / 16.1, 52^2 18.5 / 20.1, 104^2 36.5 / 40.9.
+    const bool team = c->frozen_team && c->E <= 2;
     const int nblk = team ? c->ncol : nk2d_grid(c->ncol);
     A.tickets = (unsigned*)((char*)c->YR_SYNC + 6144);
     A.nwg = nblk;

@@ -48,10 +48,8 @@ def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
     fxp_p, st_pp = eng.comp_fcn_frozen(xp, sched)
     assert np.array_equal(eng.download(fxp_p), eng.download(fxp_l))          # and the launch-per-phase year of another state
     assert eng.counter("frozen_persistent_years") == 2 and eng.counter("frozen_cache_builds") == 1   # one cache per schedule
-    # which flavour ran: up to 32 levels a wave per column with all workgroups on one XCD, beyond a four-wave team per column
-    # (cooperative launch), option "frozen_team"
-    assert eng.counter("frozen_team_years") == (0 if n <= 32 else 2)
-    assert eng.counter("frozen_xcd_years") == (2 if n <= 32 else 0)
+    # which flavour ran: a four-wave team per column, cooperative launch (option "frozen_team", the default)
+    assert eng.counter("frozen_team_years") == 2 and eng.counter("frozen_xcd_years") == 0
     for key in ("nsteps", "nnewton"):
         assert st_p[key] == st_l[key], key
     # (the launch-per-phase year also evaluates the error estimate of every 128th step -- a tendency and a solve each;
@@ -121,8 +119,8 @@ def test_forced_modules_and_column_grids():
 
 @pytest.mark.parametrize("case", ["iage_26", "iage_52_two_sweeps", "forced_decay_22x9"])
 def test_team_and_wave_per_column_flavours_agree(case):
-    """the four-wave team inside the one-launch year (option "frozen_team" 2: wherever it exists) against the wave per column
-    (0), each against the launch-per-phase year: the recorded and a perturbed state, bit for bit -- also with two-sweep solves
+    """the four-wave team inside the one-launch year (option "frozen_team" 1, the default) against the wave per column
+    (0: on one XCD where the workgroups fit), each against the launch-per-phase year: the recorded and a perturbed state, bit for bit -- also with two-sweep solves
     (inner tolerance 1e-3), whose second launch of an iteration has no stage part"""
     from nk_ooc_amd.engine import forced_engine
     from nk_ooc_amd.grid import Grid2d
@@ -148,11 +146,12 @@ def test_team_and_wave_per_column_flavours_agree(case):
     want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
     assert np.array_equal(want[0], eng.download(fx))
     eng.set_option("frozen_persistent", 1)
-    for team, years in ((2, 2), (0, 2), (2, 4)):
+    for team, years in ((1, 2), (0, 2), (1, 4)):
         eng.set_option("frozen_team", team)
         got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team)
         assert eng.counter("frozen_team_years") == years
+    assert eng.counter("frozen_xcd_years") == 2         # the two years of the wave-per-column flavour
     assert eng.counter("frozen_persistent_years") == 6 and eng.frozen_fallbacks() == 0
     eng.close()
 

@@ -23,7 +23,7 @@ for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104", "208"])]:
     rng = np.random.default_rng(0)
     xp = eng.upload(eng.download(x) * (1.0 + 1.0e-4 * rng.standard_normal(eng.shape)))
     ref = None
-    for flag, team, xcd in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0)):
+    for flag, team, xcd in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0), (1, 0, 1), (1, 1, 1)):
         eng.set_option("frozen_persistent", flag)
         eng.set_option("frozen_team", team)
         eng.set_option("frozen_xcd", xcd)
