@@ -373,7 +373,8 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
    grids, see nk2d_get_counter), "frozen_team" (1, default: a four-wave team per column inside that launch, cooperative
-   flavour; 0: a wave per column, on one XCD where the workgroups fit),
+   flavour; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: team columns hand over to
+   their two lateral neighbours instead of meeting at a grid barrier),
    "hook_spec_depth" (1 or 2, default 2: whole Newton iterations a controller with a vector norm hook queues ahead of a verdict), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
    then the year is rerun launch by launch), "year_fences" (1: release / acquire fences around those barriers, validation),
    "pc_fp32" (1: the preconditioner's Schur inverses stored in single precision -- half the HBM -- and every apply refined

@@ -144,6 +144,7 @@ struct nk2d_ctx {
     int64_t frozen_cache_builds, frozen_persistent_years, frozen_xcd_years;
     int frozen_xcd, frozen_xcd_failed;   // option "frozen_xcd": the year's workgroups on one XCD; set once the placement failed
     int frozen_team;      // option "frozen_team": a four-wave team per column inside the one-launch frozen year (grids of at most two levels per lane)
+    int frozen_nbsync;    // option "frozen_nbsync": team columns hand over to their lateral neighbours instead of meeting at a grid barrier
     int64_t frozen_team_years;
     double barrier_timeout_ms;  // longest wait at a grid barrier of the persistent year (option "barrier_timeout_ms")
     int year_fences;            // 1: release / acquire fences around its grid barriers (option "year_fences", validation)

@@ -3077,6 +3077,60 @@ struct GridBarrier {
     }
 };
 
+// Synchronisation block of the one-launch years: arrival counters (32 shards on lines of their own), abort flag at 4096,
+// tickets of the XCD flavour at 6144, and from 8192 one 128-byte line per column for NeighbourSync.
+static size_t yr_sync_bytes(const nk2d_ctx* c) { return 8192 + (size_t)c->ncol * 128; }
+
+// Where a workgroup is ONE column (the team flavour of k_frozen_persistent) the grid barrier asks for more than the data
+// flow needs: a column reads what its two lateral neighbours (same tracer) wrote in the phase before, and nothing else of
+// another workgroup.  So a column publishes the number of phases it has completed -- after every wave of the team has
+// drained its write-through stores -- and waits until both neighbours have completed as many: it then runs at most one
+// phase ahead of them, which is also what the buffers that alternate between phases (Z / ZN, the sweep iterates) and the
+// ones rewritten in place two phases later need.  Point to point instead of all to all: no counter everybody adds to, no
+// waiting for the slowest of all workgroups in every phase.  Same accessors, same bounded wait, same abort flag.
+struct NeighbourSync {
+    unsigned* flags;     // [ncol][32]: phases completed, one 128-byte line per column
+    int* abort_flag;
+    int me, left, right; // columns (left / right: -1 at the edge of the tracer's plane)
+    unsigned phase;
+    int* lds_ok;
+    long long spin_ticks;
+    int fences;
+    __device__ __forceinline__ bool sync() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        ++phase;
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            if (lane == 0) __hip_atomic_store(flags + (size_t)me * 32, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int other = (lane == 0) ? left : ((lane == 1) ? right : -1);
+            int good = 1;
+            long long spins = 0;
+            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                unsigned v = phase;
+                if (other >= 0) v = __hip_atomic_load(flags + (size_t)other * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)(v >= phase))) break;
+                const int ab = __builtin_amdgcn_readfirstlane(
+                    (lane == 0) ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+                const bool late = ((++spins & 63) == 0 || spin_ticks == 0) &&
+                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > spin_ticks;
+                if (late || spins > 4000LL * NK2D_SPIN_LIMIT || ab != 0) {
+                    if (lane == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) *lds_ok = good;
+        }
+        __syncthreads();
+        if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return *lds_ok != 0;
+    }
+};
+
 // sum of the ncol per-column partials in the association of nk2d_part_sum / k_reduce (256 strided
 // accumulators, then a binary tree), identical in every wave
 __device__ __forceinline__ double year_part_sum(const double* part, int n, int lane) {
@@ -3578,7 +3632,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     if (!c->YR_OUT) {
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_PART, sizeof(double) * 2 * c->ncol));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_OUT, sizeof(double) * 32));
-        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 8192));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, yr_sync_bytes(c)));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_MTAB, sizeof(int) * std::max<size_t>(c->rho_tab.size(), 1)));
         NK2D_CHECK(c, hipHostMalloc((void**)&c->hYR_OUT, sizeof(double) * 32));
         NK2D_CHECK(c, hipEventCreate(&c->yr_ev[0]));
@@ -3602,7 +3656,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * record_cap));
         c->yr_rec_cap = record_cap;
     }
-    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 8192, c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), c->stream));
     YearArgs A = {};
     A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.ZN = c->ZN; A.W = c->W;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
@@ -3923,7 +3977,7 @@ struct FrozenArgs {
 // the complex system on the fourth, exchanges through LDS): the phase of a small grid is the dependent arithmetic of one
 // column's Newton iteration, and the team cuts that chain (three tendencies one after the other, then the real and the
 // complex solve one after the other -> one tendency, then both solves side by side).  Same arithmetic, same bits.
-template <int E, int KIND, int XCD, int TEAM = 0>
+template <int E, int KIND, int XCD, int TEAM = 0, int NB = 0>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, FrozenArgs A) {
     __shared__ int lds_ok;
     __shared__ int lds_id;
@@ -3950,6 +4004,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
     const int wave = TEAM ? uni_i(wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // the column
     const bool col_wave = wave < P.ncol;
     GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
+    // NB (teams only: a workgroup is a column): neighbour-to-neighbour hand-over instead of the grid barrier
+    const int nb_j = wave % P.ny;
+    NeighbourSync nbs{(unsigned*)((char*)A.arrive + 8192), A.abort_flag, wave, (nb_j > 0) ? wave - 1 : -1,
+                      (nb_j < P.ny - 1) ? wave + 1 : -1, 0u, &lds_ok, A.spin_ticks, A.fences};
     const size_t nv = A.C.nv;
     int swapY = 0, swapZ = 0, status = 0, done = 0;
 #define FZ_Y (swapY ? A.YOLD : A.Y)
@@ -3957,7 +4015,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
 #define FZ_Z (swapZ ? A.ZN : A.Z)
 #define FZ_ZN (swapZ ? A.Z : A.ZN)
 #define FZ_SYNC() \
-    if (!bar.sync()) { status = 1; goto finish; }
+    if (!((NB && TEAM) ? nbs.sync() : bar.sync())) { status = 1; goto finish; }
     // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
     if (col_wave && (!TEAM || tw == 0)) {
         double zero[E];
@@ -4040,7 +4098,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         done = i + 1;
     }
 finish:
-    if (wave == 0 && lane == 0 && (!TEAM || tw == 0)) {
+    if constexpr (NB && TEAM) {
+        // no barrier behind the last phase: every column reports a failure of its own (the host cleared `out`), column 0
+        // the rest -- a column that gave up raised the abort flag, its neighbours time out on it in turn
+        if (status != 0 && lane == 0 && tw == 0) A.out[0] = (double)status;
+        if (wave == 0 && lane == 0 && tw == 0) {
+            A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ; A.out[4] = (double)nbs.phase;
+        }
+    } else if (wave == 0 && lane == 0 && (!TEAM || tw == 0)) {
         A.out[0] = (double)status; A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ;
         A.out[4] = (double)bar.epoch;
     }
@@ -4090,9 +4155,13 @@ template <int E, int KIND, int XCD, int TEAM>
 static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
     if (coop) {
         void* args[2] = {&P, &A};
-        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
+        if constexpr (TEAM && !XCD) {
+            if (c->frozen_nbsync)
+                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
+        }
+        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
     }
-    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A);
+    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A);
     return hipGetLastError();
 }
 template <int KIND, int XCD, int TEAM>
@@ -4212,7 +4281,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     if (!c->YR_OUT) {
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_PART, sizeof(double) * 2 * c->ncol));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_OUT, sizeof(double) * 32));
-        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, 8192));
+        NK2D_CHECK(c, hipMalloc((void**)&c->YR_SYNC, yr_sync_bytes(c)));
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_MTAB, sizeof(int) * std::max<size_t>(c->rho_tab.size(), 1)));
         NK2D_CHECK(c, hipHostMalloc((void**)&c->hYR_OUT, sizeof(double) * 32));
         NK2D_CHECK(c, hipEventCreate(&c->yr_ev[0]));
@@ -4221,7 +4290,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         c->yr_rec_cap = 0;
         c->YR_REC = nullptr;
     }
-    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, 8192, c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), c->stream));
     FrozenArgs A = {};
     A.Y = c->Y; A.YOLD = c->YOLD; A.Z = c->Z; A.ZN = c->ZN; A.W = c->W;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
@@ -4269,6 +4338,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     if (!ran) {
         A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
         hipError_t rc = hipErrorInvalidValue;
+        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
         {
             std::lock_guard<std::mutex> coop(coop_launch_mutex());
             rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);

@@ -119,7 +119,8 @@ def test_forced_modules_and_column_grids():
 
 @pytest.mark.parametrize("case", ["iage_26", "iage_52_two_sweeps", "forced_decay_22x9"])
 def test_team_and_wave_per_column_flavours_agree(case):
-    """the four-wave team inside the one-launch year (option "frozen_team" 1, the default) against the wave per column
+    """(also: columns that hand over to their lateral neighbours instead of meeting at a grid barrier, with and without the
+    validation fences)  the four-wave team inside the one-launch year (option "frozen_team" 1, the default) against the wave per column
     (0: on one XCD where the workgroups fit), each against the launch-per-phase year: the recorded and a perturbed state, bit for bit -- also with two-sweep solves
     (inner tolerance 1e-3), whose second launch of an iteration has no stage part"""
     from nk_ooc_amd.engine import forced_engine
@@ -146,13 +147,16 @@ def test_team_and_wave_per_column_flavours_agree(case):
     want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
     assert np.array_equal(want[0], eng.download(fx))
     eng.set_option("frozen_persistent", 1)
-    for team, years in ((1, 2), (0, 2), (1, 4)):
+    # (team, neighbour hand-over instead of the grid barrier -- option "frozen_nbsync", default with teams --, fences)
+    for team, nbsync, fences, years in ((1, 1, 0, 2), (0, 0, 0, 2), (1, 0, 0, 4), (1, 1, 1, 6)):
         eng.set_option("frozen_team", team)
+        eng.set_option("frozen_nbsync", nbsync)
+        eng.set_option("year_fences", fences)
         got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team, nbsync, fences)
         assert eng.counter("frozen_team_years") == years
     assert eng.counter("frozen_xcd_years") == 2         # the two years of the wave-per-column flavour
-    assert eng.counter("frozen_persistent_years") == 6 and eng.frozen_fallbacks() == 0
+    assert eng.counter("frozen_persistent_years") == 8 and eng.frozen_fallbacks() == 0
     eng.close()
 
 

@@ -23,10 +23,11 @@ for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104", "208"])]:
     rng = np.random.default_rng(0)
     xp = eng.upload(eng.download(x) * (1.0 + 1.0e-4 * rng.standard_normal(eng.shape)))
     ref = None
-    for flag, team, xcd in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0), (1, 0, 1), (1, 1, 1)):
+    for flag, team, xcd, nbs in ((0, 0, 1, 0), (1, 0, 1, 0), (1, 1, 1, 0), (1, 1, 1, 1), (1, 0, 0, 0), (1, 0, 1, 0), (1, 1, 1, 0), (1, 1, 1, 1)):
         eng.set_option("frozen_persistent", flag)
         eng.set_option("frozen_team", team)
         eng.set_option("frozen_xcd", xcd)
+        eng.set_option("frozen_nbsync", nbs)
         builds = eng.counter("frozen_cache_builds")
         t0 = time.perf_counter()
         fx2, st2 = eng.comp_fcn_frozen(x, sched)
@@ -35,7 +36,7 @@ for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104", "208"])]:
         fx3, st3 = eng.comp_fcn_frozen(xp, sched)
         got = eng.download(fx3)
         ref = got if ref is None else ref
-        print(f"n={n} frozen_persistent={flag} team={team} xcd={xcd} (team years {eng.counter('frozen_team_years')}, XCD years {eng.counter('frozen_xcd_years')}): year {st2['seconds']*1e3:.2f} ms / {st3['seconds']*1e3:.2f} ms "
+        print(f"n={n} frozen_persistent={flag} team={team} xcd={xcd} nbsync={nbs} (team years {eng.counter('frozen_team_years')}, XCD years {eng.counter('frozen_xcd_years')}): year {st2['seconds']*1e3:.2f} ms / {st3['seconds']*1e3:.2f} ms "
               f"(first call {t_first*1e3:.2f} ms, cache builds {eng.counter('frozen_cache_builds') - builds}), "
               f"{st3['nlaunch']} launches, {st3['nnewton']} Newton iterations in {len(sched)} steps; "
               f"one-launch years so far {eng.counter('frozen_persistent_years')}; free-running year {st['seconds']*1e3:.1f} ms; "
