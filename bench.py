@@ -415,23 +415,49 @@ def roofline_of(eng, n):
     # the years of the timed region are frozen years (host-launched replays of the base year's steps) unless
     # NK2D_JVP_FROZEN=0 leaves them to the engine's own mode, which may be the persistent kernel
     persistent = getattr(eng, "device_ctl", 0) == 3 and os.environ.get("NK2D_JVP_FROZEN", "1") == "0"
-    if not persistent and eng.counter("frozen_persistent_years") > 0:
+    if not persistent and eng.counter("frozen_persistent_years") - getattr(eng, "_launch_years_base", 0) > 0:
         # small grids: every frozen year of the timed region was ONE launch on the schedule cache (k_frozen_persistent): its
         # phases' algorithmic bytes over the wall time of the year around that launch
         from nk_ooc_amd.model_state import ModelState
 
         totals = eng.profile_totals()
-        year_s = ModelState.last_stats[0]["seconds"]
         years = max(totals["launches"], 1)
         nbytes = totals["bytes"] / years
-        achieved = nbytes / year_s / 1e9
-        return {"bound": "hbm", "kernel": f"k_frozen_persistent<{(eng.nz + 63) // 64}, 0, xcd> (a whole frozen year in one launch: "
-                                          "one simplified-Newton iteration per phase, grid barriers between them)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_us": 1.0e6 * year_s, "timing": "host wall clock of the nk2d_comp_fcn_frozen call around the one launch",
-                "launches": totals["launches"], "algorithmic_bytes_per_launch": nbytes,
-                "phases_per_launch": ModelState.last_stats[0]["nsweeps"],
-                "one_launch_years": eng.counter("frozen_persistent_years"), "xcd_local_years": eng.counter("frozen_xcd_years")}
+        # the launches themselves: a HIP event pair on the context's stream around every one of them (counter
+        # "frozen_launch_us", since profile_reset: bench.py zeroes its reading there)
+        launch_us = (eng.counter("frozen_launch_us") - getattr(eng, "_launch_us_base", 0)) / max(
+            eng.counter("frozen_persistent_years") - getattr(eng, "_launch_years_base", 0), 1)
+        achieved = nbytes / (launch_us * 1e-6) / 1e9
+        levels = (eng.nz + 63) // 64
+        flavour = ("a four-wave team per column" if eng.counter("frozen_team_years") else "a wave per column") + (
+            ", all workgroups on one XCD" if eng.counter("frozen_xcd_years") else
+            ", cooperative launch, workgroups hand over to their lateral neighbours")
+        out = {"bound": "hbm", "kernel": f"k_frozen_persistent<{levels}, 0, ...> (a whole frozen year in ONE launch on the schedule "
+                                         f"cache: one simplified-Newton iteration per phase; {flavour})",
+               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+               "avg_launch_us": launch_us,
+               "timing": "HIP event pair on the context's stream around every one-launch year of the timed region "
+                         "(ALGORITHMIC bytes of the year's phases -- the launches they replace -- over that time)",
+               "launches": totals["launches"], "algorithmic_bytes_per_launch": nbytes,
+               "phases_per_launch": ModelState.last_stats[0]["nsweeps"],
+               "year_seconds_host_clock": ModelState.last_stats[0]["seconds"],
+               "one_launch_years": eng.counter("frozen_persistent_years"), "team_years": eng.counter("frozen_team_years"),
+               "xcd_local_years": eng.counter("frozen_xcd_years"), "schedule_cache_builds": eng.counter("frozen_cache_builds")}
+        pmc_fname = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_one_launch_{n}.json")
+        if os.path.exists(pmc_fname):
+            pmc = json.load(open(pmc_fname))
+            out["traffic"] = pmc["traffic_bytes_per_launch_upper"]
+            out["traffic_source"] = ("static profile file " + os.path.relpath(pmc_fname, ROOT) +
+                                     " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not collected in this run)")
+        stats_fname = os.path.join(ROOT, "profiles", f"r03_rocprof_one_launch_{n}", "kernel_stats.csv")
+        if os.path.exists(stats_fname):
+            for line in open(stats_fname):
+                if line.startswith('"void k_frozen_persistent<' + str(levels)):
+                    avg_ns = float(line.rsplit('",', 1)[1].split(",")[2])
+                    out["rocprofv3"] = {"avg_launch_us": avg_ns / 1000.0, "frac": nbytes / (avg_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                        "source": "static profile file " + os.path.relpath(stats_fname, ROOT)}
+                    break
+        return out
     windows = {
         "what": "HIP event pairs around the launches of single Newton iterations inside the timed region",
         "avg_launch_us_event_cost_included": raw_us,
@@ -534,6 +560,8 @@ def run_ladder(device_ordinal, device, args):
         try:
             wl.krylov(1, "warm", device)
             wl.eng.profile_reset(1)
+            wl.eng._launch_us_base = wl.eng.counter("frozen_launch_us")
+            wl.eng._launch_years_base = wl.eng.counter("frozen_persistent_years")
             wl.eng.sync()
             t0 = time.perf_counter()
             wl.krylov(args.ladder_steps, "timed", device)
@@ -704,6 +732,8 @@ def main():
         if args.warmup > 0:
             wl.krylov(args.warmup, "krylov_warm", device)
         eng.profile_reset(1)
+        eng._launch_us_base = eng.counter("frozen_launch_us")
+        eng._launch_years_base = eng.counter("frozen_persistent_years")
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -790,6 +820,23 @@ def main():
                 "setup_seconds": {"total": wl.setup_s, "precond_factorisation": wl.precond_setup_s},
             }
             if world == 1:
+                if "one_launch_years" in roof:
+                    # the same year launch by launch (option "frozen_persistent" 0), with the per-launch figures of its dominant
+                    # kernel as rounds 1 and 2 reported them
+                    eng.set_option("frozen_persistent", 0)
+                    eng.profile_reset(1)
+                    eng._launch_us_base = eng.counter("frozen_launch_us")
+                    eng._launch_years_base = eng.counter("frozen_persistent_years")
+                    t_l = time.perf_counter()
+                    wl.krylov(2, "krylov_launch_path", device)
+                    eng.sync()
+                    t_l = time.perf_counter() - t_l
+                    out["launch_per_phase_path"] = {"what": "the same Krylov iterations with every frozen year as a sequence of "
+                                                            "launches (option frozen_persistent 0)",
+                                                    "jvps_per_s": 2.0 / t_l, "ms_per_jvp": 500.0 * t_l,
+                                                    "year_seconds": ModelState.last_stats[0]["seconds"],
+                                                    "roofline": roofline_of(eng, n)}
+                    eng.set_option("frozen_persistent", 1)
                 out["roofline_precond"] = precond_roofline(eng)
                 # the same Krylov iterations as ONE C call with every vector in HBM and no file trail (nk2d_gmres_solve),
                 # for what the checkpoint trail and the Python mirror cost in the timed region above

@@ -4004,10 +4004,21 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
     const int wave = TEAM ? uni_i(wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // the column
     const bool col_wave = wave < P.ncol;
     GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
-    // NB (teams only: a workgroup is a column): neighbour-to-neighbour hand-over instead of the grid barrier
-    const int nb_j = wave % P.ny;
-    NeighbourSync nbs{(unsigned*)((char*)A.arrive + 8192), A.abort_flag, wave, (nb_j > 0) ? wave - 1 : -1,
-                      (nb_j < P.ny - 1) ? wave + 1 : -1, 0u, &lds_ok, A.spin_ticks, A.fences};
+    // NB: neighbour-to-neighbour hand-over instead of the grid barrier.  The unit is the workgroup: one column (teams), or
+    // the columns of its waves -- then the workgroup to the left matters if its first column has a left neighbour, the one to
+    // the right if its last column has a right neighbour (a tracer boundary inside the workgroup needs nothing)
+    int nb_left, nb_right;
+    if constexpr (TEAM) {
+        const int nb_j = wave % P.ny;
+        nb_left = (nb_j > 0) ? wg - 1 : -1;
+        nb_right = (nb_j < P.ny - 1) ? wg + 1 : -1;
+    } else {
+        const int wpb = (int)(blockDim.x >> 6);
+        const int c0 = wg * wpb, cl = min(c0 + wpb - 1, P.ncol - 1);
+        nb_left = (c0 % P.ny > 0) ? wg - 1 : -1;
+        nb_right = (cl % P.ny < P.ny - 1) ? wg + 1 : -1;
+    }
+    NeighbourSync nbs{(unsigned*)((char*)A.arrive + 8192), A.abort_flag, wg, nb_left, nb_right, 0u, &lds_ok, A.spin_ticks, A.fences};
     const size_t nv = A.C.nv;
     int swapY = 0, swapZ = 0, status = 0, done = 0;
 #define FZ_Y (swapY ? A.YOLD : A.Y)
@@ -4015,7 +4026,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
 #define FZ_Z (swapZ ? A.ZN : A.Z)
 #define FZ_ZN (swapZ ? A.Z : A.ZN)
 #define FZ_SYNC() \
-    if (!((NB && TEAM) ? nbs.sync() : bar.sync())) { status = 1; goto finish; }
+    if (!(NB ? nbs.sync() : bar.sync())) { status = 1; goto finish; }
     // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
     if (col_wave && (!TEAM || tw == 0)) {
         double zero[E];
@@ -4098,11 +4109,11 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         done = i + 1;
     }
 finish:
-    if constexpr (NB && TEAM) {
-        // no barrier behind the last phase: every column reports a failure of its own (the host cleared `out`), column 0
-        // the rest -- a column that gave up raised the abort flag, its neighbours time out on it in turn
-        if (status != 0 && lane == 0 && tw == 0) A.out[0] = (double)status;
-        if (wave == 0 && lane == 0 && tw == 0) {
+    if constexpr (NB != 0) {
+        // no barrier behind the last phase: every workgroup reports a failure of its own (the host cleared `out`), the first
+        // the rest -- a workgroup that gave up raised the abort flag, its neighbours give up on it in turn
+        if (status != 0 && threadIdx.x == 0) A.out[0] = (double)status;
+        if (wg == 0 && threadIdx.x == 0) {
             A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ; A.out[4] = (double)nbs.phase;
         }
     } else if (wave == 0 && lane == 0 && (!TEAM || tw == 0)) {
@@ -4155,7 +4166,7 @@ template <int E, int KIND, int XCD, int TEAM>
 static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
     if (coop) {
         void* args[2] = {&P, &A};
-        if constexpr (TEAM && !XCD) {
+        if constexpr (!XCD) {
             if (c->frozen_nbsync)
                 return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
         }
@@ -4171,6 +4182,11 @@ static hipError_t launch_frozen_e(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, Fr
         case 2: return launch_frozen_one<2, KIND, XCD, TEAM>(c, coop, grid, P, A);
         case 3: if constexpr (!TEAM) return launch_frozen_one<3, KIND, XCD, 0>(c, coop, grid, P, A); else break;
         case 4: if constexpr (!TEAM) return launch_frozen_one<4, KIND, XCD, 0>(c, coop, grid, P, A); else break;
+        // five to eight levels per lane (up to 512 levels): a wave per column, cooperative flavour, linear sources
+        case 5: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<5, 0, 0, 0>(c, coop, grid, P, A); else break;
+        case 6: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<6, 0, 0, 0>(c, coop, grid, P, A); else break;
+        case 7: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<7, 0, 0, 0>(c, coop, grid, P, A); else break;
+        case 8: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<8, 0, 0, 0>(c, coop, grid, P, A); else break;
         default: break;
     }
     return hipErrorInvalidValue;
@@ -4188,7 +4204,8 @@ static hipError_t launch_frozen(nk2d_ctx* c, bool xcd, bool team, bool coop, dim
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
     if (!c->frozen_persistent || needs_state || c->hist_n != 0 || c->norm_hook || n < 1) return 1;
-    if (c->E > c->frozen_persistent_max_e || c->E > 4) return 1;
+    // (instantiated for one to four levels per lane, and for five to eight with linear sources)
+    if (c->E > c->frozen_persistent_max_e || c->E > 8 || (c->E > 4 && c->kind != 0)) return 1;
     // every row but the last must hand over to the next one (t_new == next t, whole step taken): the step-ending launch
     // predicts the next attempt from this step's collocation polynomial
     for (int64_t i = 0; i + 1 < n; ++i) {
@@ -4199,9 +4216,25 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     const size_t ntab = (size_t)c->ncol * NK2D_TAB * 64;
     const double bytes = 8.0 * (double)n * (3.0 * c->kv_len + 5.0 * c->np + 3.0 * c->nv + 3.0 * ntab);
     if (bytes > c->frozen_cache_max_gb * 1.0e9) return 1;
+    {   // ... and never more than what the device has to spare right now (other contexts of the process, other tenants)
+        nk2d_frozen_cache* have = (nk2d_frozen_cache*)c->frozen_cache;
+        if (!have || have->cap_rows < (size_t)n) {
+            size_t free_b = 0, total_b = 0;
+            NK2D_CHECK(c, hipMemGetInfo(&free_b, &total_b));
+            const double held = have ? 8.0 * (double)have->cap_rows * (3.0 * c->kv_len + 5.0 * c->np + 3.0 * c->nv + 3.0 * ntab) : 0.0;
+            if (1.02 * bytes > 0.85 * ((double)free_b + held)) return 1;
+        }
+    }
     nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
     if (!fc) { fc = new nk2d_frozen_cache(); c->frozen_cache = fc; }
     const uint64_t key = sched_key(sched, n) ^ (uint64_t)nk2d_fingerprint(c);
+    if (fc->key != key || fc->n != n) {
+        // option "frozen_cache_after" (default 0): that many years of a schedule run launch by launch before its cache is built
+        // (26 ms at 416 x 416, where a one-launch year saves 40 ms: it pays from the first year on; tools/probe_cache_build.py)
+        const int after = std::max(c->frozen_cache_after, 0);
+        if (c->frozen_seen_key != key) { c->frozen_seen_key = key; c->frozen_seen_years = 0; }
+        if (c->frozen_seen_years++ < after) return 1;
+    }
     DevP P = make_devp(c);
     P.guard = nullptr;
     if (fc->key != key || fc->n != n) {
@@ -4213,7 +4246,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
             if (fc->rows_dev) (void)hipFree(fc->rows_dev);
             if (fc->frows_dev) (void)hipFree(fc->frows_dev);
             fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
-            const size_t cap = (size_t)n + (size_t)n / 8 + 16;
+            const size_t cap = (size_t)n + (bytes > 8.0e9 ? (size_t)n / 64 : (size_t)n / 8) + 16;   // (a large cache: little slack)
             NK2D_CHECK(c, hipMalloc((void**)&fc->C.KV, sizeof(double) * cap * 3 * c->kv_len));
             NK2D_CHECK(c, hipMalloc((void**)&fc->C.J, sizeof(double) * cap * 5 * c->np));
             NK2D_CHECK(c, hipMalloc((void**)&fc->C.fr_inv, sizeof(double) * cap * c->nv));
@@ -4314,7 +4347,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     A.tickets = (unsigned*)((char*)c->YR_SYNC + 6144);
     A.nwg = nblk;
     const double* o = c->hYR_OUT;
-    bool ran = false;
+    bool ran = false, timed = false;
     // ---- all of the year's workgroups on ONE XCD (option "frozen_xcd"; at most what an XCD's 32 CUs hold at once)
     // (one workgroup per CU is what the kernel's registers admit at two levels per lane: an XCD holds 32 of them at once)
     if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28) {
@@ -4322,11 +4355,14 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
         const dim3 grid(8 * nblk + 64);
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
         NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
         NK2D_CHECK(c, hipGetLastError());
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
         NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
         ran = (int)o[0] == 0 && (int64_t)o[1] == n;
+        timed = true;
         if (!ran) {
             // XCD 0 did not get its workgroups (placement is not promised): not again on this context; the state is
             // where the year started only if nothing ran -- hand the year back to the caller, who restarts it
@@ -4339,17 +4375,25 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
         hipError_t rc = hipErrorInvalidValue;
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
         {
             std::lock_guard<std::mutex> coop(coop_launch_mutex());
             rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
         }
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
+        timed = true;
         NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
         NK2D_CHECK(c, hipStreamSynchronize(c->stream));
         if ((int)o[0] != 0 || (int64_t)o[1] != n) return 2;
     }
     if (team) c->frozen_team_years++;
+    if (timed) {   // the launch itself, between two events on the context's stream (bench.py's roofline of the one-launch year)
+        float ms = 0.f;
+        NK2D_CHECK(c, hipEventElapsedTime(&ms, c->yr_ev[0], c->yr_ev[1]));
+        c->frozen_launch_us += (int64_t)(1000.0 * (double)ms);
+    }
     if ((int)o[2]) std::swap(c->Y, c->YOLD);
     if ((int)o[3]) std::swap(c->Z, c->ZN);
     // counters of the year, as the launch-per-phase path books them, and the algorithmic bytes of its phases (the formula of

@@ -160,6 +160,36 @@ def test_team_and_wave_per_column_flavours_agree(case):
     eng.close()
 
 
+def test_full_size_year_in_one_launch():
+    """416 x 416 (seven levels per lane, a wave per column, workgroups hand over to their neighbours): the one-launch year on
+    the schedule cache -- 2 600 steps' planes and factorisations, 100 GB of the 288 -- against the launch-per-phase year: bit for
+    bit for the recorded and for a perturbed state, the launch itself faster than the year of launches, and a second schedule
+    rebuilds the cache in place"""
+    n = 416
+    eng = _iage(n)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
+    x = eng.upload(x0)
+    # a smooth perturbation (white noise is not a state the recorded steps control: the sampled error estimates object)
+    zz = np.linspace(0.0, 1.0, n)
+    xp = eng.upload(x0 * (1.0 + 1.0e-4 * np.outer(np.sin(3.0 * zz), np.cos(2.0 * zz))[None]))
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    eng.set_option("frozen_persistent", 0)
+    want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_l = eng.comp_fcn_frozen(xp, sched)
+    eng.set_option("frozen_persistent", 1)
+    got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_p = eng.comp_fcn_frozen(xp, sched)
+    assert eng.counter("frozen_persistent_years") == 3 and eng.counter("frozen_cache_builds") == 1
+    assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert st_p["nlaunch"] < 20 < st_l["nlaunch"] and st_p["seconds"] < 0.9 * st_l["seconds"]
+    print(f"416^2 frozen year: {1e3 * st_l['seconds']:.1f} ms launch by launch, {1e3 * st_p['seconds']:.1f} ms in one launch")
+    fx2, _, sched2 = eng.comp_fcn(xp, record=True)
+    fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
+    assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
+    eng.close()
+
+
 def test_what_it_is_not_for_takes_the_other_path():
     from nk_ooc_amd.engine import phosphorus_engine
     from nk_ooc_amd.grid import Grid2d
@@ -178,6 +208,7 @@ def test_what_it_is_not_for_takes_the_other_path():
     eng = _iage(130, 9)
     _, x, _ = _state(eng)
     fx, _, sched = eng.comp_fcn(x, record=True)
+    eng.set_option("frozen_persistent_max_e", 2)
     eng.comp_fcn_frozen(x, sched)
     assert eng.counter("frozen_persistent_years") == 0
     eng.set_option("frozen_persistent_max_e", 3)

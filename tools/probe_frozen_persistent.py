@@ -14,7 +14,8 @@ from nk_ooc_amd.grid import Grid2d  # noqa: E402
 for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104", "208"])]:
     eng = iage_engine(Grid2d.default(n, n))
     eng.set_option("frozen_persistent_max_e", 8)
-    eng.set_option("frozen_cache_gb", 64.0)
+    eng.set_option("frozen_cache_gb", 128.0)
+    eng.set_option("frozen_err_check", 0)     # (the perturbed state below is white noise: not a state the recorded steps control)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
     x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])
