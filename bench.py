@@ -446,9 +446,14 @@ def roofline_of(eng, n):
         pmc_fname = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_one_launch_{n}.json")
         if os.path.exists(pmc_fname):
             pmc = json.load(open(pmc_fname))
-            out["traffic"] = pmc["traffic_bytes_per_launch_upper"]
-            out["traffic_source"] = ("static profile file " + os.path.relpath(pmc_fname, ROOT) +
-                                     " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not collected in this run)")
+            # the counters were collected on a year of another schedule (tools/probe_traffic.py: 9 751 phases, here
+            # `phases_per_launch`): their ratio to the algorithmic bytes of THAT year, applied to this one's
+            out["traffic"] = pmc["traffic_over_algorithmic"] * nbytes
+            out["traffic_over_algorithmic"] = pmc["traffic_over_algorithmic"]
+            out["traffic_source"] = ("static profile file " + os.path.relpath(pmc_fname, ROOT) + " (separate rocprofv3 --pmc "
+                                     "FETCH_SIZE / WRITE_SIZE passes over the same kernel on another year: "
+                                     f"{pmc['traffic_bytes_per_launch_upper']:.4g} B of fabric traffic for "
+                                     f"{pmc['algorithmic_bytes_per_launch']:.4g} algorithmic; not collected in this run)")
         stats_fname = os.path.join(ROOT, "profiles", f"r03_rocprof_one_launch_{n}", "kernel_stats.csv")
         if os.path.exists(stats_fname):
             for line in open(stats_fname):

@@ -204,11 +204,13 @@ int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n
    resumed. */
 int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
 int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
-/* Small grids (at most "frozen_persistent_max_e" levels per lane, default 2 = 128 levels; modules whose Jacobian is a function
-   of time alone): a frozen year runs as ONE cooperative launch (a wave per column, grid barriers between the simplified-Newton
-   iterations) on a cache of everything its schedule fixes besides the state -- mixing planes, Jacobian planes and line
+/* Modules whose Jacobian is a function of time alone, grids of up to 512 levels (option "frozen_persistent_max_e", levels per
+   lane, default 8; five to eight only with linear sources): a frozen year runs as ONE cooperative launch -- a wave or a
+   four-wave team per column, one simplified-Newton iteration per phase, workgroups handing over to their lateral neighbours
+   between phases -- on a cache of everything its schedule fixes besides the state: mixing planes, Jacobian planes and line
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
-   "frozen_cache_gb").  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
+   "frozen_cache_gb": at most that much HBM, default 128, and never more than 85 % of what the device has free; 102 GB and 26 ms
+   per schedule at 416 x 416, where the year takes 149 ms instead of 190 ms).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
    "frozen_xcd_years" (of them: all workgroups on one XCD), "frozen_team_years" (of them: a four-wave team per column),
    "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes"; of the host-side controller: "spec_launches_dropped",

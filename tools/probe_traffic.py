@@ -20,11 +20,17 @@ x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
 eng.profile_reset(0)
 fx, st, sched = eng.comp_fcn(x, record=True)
 rng = np.random.default_rng(0)
+eng.set_option("frozen_err_check", 0)       # (white-noise perturbations: not states the recorded steps control)
 for _ in range(2):
     xp = eng.upload(eng.download(x) * (1.0 + 1.0e-4 * rng.standard_normal(eng.shape)))
+    before = eng.profile_totals()
     _, stf = eng.comp_fcn_frozen(xp, sched)
+    after = eng.profile_totals()
 shapes = eng.profile_shapes()
 totals = eng.profile_totals()
 print(json.dumps({"free_year": st, "frozen_year": stf, "launch_shapes_without_factorisation": shapes,
                   "all_launches": totals,
+                  "last_frozen_year": {"algorithmic_bytes": after["bytes"] - before["bytes"],
+                                       "launches_booked": after["launches"] - before["launches"],
+                                       "one_launch_years_so_far": eng.counter("frozen_persistent_years")},
                   "algorithmic_bytes_per_launch_without_factorisation": sum(shapes["bytes"]) / max(sum(shapes["counts"]), 1)}))
