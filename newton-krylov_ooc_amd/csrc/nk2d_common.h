@@ -601,7 +601,7 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 double nk2d_fingerprint(const nk2d_ctx* c);
-int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n);
+int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows = nullptr);
 void nk2d_frozen_cache_free(nk2d_ctx* c);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);

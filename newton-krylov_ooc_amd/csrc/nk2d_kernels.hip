@@ -3948,10 +3948,12 @@ struct FrozenRow {
     double mreal, mcr, mci;      // MU / h of the row
     double x0, x1, x2;           // dense-output abscissae of the NEXT row's stage times (the step-ending launch)
     int n_iter, m;               // simplified-Newton iterations, sweeps per solve
+    double h;                    // step size
+    int err;                     // 1: SciPy's error estimate of this step is evaluated too (its partials to row 3 i + 2 of STEP_PART)
 };
 
 struct FrozenArgs {
-    double *Y, *YOLD, *Z, *ZN, *W;
+    double *Y, *YOLD, *Z, *ZN, *W, *F;
     double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2];
     double* PART;                // scratch partials [ncol]
     double* STEP_PART;           // rows of ncol: 3 per step (last iteration, the one before, error estimate -- unused here)
@@ -3973,6 +3975,63 @@ struct FrozenArgs {
 // -- a barrier costs 1.0-1.5 us instead of 2.1 us and a neighbour's column comes from L2 instead of the fabric
 // (tools/proto_xcd_barrier.hip, profiles/r03_xcd_barrier.log).  HIP promises no placement: if XCD 0 does not get its nwg
 // workgroups the barrier times out, the abort flag is raised and the caller runs the cooperative flavour (XCD = 0).
+// f = fun(t, y) of the column (the plane kvp is the mixing plane at t): the tendency at a step start, for the error estimate
+template <int E, int KIND, int MP>
+__device__ __forceinline__ void tend_at_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ kvp,
+                                             double* __restrict__ f, int task, int lane) {
+    const int tr = task / P.ny, j = task - tr * P.ny;
+    const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
+    ColCoef<E> cf;
+    load_coef<E>(P, j, lane, cf);
+    double c[E], cs[E], cn[E], kv[E], ff[E];
+    load_col<E, MP>(y, task, lane, c);
+    load_col<E, MP>(y, cs_col, lane, cs);
+    load_col<E, MP>(y, cn_col, lane, cn);
+    load_col<E, MP>(kvp, j, lane, kv);
+    tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, ff);
+    if constexpr (KIND == 2) forced_sources<E>(P, kvp, j, lane, c, ff);
+    store_col<E, MP>(f, task, lane, ff);
+}
+
+// what the step-ending launch does behind the update (FINAL in newton_fused_body), from the stage values in memory: for
+// the steps whose last Newton iteration is an ordinary one because their error estimate sits in between
+template <int E, int MP>
+__device__ __forceinline__ void step_tail_body(const double* __restrict__ y, const double* __restrict__ z, size_t nv,
+                                               const FinalArgs& fin, double* __restrict__ wout, int task, int lane) {
+    double yy[E], z0[E], z1[E], z2[E], yn[E];
+    load_col<E, MP>(y, task, lane, yy);
+    load_col<E, MP>(z, task, lane, z0);
+    load_col<E, MP>(z + nv, task, lane, z1);
+    load_col<E, MP>(z + 2 * nv, task, lane, z2);
+#pragma unroll
+    for (int e = 0; e < E; ++e) yn[e] = yy[e] + z2[e];
+    store_col<E, MP>(fin.ynew, task, lane, yn);
+    const double xs[3] = {fin.x0, fin.x1, fin.x2};
+    double o[3][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        double q[3];
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) q[cidx] = (z0[e] * cP[0][cidx] + z1[e] * cP[1][cidx]) + z2[e] * cP[2][cidx];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double p1 = xs[i], p2 = p1 * xs[i], p3 = p2 * xs[i];
+            double v = (q[0] * p1 + q[1] * p2) + q[2] * p3;
+            v = v + yy[e];
+            o[i][e] = v - yn[e];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) store_col<E, MP>(fin.znext + i * nv, task, lane, o[i]);
+    double wv[E];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
+        store_col<E, MP>(wout + r * nv, task, lane, wv);
+    }
+}
+
 // TEAM = 1: a workgroup is ONE column, its four waves the team of newton_team_body (a stage tendency each on three of them,
 // the complex system on the fourth, exchanges through LDS): the phase of a small grid is the dependent arithmetic of one
 // column's Newton iteration, and the team cuts that chain (three tendencies one after the other, then the real and the
@@ -4045,11 +4104,20 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         const bool last_row = i == A.n - 1;
         const double* kvb = A.C.KV + (size_t)i * 3 * A.C.kv_len;
         const double* J = A.C.J + (size_t)i * 5 * A.C.np;
+        // SciPy's error estimate on this step too (every "frozen_err_check"-th: the host compares it with what the recorded
+        // step was accepted with).  Three phases of their own, one wave per column: the tendency at the step start before the
+        // Newton iterations, the estimate behind the last of them -- which is then an ordinary iteration --, the end of the step
+        const bool with_err = uni_i(R.err) != 0 && !last_row && i > 0;
+        if (with_err) {
+            if (col_wave && (!TEAM || tw == 0))
+                tend_at_body<E, KIND, MPX>(P, FZ_Y, A.C.KV + ((size_t)(i - 1) * 3 + 2) * A.C.kv_len, A.F, wave, lane);
+            FZ_SYNC()
+        }
         for (int k = 0; k < n_iter; ++k) {
             int src = 0;
             for (int it = 0; it < m; ++it) {
                 const bool do_stage = it == 0, first = it == 0, do_update = it == m - 1, delta = m == 2;
-                const bool is_final = do_update && k == n_iter - 1 && !last_row;
+                const bool is_final = do_update && k == n_iter - 1 && !last_row && !with_err;
                 FusedArgs FA = {};
                 FA.st.y = FZ_Y; FA.st.z = FZ_Z; FA.st.w = A.W;
                 FA.st.zout = (do_stage && do_update) ? FZ_ZN : FZ_Z;
@@ -4105,6 +4173,31 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                 src = 1 - src;
                 FZ_SYNC()
             }
+        }
+        if (with_err) {
+            if (col_wave && (!TEAM || tw == 0)) {
+                ErrArgs EA = {};
+                EA.sw.JL = J; EA.sw.JU = J + A.C.np; EA.sw.JS = J + 2 * A.C.np; EA.sw.JN = J + 3 * A.C.np; EA.sw.JC = J + 4 * A.C.np;
+                EA.sw.fr_inv = A.C.fr_inv + (size_t)i * nv;
+                EA.sw.fr_tab = A.C.fr_tab + (size_t)i * A.C.ntab;
+                EA.sw.xr_old = A.XR[0]; EA.sw.xr_new = A.XR[1];
+                EA.f = A.F; EA.z = FZ_Z; EA.y = FZ_Y; EA.nv = nv; EA.h = R.h;
+                EA.part = A.STEP_PART + (size_t)(3 * i + 2) * P.ncol;
+                EA.stage = 0; EA.last = 1;
+                err_fused_body<E, KIND, MPX>(P, EA, wave, lane);
+            }
+            FZ_SYNC()
+            if (col_wave && (!TEAM || tw == 0)) {
+                FinalArgs Fin;
+                Fin.ynew = FZ_YOLD;
+                Fin.znext = FZ_ZN;
+                Fin.x0 = R.x0; Fin.x1 = R.x1; Fin.x2 = R.x2;
+                Fin.nblk_cols = 0;
+                step_tail_body<E, MPX>(FZ_Y, FZ_Z, nv, Fin, A.W, wave, lane);
+            }
+            swapY ^= 1;
+            swapZ ^= 1;
+            FZ_SYNC()
         }
         done = i + 1;
     }
@@ -4201,7 +4294,7 @@ static hipError_t launch_frozen(nk2d_ctx* c, bool xcd, bool team, bool coop, dim
     return forced ? launch_frozen_e<2, 0, 0>(c, coop, grid, P, A) : launch_frozen_e<0, 0, 0>(c, coop, grid, P, A);
 }
 
-int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
+int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows) {
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
     if (!c->frozen_persistent || needs_state || c->hist_n != 0 || c->norm_hook || n < 1) return 1;
     // (instantiated for one to four levels per lane, and for five to eight with linear sources)
@@ -4227,7 +4320,8 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     }
     nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
     if (!fc) { fc = new nk2d_frozen_cache(); c->frozen_cache = fc; }
-    const uint64_t key = sched_key(sched, n) ^ (uint64_t)nk2d_fingerprint(c);
+    // (the rows also say which steps carry an error estimate)
+    const uint64_t key = sched_key(sched, n) ^ (uint64_t)nk2d_fingerprint(c) ^ ((uint64_t)(c->frozen_err_check + 1) * 0x9E3779B97F4A7C15ull);
     if (fc->key != key || fc->n != n) {
         // option "frozen_cache_after" (default 0): that many years of a schedule run launch by launch before its cache is built
         // (26 ms at 416 x 416, where a one-launch year saves 40 ms: it pays from the first year on; tools/probe_cache_build.py)
@@ -4284,6 +4378,9 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
             int m_real = nk2d_sweeps_for(c, MU_REAL / h_lu), m_cplx = nk2d_sweeps_for(c, MU_CR / h_lu);
             if (c->min_sweeps > 1 && nk2d_has_lateral(c)) { m_real = std::max(m_real, 2); m_cplx = std::max(m_cplx, 2); }
             F.m = std::max(m_real, m_cplx);
+            F.h = h;
+            // (single-sweep solves only: the estimate is then the column's own; two-sweep rows go unsampled)
+            F.err = (c->frozen_err_check > 0 && i > 0 && i + 1 < n && (i % c->frozen_err_check) == 0 && F.m == 1 && F.n_iter >= 1) ? 1 : 0;
             F.x0 = F.x1 = F.x2 = 1.0;
             if (i + 1 < n) {
                 const double h2 = r[NK2D_SCHED_WIDTH + 2];
@@ -4325,7 +4422,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
     }
     NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), c->stream));
     FrozenArgs A = {};
-    A.Y = c->Y; A.YOLD = c->YOLD; A.Z = c->Z; A.ZN = c->ZN; A.W = c->W;
+    A.Y = c->Y; A.YOLD = c->YOLD; A.Z = c->Z; A.ZN = c->ZN; A.W = c->W; A.F = c->F;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
     for (int i = 0; i < 2; ++i) { A.XR[i] = c->XR[i]; A.XCR[i] = c->XCR[i]; A.XCI[i] = c->XCI[i]; }
     A.PART = c->YR_PART;
@@ -4405,6 +4502,11 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n) {
         double words = 0.0;
         for (int it = 0; it < F.m; ++it) words += fused_words(c, it == 0, it == 0, it == F.m - 1, F.m == 2, false);
         c->fused_bytes_all += 8.0 * words * F.n_iter;
+    }
+    if (err_rows) {
+        err_rows->assign((size_t)n, 0);
+        for (int64_t i = 0; i < n; ++i)
+            if (fc->frows[(size_t)i].err) { (*err_rows)[(size_t)i] = 1; c->st.nerr_checked++; c->st.nfev++; c->st.nsolve++; }
     }
     c->sweep_launches += 1;
     c->st.nsteps += n - 1;      // the last row's commit is the caller's

@@ -1009,8 +1009,32 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
     // ---- small grids: the whole year in one launch on the schedule cache (k_frozen_persistent).  Its steps are checked like
     // any frozen year's; one that does not pass -- or a barrier that timed out -- hands the year back, from x, to the
     // launch-per-phase path below with its checkpoints and resumes (return 3: the caller restarts the year)
+    // the sampled error estimates of the rows flagged in `done`, from row `from` up to (not including) row `upto` (-1: all):
+    // the first row whose estimate exceeds what the recorded step was accepted with, or -1
+    auto first_bad_err = [&](const double* rows, int64_t from, int64_t upto, const std::vector<char>& done) -> int64_t {
+        double max_err = 0.0;
+        int64_t bad_err = -1;
+        for (int64_t i = from; i < n; ++i) {
+            if (upto >= 0 && i >= upto) break;       // beyond a step that did not converge the state means nothing
+            if (!done[(size_t)i]) continue;
+            const double err = rms_from_sum(sums[3 * i + 2], n_unknowns);
+            if (!(err == err)) { bad_err = i; break; }
+            max_err = std::max(max_err, err);
+            const double base = rows[i * NK2D_SCHED_WIDTH + 6];
+            if (err > 1.5 * std::max(1.0, base) && bad_err < 0) bad_err = i;
+        }
+        c->st.max_err = std::max(c->st.max_err, max_err);
+        return bad_err;
+    };
+    auto err_failure = [&](int64_t bad_err) {
+        c->frozen_fallbacks++;
+        return nk2d_fail(c, "nk2d_comp_fcn_frozen: the error estimate of step " + std::to_string(bad_err) + " of " +
+                            std::to_string(n) + " exceeds what the recorded step was accepted with: the recorded steps "
+                            "do not control the error for this state", -7);
+    };
     if (!s.no_persistent && s.device_ctl == 0) {
-        const int prc = nk2d_frozen_persistent(c, sched, n);
+        std::vector<char> sampled;
+        const int prc = nk2d_frozen_persistent(c, sched, n, &sampled);
         if (prc < 0) return prc;
         if (prc == 0) {
             const double* r = sched + (n - 1) * NK2D_SCHED_WIDTH;
@@ -1018,6 +1042,9 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
             NK2D_TRY(commit_step(s, r[0], r[1]));
             NK2D_TRY(fetch_sums(0));
             if (first_unconverged(sched, 0) < 0) {
+                // (not with a norm hook -- but a hooked context never takes this way)
+                const int64_t bad_err = first_bad_err(sched, 0, -1, sampled);
+                if (bad_err >= 0) return err_failure(bad_err);
                 c->frozen_persistent_years++;
                 return 0;
             }
@@ -1060,25 +1087,8 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
         const int64_t bad = first_unconverged(cur, start);
         const std::string why = "the recorded Newton iteration count does not converge for this state";
         // the sampled error estimates (not with a norm hook: a shard sees only its own tracers' share)
-        double max_err = 0.0;
-        int64_t bad_err = -1;
-        if (!hooked)
-            for (int64_t i = start; i < n; ++i) {
-                if (bad >= 0 && i >= bad) break;       // beyond a step that did not converge the state means nothing
-                if (!err_done[(size_t)i]) continue;
-                const double err = rms_from_sum(sums[3 * i + 2], n_unknowns);
-                if (!(err == err)) { bad_err = i; break; }
-                max_err = std::max(max_err, err);
-                const double base = cur[i * NK2D_SCHED_WIDTH + 6];
-                if (err > 1.5 * std::max(1.0, base) && bad_err < 0) bad_err = i;
-            }
-        c->st.max_err = std::max(c->st.max_err, max_err);
-        if (bad_err >= 0) {
-            c->frozen_fallbacks++;
-            return nk2d_fail(c, "nk2d_comp_fcn_frozen: the error estimate of step " + std::to_string(bad_err) + " of " +
-                                std::to_string(n) + " exceeds what the recorded step was accepted with: the recorded steps "
-                                "do not control the error for this state", -7);
-        }
+        const int64_t bad_err = hooked ? -1 : first_bad_err(cur, start, bad, err_done);
+        if (bad_err >= 0) return err_failure(bad_err);
         if (bad < 0) return 0;
         // one more Newton iteration at the first step that did not converge, from the checkpoint before it -- where that
         // can be done (host-launched replay, SciPy's cap of six iterations, two resumes per year)

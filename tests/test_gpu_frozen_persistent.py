@@ -52,9 +52,9 @@ def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
     assert eng.counter("frozen_team_years") == 2 and eng.counter("frozen_xcd_years") == 0
     for key in ("nsteps", "nnewton"):
         assert st_p[key] == st_l[key], key
-    # (the launch-per-phase year also evaluates the error estimate of every 128th step -- a tendency and a solve each;
-    # the one-launch year checks the Newton convergence of every step only)
-    assert st_l["nerr_checked"] > 0 and st_p["nerr_checked"] == 0 and st_l["nfev"] > st_p["nfev"]
+    # (both evaluate the error estimate of every 128th step -- a tendency and a solve each; the one-launch year leaves out
+    # the first step and steps with two-sweep solves)
+    assert 0 < st_p["nerr_checked"] <= st_l["nerr_checked"] and st_p["max_err"] > 0.0
     assert st_p["nlaunch"] < 20 < st_l["nlaunch"]
     assert st_pp["seconds"] < st_l["seconds"]
     # a new schedule (another state's year): a new cache
