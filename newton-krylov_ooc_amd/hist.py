@@ -171,7 +171,7 @@ class HistWriter:
         # at most two files in flight: a third submit waits for the oldest (bounds the host memory held by the queue)
         while len(self._pending) >= 2:
             self.wait(next(iter(self._pending)))
-        self._pending[key] = self._pool.submit(write_hist_file, fname, grid, time, module_hists, vmix_samples, stamp)
+        self._pending[key] = self._pool.submit(_write_then_rename, fname, grid, time, module_hists, vmix_samples, stamp)
 
     def wait(self, fname=None):
         import os
@@ -248,6 +248,17 @@ class HistWriter:
     def forget(self):
         self.wait()
         self._records.clear()
+
+
+def _write_then_rename(fname, grid, time, module_hists, vmix_samples, stamp):
+    """the background write: under a temporary name, then renamed -- the step log may already call the forward year complete
+    while this is on its way, and a run killed in between must find either the whole file or none under the name (a resumed
+    run then fails on the missing file and is rewound, as after any other interrupted step; never on half a file)"""
+    import os
+
+    tmp = fname + ".partial"
+    write_hist_file(tmp, grid, time, module_hists, vmix_samples, stamp)
+    os.replace(tmp, fname)
 
 
 def write_hist_file(fname, grid, time, module_hists, vmix_coeff, stamp=None):
