@@ -210,7 +210,9 @@ int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
    between phases -- on a cache of everything its schedule fixes besides the state: mixing planes, Jacobian planes and line
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
    "frozen_cache_gb": at most that much HBM, default 128, and never more than 85 % of what the device has free; 102 GB and 26 ms
-   per schedule at 416 x 416, where the year takes 149 ms instead of 190 ms).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
+   per schedule at 416 x 416, where the year takes 149 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
+   that run launch by launch before its cache is built, default -1 = none for caches up to 8 GB, three above -- the first
+   allocation of a 100 GB cache can take a second inside a solver run).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
    "frozen_xcd_years" (of them: all workgroups on one XCD), "frozen_team_years" (of them: a four-wave team per column),
    "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes"; of the host-side controller: "spec_launches_dropped",

@@ -514,7 +514,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_xcd = 1;
     c->frozen_team = 1;
     c->frozen_nbsync = 1;
-    c->frozen_cache_after = 0;
+    c->frozen_cache_after = -1;
     c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;

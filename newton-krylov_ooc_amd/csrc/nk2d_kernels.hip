@@ -4225,6 +4225,7 @@ struct nk2d_frozen_cache {
     uint64_t key = 0;
     int64_t n = 0;
     CachePtrs C = {};
+    double* slab = nullptr;            // the one allocation the table pointers of C point into
     CacheRow* rows_dev = nullptr;      // [n]
     FrozenRow* frows_dev = nullptr;    // [n]
     size_t cap_rows = 0;
@@ -4242,9 +4243,7 @@ static uint64_t sched_key(const double* sched, int64_t n) {
 void nk2d_frozen_cache_free(nk2d_ctx* c) {
     nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
     if (!fc) return;
-    double* bufs[] = {fc->C.KV, fc->C.J, fc->C.fr_inv, fc->C.fc_invr, fc->C.fc_invi, fc->C.fr_tab, fc->C.fc_tabr, fc->C.fc_tabi};
-    for (double* b : bufs)
-        if (b) (void)hipFree(b);
+    if (fc->slab) (void)hipFree(fc->slab);
     if (fc->rows_dev) (void)hipFree(fc->rows_dev);
     if (fc->frows_dev) (void)hipFree(fc->frows_dev);
     delete fc;
@@ -4323,9 +4322,11 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     // (the rows also say which steps carry an error estimate)
     const uint64_t key = sched_key(sched, n) ^ (uint64_t)nk2d_fingerprint(c) ^ ((uint64_t)(c->frozen_err_check + 1) * 0x9E3779B97F4A7C15ull);
     if (fc->key != key || fc->n != n) {
-        // option "frozen_cache_after" (default 0): that many years of a schedule run launch by launch before its cache is built
-        // (26 ms at 416 x 416, where a one-launch year saves 40 ms: it pays from the first year on; tools/probe_cache_build.py)
-        const int after = std::max(c->frozen_cache_after, 0);
+        // option "frozen_cache_after": that many years of a schedule run launch by launch before its cache is built.  Default:
+        // 0 for caches below 8 GB, 3 above.  Building a 100 GB cache takes 26 ms where a one-launch year saves 40
+        // (tools/probe_cache_build.py) -- but its FIRST allocation has been seen to take 0.8 s inside a Newton run, and a Newton
+        // iteration with two or three Krylov iterations has nothing to pay that back with; a long Krylov solve has.
+        const int after = c->frozen_cache_after >= 0 ? c->frozen_cache_after : (bytes > 8.0e9 ? 3 : 0);
         if (c->frozen_seen_key != key) { c->frozen_seen_key = key; c->frozen_seen_years = 0; }
         if (c->frozen_seen_years++ < after) return 1;
     }
@@ -4334,21 +4335,31 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     if (fc->key != key || fc->n != n) {
         // ---- (re)build the cache for this schedule
         if (fc->cap_rows < (size_t)n) {
+            // ONE allocation for the whole cache, with room for the longer schedules of later Newton iterates: giving 100 GB
+            // back and asking for them again costs seconds (measured inside a Newton run: 4.4 s), the first request 0.03 - 0.8 s
             NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-            double** bufs[] = {&fc->C.KV, &fc->C.J, &fc->C.fr_inv, &fc->C.fc_invr, &fc->C.fc_invi, &fc->C.fr_tab, &fc->C.fc_tabr, &fc->C.fc_tabi};
-            for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+            if (fc->slab) (void)hipFree(fc->slab);
             if (fc->rows_dev) (void)hipFree(fc->rows_dev);
             if (fc->frows_dev) (void)hipFree(fc->frows_dev);
-            fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
-            const size_t cap = (size_t)n + (bytes > 8.0e9 ? (size_t)n / 64 : (size_t)n / 8) + 16;   // (a large cache: little slack)
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.KV, sizeof(double) * cap * 3 * c->kv_len));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.J, sizeof(double) * cap * 5 * c->np));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fr_inv, sizeof(double) * cap * c->nv));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_invr, sizeof(double) * cap * c->nv));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_invi, sizeof(double) * cap * c->nv));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fr_tab, sizeof(double) * cap * ntab));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_tabr, sizeof(double) * cap * ntab));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->C.fc_tabi, sizeof(double) * cap * ntab));
+            fc->slab = nullptr; fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
+            const size_t per_row = 3 * c->kv_len + 5 * c->np + 3 * c->nv + 3 * ntab;
+            size_t cap = (size_t)n + (size_t)n / 6 + 16;
+            {
+                size_t free_b = 0, total_b = 0;
+                NK2D_CHECK(c, hipMemGetInfo(&free_b, &total_b));
+                const size_t fit = (size_t)(0.9 * (double)free_b / (8.0 * (double)per_row));
+                cap = std::max((size_t)n, std::min(cap, fit));
+            }
+            NK2D_CHECK(c, hipMalloc((void**)&fc->slab, sizeof(double) * cap * per_row));
+            double* p = fc->slab;
+            fc->C.KV = p; p += cap * 3 * c->kv_len;
+            fc->C.J = p; p += cap * 5 * c->np;
+            fc->C.fr_inv = p; p += cap * c->nv;
+            fc->C.fc_invr = p; p += cap * c->nv;
+            fc->C.fc_invi = p; p += cap * c->nv;
+            fc->C.fr_tab = p; p += cap * ntab;
+            fc->C.fc_tabr = p; p += cap * ntab;
+            fc->C.fc_tabi = p;
             NK2D_CHECK(c, hipMalloc((void**)&fc->rows_dev, sizeof(CacheRow) * cap));
             NK2D_CHECK(c, hipMalloc((void**)&fc->frows_dev, sizeof(FrozenRow) * cap));
             fc->cap_rows = cap;

@@ -14,6 +14,7 @@ def _iage(n, ny=None):
 
     eng = iage_engine(Grid2d.default(n, ny or n))
     eng.set_option("device_ctl", 0)
+    eng.set_option("frozen_cache_after", 0)     # (a cache above 8 GB -- 104 x 104 -- is otherwise built for the fourth year of a schedule)
     return eng
 
 
@@ -167,6 +168,7 @@ def test_full_size_year_in_one_launch():
     rebuilds the cache in place"""
     n = 416
     eng = _iage(n)
+    eng.set_option("frozen_cache_after", 0)       # (default for a cache of this size: built for the fourth year of a schedule)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
     x = eng.upload(x0)
@@ -187,6 +189,15 @@ def test_full_size_year_in_one_launch():
     fx2, _, sched2 = eng.comp_fcn(xp, record=True)
     fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
     assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
+    # the default policy for a cache of 100 GB: the first three years of a schedule launch by launch, then the cache
+    eng.set_option("frozen_cache_after", -1)
+    fx3, _, sched3 = eng.comp_fcn(x, record=True)       # (the first schedule again: its cache was replaced)
+    years = eng.counter("frozen_persistent_years")
+    for k in range(4):
+        fx3_p, _ = eng.comp_fcn_frozen(x, sched3)
+        assert np.array_equal(eng.download(fx3_p), eng.download(fx3))
+        assert eng.counter("frozen_persistent_years") == years + (1 if k == 3 else 0)
+    assert eng.counter("frozen_cache_builds") == 3
     eng.close()
 
 

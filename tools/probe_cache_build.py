@@ -29,6 +29,20 @@ def timed(vec, sched):
 
 
 fx, st, sched = eng.comp_fcn(x, record=True)
+extra = sys.argv[2:] if len(sys.argv) > 2 else []
+if "precond" in extra:      # the preconditioner's 10 GB first, as a solver has them
+    t0 = time.perf_counter()
+    eng.precond_setup()
+    eng.sync()
+    print(f"precond_setup {1e3 * (time.perf_counter() - t0):.0f} ms", flush=True)
+if "launchfirst" in extra:  # a launch-per-phase frozen year first
+    eng.set_option("frozen_persistent", 0)
+    print(f"launch-per-phase year first: {timed(x, sched)[0]:.1f} ms", flush=True)
+    eng.set_option("frozen_persistent", 1)
+if "hist" in extra:         # a year with history samples first (the 169 MB host array of a Newton iteration)
+    t0 = time.perf_counter()
+    eng.comp_fcn_hist(x, np.linspace(0.0, 365.0 * 86400.0, 61))
+    print(f"comp_fcn_hist {1e3 * (time.perf_counter() - t0):.0f} ms", flush=True)
 t_first, _ = timed(x, sched)
 t_again, st_a = timed(x, sched)
 x2 = eng.axpby(1.0, x, 0.5, fx)

@@ -15,6 +15,7 @@ for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104", "208"])]:
     eng = iage_engine(Grid2d.default(n, n))
     eng.set_option("frozen_persistent_max_e", 8)
     eng.set_option("frozen_cache_gb", 128.0)
+    eng.set_option("frozen_cache_after", 0)
     eng.set_option("frozen_err_check", 0)     # (the perturbed state below is white noise: not a state the recorded steps control)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())

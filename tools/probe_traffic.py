@@ -20,6 +20,7 @@ x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
 eng.profile_reset(0)
 fx, st, sched = eng.comp_fcn(x, record=True)
 rng = np.random.default_rng(0)
+eng.set_option("frozen_cache_after", 0)      # (a cache of this size is otherwise built for the fourth year of a schedule)
 eng.set_option("frozen_err_check", 0)       # (white-noise perturbations: not states the recorded steps control)
 for _ in range(2):
     xp = eng.upload(eng.download(x) * (1.0 + 1.0e-4 * rng.standard_normal(eng.shape)))

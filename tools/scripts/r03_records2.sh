@@ -2,7 +2,7 @@
 # kernel now), HBM traffic of that kernel (separate --pmc passes)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/rec4; R=$GRAFT_REPO_ROOT/gpurun_out/rec4
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-ladder --no-shard --no-mix --no-shard3 --cpu-baseline-seconds 0 > $R/bench_line_under_rocprof.json 2> $R/rocprof.err; echo "rocprof rc=$?" >> $R/rocprof.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 4 --no-ladder --no-shard --no-mix --no-shard3 --cpu-baseline-seconds 0 > $R/bench_line_under_rocprof.json 2> $R/rocprof.err; echo "rocprof rc=$?" >> $R/rocprof.err
 find /tmp/prof_b -name "*kernel_stats.csv" -exec cp {} $R/kernel_stats.csv \;
 rm -rf /tmp/prof_b
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
