@@ -210,7 +210,7 @@ int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
    between phases -- on a cache of everything its schedule fixes besides the state: mixing planes, Jacobian planes and line
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
    "frozen_cache_gb": at most that much HBM, default 128, and never more than 85 % of what the device has free; 102 GB and 26 ms
-   per schedule at 416 x 416, where the year takes 149 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
+   per schedule at 416 x 416, where the year takes 145 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
    that run launch by launch before its cache is built, default -1 = none for caches up to 8 GB, three above -- the first
    allocation of a 100 GB cache can take a second inside a solver run).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
@@ -377,8 +377,10 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
    grids, see nk2d_get_counter), "frozen_team" (1, default: a four-wave team per column inside that launch, cooperative
-   flavour; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: team columns hand over to
-   their two lateral neighbours instead of meeting at a grid barrier),
+   flavour; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: workgroups hand over to
+   their two lateral neighbours instead of meeting at a grid barrier), "frozen_wpb" (columns per workgroup of the wave-per-column
+   flavour with that hand-over, 1 .. 4, default 2: the waves of a workgroup move in lock step, a neighbour in another
+   workgroup is read over the fabric),
    "hook_spec_depth" (1 or 2, default 2: whole Newton iterations a controller with a vector norm hook queues ahead of a verdict), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
    then the year is rerun launch by launch), "year_fences" (1: release / acquire fences around those barriers, validation),
    "pc_fp32" (1: the preconditioner's Schur inverses stored in single precision -- half the HBM -- and every apply refined

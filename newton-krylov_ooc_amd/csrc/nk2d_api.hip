@@ -150,6 +150,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
     if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
+    if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
     if (key == "frozen_cache_gb") { c->frozen_cache_max_gb = value; return 0; }
     if (key == "barrier_timeout_ms") {
@@ -515,6 +516,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_team = 1;
     c->frozen_nbsync = 1;
     c->frozen_cache_after = -1;
+    c->frozen_wpb = 2;
     c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;

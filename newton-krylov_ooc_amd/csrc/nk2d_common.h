@@ -145,6 +145,7 @@ struct nk2d_ctx {
     int frozen_xcd, frozen_xcd_failed;   // option "frozen_xcd": the year's workgroups on one XCD; set once the placement failed
     int frozen_team;      // option "frozen_team": a four-wave team per column inside the one-launch frozen year (grids of at most two levels per lane)
     int frozen_nbsync;    // option "frozen_nbsync": team columns hand over to their lateral neighbours instead of meeting at a grid barrier
+    int frozen_wpb;       // option "frozen_wpb": columns (waves) per workgroup of the wave-per-column one-launch year with neighbour hand-over
     int frozen_cache_after;   // option "frozen_cache_after": frozen years of a schedule that run launch by launch before its cache is built (-1: 0 up to two levels per lane, 2 beyond)
     uint64_t frozen_seen_key; int frozen_seen_years;   // the schedule last seen by nk2d_frozen_persistent and its years so far
     int64_t frozen_team_years;

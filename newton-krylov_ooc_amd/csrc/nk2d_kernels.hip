@@ -4259,8 +4259,13 @@ static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, 
     if (coop) {
         void* args[2] = {&P, &A};
         if constexpr (!XCD) {
-            if (c->frozen_nbsync)
-                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
+            if (c->frozen_nbsync) {
+                // a wave per column with the neighbour hand-over: option "frozen_wpb" waves (= columns) to a workgroup -- the
+                // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
+                const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
+                const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
+                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), args, 0, c->stream);
+            }
         }
         return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
     }

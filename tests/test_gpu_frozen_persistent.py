@@ -186,6 +186,14 @@ def test_full_size_year_in_one_launch():
     assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert st_p["nlaunch"] < 20 < st_l["nlaunch"] and st_p["seconds"] < 0.9 * st_l["seconds"]
     print(f"416^2 frozen year: {1e3 * st_l['seconds']:.1f} ms launch by launch, {1e3 * st_p['seconds']:.1f} ms in one launch")
+    # four columns to a workgroup instead of one (option "frozen_wpb"), and the grid barrier instead of the hand-over: the same bits
+    for wpb, nbsync in ((4, 1), (1, 0)):
+        eng.set_option("frozen_wpb", wpb)
+        eng.set_option("frozen_nbsync", nbsync)
+        assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), want[1]), (wpb, nbsync)
+    eng.set_option("frozen_wpb", 1)
+    eng.set_option("frozen_nbsync", 1)
+    assert eng.counter("frozen_persistent_years") == 5
     fx2, _, sched2 = eng.comp_fcn(xp, record=True)
     fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
     assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
