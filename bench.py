@@ -52,6 +52,21 @@ YEAR = 365.0 * 86400.0
 WARM_ITERS = 4
 
 
+def warm_until_cached(krylov_once, engines, max_extra=40):
+    """untimed Krylov iterations until the frozen years of `engines` run as ONE launch: the schedule cache of a large grid
+    (above 8 GB) is allocated by a thread of the library's own -- hipMalloc of 120 GB has been seen to take 0.03 to 3 s -- and
+    the years of the meantime run launch by launch.  One-off set-up, like the preconditioner's factorisation: not timed.
+    Returns the iterations it took (0 where the years already are one launch, or never will be)."""
+    extra = 0
+    while any(eng.cache_pending() for eng in engines) and extra < max_extra:
+        krylov_once()
+        extra += 1
+    if extra or any(eng.counter("frozen_persistent_years") == 0 for eng in engines):
+        krylov_once()       # the year that adopts the slab and builds the cache (or: an engine that never takes that way)
+        extra += 1
+    return extra
+
+
 def progress(msg):
     """a line on stderr per leg (a long run shows that it is alive; the JSON line on stdout stays the only stdout output)"""
     rank = os.environ.get("RANK", "0")
@@ -269,6 +284,9 @@ class MixWorkload:
         for tms in self.iterate.tracer_modules:
             tms.eng.sync()
 
+    def engines(self):
+        return [tms.eng for tms in self.iterate.tracer_modules]
+
     def counters(self):
         return {tms.name: {"frozen_years_rejected": tms.eng.frozen_fallbacks(), "frozen_years_resumed": tms.eng.frozen_resumes()}
                 for tms in self.iterate.tracer_modules}
@@ -299,6 +317,8 @@ def run_config4_mix(args, rank, local_rank, world, device):
 
     def timed(wl, tag, group=None, nranks=1):
         wl.krylov(WARM_ITERS, f"{tag}_warm", device, group)
+        if nranks == 1:      # (a collective per iteration for more ranks: everybody warms up the same fixed count)
+            warm_until_cached(lambda: wl.krylov(1, f"{tag}_warm_more", device, group), wl.engines())
         wl.sync()
         if nranks > 1:
             torch.distributed.barrier(group=group)
@@ -569,6 +589,7 @@ def run_ladder(device_ordinal, device, args):
         wl = Workload(n, device_ordinal, f"ladder{n}")
         try:
             wl.krylov(WARM_ITERS, "warm", device)
+            warm_until_cached(lambda: wl.krylov(1, "warm_more", device), [wl.eng])
             wl.eng.profile_reset(1)
             wl.eng._launch_us_base = wl.eng.counter("frozen_launch_us")
             wl.eng._launch_years_base = wl.eng.counter("frozen_persistent_years")
@@ -743,6 +764,7 @@ def main():
         progress("warm-up and timed Krylov iterations")
         if args.warmup > 0:
             wl.krylov(args.warmup, "krylov_warm", device)
+        extra_warm = warm_until_cached(lambda: wl.krylov(1, "krylov_warm_more", device), [eng])
         eng.profile_reset(1)
         eng._launch_us_base = eng.counter("frozen_launch_us")
         eng._launch_years_base = eng.counter("frozen_persistent_years")
@@ -793,6 +815,7 @@ def main():
                     "grid": [n, n],
                     "tracer_modules_per_gpu": 1,
                     "krylov_iterations": args.steps,
+                    "untimed_iterations_until_the_schedule_cache_was_allocated": extra_warm,
                     "parallelism": f"tracer-module-per-gpu x{world}",
                     "collective_backend": backend if world > 1 else None,
                     "integrator_mode": integrator_mode(),

@@ -211,10 +211,12 @@ int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
    "frozen_cache_gb": at most that much HBM, default 128, and never more than 85 % of what the device has free; 102 GB and 26 ms
    per schedule at 416 x 416, where the year takes 145 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
-   that run launch by launch before its cache is built, default -1 = none for caches up to 8 GB, three above -- the first
-   allocation of a 100 GB cache can take a second inside a solver run).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
+   that run launch by launch before its cache is built, default 0; "frozen_alloc_async" 1, default: a cache above 8 GB is
+   allocated by a thread of the library's own -- hipMalloc of 120 GB takes 0.03 to 3 s -- and the years of the meantime run
+   launch by launch).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
    "frozen_xcd_years" (of them: all workgroups on one XCD), "frozen_team_years" (of them: a four-wave team per column),
+   "frozen_launch_us" (device time of those launches), "frozen_cache_pending" (1 while a thread allocates a large cache),
    "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes"; of the host-side controller: "spec_launches_dropped",
    "spec_front_launches_dropped", "err_estimates_queued", "err_estimates_dropped" (work queued ahead of a verdict). */
 int nk2d_get_counter(nk2d_ctx* ctx, const char* name, int64_t* out);

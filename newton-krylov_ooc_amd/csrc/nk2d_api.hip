@@ -151,6 +151,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
     if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
+    if (key == "frozen_alloc_async") { c->frozen_alloc_async = value != 0.0; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
     if (key == "frozen_cache_gb") { c->frozen_cache_max_gb = value; return 0; }
     if (key == "barrier_timeout_ms") {
@@ -515,8 +516,9 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_xcd = 1;
     c->frozen_team = 1;
     c->frozen_nbsync = 1;
-    c->frozen_cache_after = -1;
+    c->frozen_cache_after = 0;
     c->frozen_wpb = 2;
+    c->frozen_alloc_async = 1;
     c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;
@@ -957,6 +959,7 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
     else if (key == "frozen_team_years") v = c->frozen_team_years;
     else if (key == "frozen_launch_us") v = c->frozen_launch_us;
+    else if (key == "frozen_cache_pending") v = nk2d_frozen_cache_pending(c);
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
     else if (key == "frozen_resumes") v = c->frozen_resumes;
     else if (key == "spec_launches_dropped") v = c->cnt_spec_dropped;

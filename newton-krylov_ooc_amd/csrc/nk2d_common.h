@@ -146,6 +146,7 @@ struct nk2d_ctx {
     int frozen_team;      // option "frozen_team": a four-wave team per column inside the one-launch frozen year (grids of at most two levels per lane)
     int frozen_nbsync;    // option "frozen_nbsync": team columns hand over to their lateral neighbours instead of meeting at a grid barrier
     int frozen_wpb;       // option "frozen_wpb": columns (waves) per workgroup of the wave-per-column one-launch year with neighbour hand-over
+    int frozen_alloc_async;   // option "frozen_alloc_async": a schedule cache above 8 GB is allocated by a thread of its own
     int frozen_cache_after;   // option "frozen_cache_after": frozen years of a schedule that run launch by launch before its cache is built (-1: 0 up to two levels per lane, 2 beyond)
     uint64_t frozen_seen_key; int frozen_seen_years;   // the schedule last seen by nk2d_frozen_persistent and its years so far
     int64_t frozen_team_years;
@@ -603,6 +604,7 @@ int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, d
                          int jac_stage = -1);
 double nk2d_fingerprint(const nk2d_ctx* c);
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows = nullptr);
+int nk2d_frozen_cache_pending(const nk2d_ctx* c);
 void nk2d_frozen_cache_free(nk2d_ctx* c);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);

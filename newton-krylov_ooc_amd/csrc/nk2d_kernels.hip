@@ -6,6 +6,11 @@
 // kernels keep the reference's operation order (nk_ooc/py_driver_2d/advection.py:51-76,
 // horiz_mix.py:50-71, vert_mix.py:24-87, iage.py:22-41); fused multiply-adds are
 // written out explicitly only inside the tridiagonal solves.
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include "nk2d_common.h"
 #include "nk2d_hostmath.h"
@@ -4230,6 +4235,14 @@ struct nk2d_frozen_cache {
     FrozenRow* frows_dev = nullptr;    // [n]
     size_t cap_rows = 0;
     std::vector<FrozenRow> frows;
+    // a LARGE slab is allocated by a thread of its own (hipMalloc of 120 GB takes 0.03 - 3 s depending on what the process
+    // holds on the host and the device): the years of the meantime run launch by launch
+    std::thread alloc_thread;
+    std::atomic<int> alloc_state{0};   // 0 nothing under way, 1 under way, 2 done (alloc_* valid), 3 failed
+    double* alloc_slab = nullptr;
+    CacheRow* alloc_rows = nullptr;
+    FrozenRow* alloc_frows = nullptr;
+    size_t alloc_cap = 0;
 };
 
 static uint64_t sched_key(const double* sched, int64_t n) {
@@ -4240,9 +4253,21 @@ static uint64_t sched_key(const double* sched, int64_t n) {
     return h ? h : 1;
 }
 
+// 1 while a thread is allocating the slab of this context's schedule cache
+int nk2d_frozen_cache_pending(const nk2d_ctx* c) {
+    const nk2d_frozen_cache* fc = (const nk2d_frozen_cache*)c->frozen_cache;
+    return (fc && fc->alloc_state.load() == 1) ? 1 : 0;
+}
+
 void nk2d_frozen_cache_free(nk2d_ctx* c) {
     nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
     if (!fc) return;
+    if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
+    if (fc->alloc_state.load() == 2) {
+        if (fc->alloc_slab) (void)hipFree(fc->alloc_slab);
+        if (fc->alloc_rows) (void)hipFree(fc->alloc_rows);
+        if (fc->alloc_frows) (void)hipFree(fc->alloc_frows);
+    }
     if (fc->slab) (void)hipFree(fc->slab);
     if (fc->rows_dev) (void)hipFree(fc->rows_dev);
     if (fc->frows_dev) (void)hipFree(fc->frows_dev);
@@ -4313,6 +4338,19 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     const size_t ntab = (size_t)c->ncol * NK2D_TAB * 64;
     const double bytes = 8.0 * (double)n * (3.0 * c->kv_len + 5.0 * c->np + 3.0 * c->nv + 3.0 * ntab);
     if (bytes > c->frozen_cache_max_gb * 1.0e9) return 1;
+    {   // a slab a thread was asked for: not there yet (launch by launch), there (adopt it), or refused (never again)
+        nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
+        const int st = fc ? fc->alloc_state.load() : 0;
+        if (st == 1) return 1;
+        if (st == 2 || st == 3) {
+            if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
+            fc->alloc_state.store(0);
+            if (st == 3) { c->frozen_persistent = 0; return 1; }
+            fc->slab = fc->alloc_slab; fc->rows_dev = fc->alloc_rows; fc->frows_dev = fc->alloc_frows; fc->cap_rows = fc->alloc_cap;
+            fc->alloc_slab = nullptr; fc->alloc_rows = nullptr; fc->alloc_frows = nullptr;
+            fc->C.KV = nullptr;     // (the tables' places are set below)
+        }
+    }
     {   // ... and never more than what the device has to spare right now (other contexts of the process, other tenants)
         nk2d_frozen_cache* have = (nk2d_frozen_cache*)c->frozen_cache;
         if (!have || have->cap_rows < (size_t)n) {
@@ -4355,7 +4393,36 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
                 const size_t fit = (size_t)(0.9 * (double)free_b / (8.0 * (double)per_row));
                 cap = std::max((size_t)n, std::min(cap, fit));
             }
-            NK2D_CHECK(c, hipMalloc((void**)&fc->slab, sizeof(double) * cap * per_row));
+            const size_t slab_bytes = sizeof(double) * cap * per_row;
+            if (slab_bytes > (size_t)8e9 && c->frozen_alloc_async) {
+                // (the old slab and tables are gone, the new ones come from the thread: launch by launch until they are there)
+                if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
+                fc->alloc_state.store(1);
+                const int dev = c->dev;
+                fc->alloc_thread = std::thread([fc, dev, slab_bytes, cap]() {
+                    bool ok = hipSetDevice(dev) == hipSuccess;
+                    fc->alloc_slab = nullptr; fc->alloc_rows = nullptr; fc->alloc_frows = nullptr;
+                    ok = ok && hipMalloc((void**)&fc->alloc_slab, slab_bytes) == hipSuccess;
+                    ok = ok && hipMalloc((void**)&fc->alloc_rows, sizeof(CacheRow) * cap) == hipSuccess;
+                    ok = ok && hipMalloc((void**)&fc->alloc_frows, sizeof(FrozenRow) * cap) == hipSuccess;
+                    if (!ok) {
+                        (void)hipGetLastError();
+                        if (fc->alloc_slab) (void)hipFree(fc->alloc_slab);
+                        if (fc->alloc_rows) (void)hipFree(fc->alloc_rows);
+                        if (fc->alloc_frows) (void)hipFree(fc->alloc_frows);
+                    }
+                    fc->alloc_cap = cap;
+                    fc->alloc_state.store(ok ? 2 : 3);
+                });
+                return 1;
+            }
+            NK2D_CHECK(c, hipMalloc((void**)&fc->slab, slab_bytes));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->rows_dev, sizeof(CacheRow) * cap));
+            NK2D_CHECK(c, hipMalloc((void**)&fc->frows_dev, sizeof(FrozenRow) * cap));
+            fc->cap_rows = cap;
+        }
+        if (fc->C.KV != fc->slab || fc->C.nv != c->nv) {   // (a new slab: the tables' places in it)
+            const size_t cap = fc->cap_rows;
             double* p = fc->slab;
             fc->C.KV = p; p += cap * 3 * c->kv_len;
             fc->C.J = p; p += cap * 5 * c->np;
@@ -4365,9 +4432,6 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
             fc->C.fr_tab = p; p += cap * ntab;
             fc->C.fc_tabr = p; p += cap * ntab;
             fc->C.fc_tabi = p;
-            NK2D_CHECK(c, hipMalloc((void**)&fc->rows_dev, sizeof(CacheRow) * cap));
-            NK2D_CHECK(c, hipMalloc((void**)&fc->frows_dev, sizeof(FrozenRow) * cap));
-            fc->cap_rows = cap;
         }
         fc->C.kv_len = c->kv_len; fc->C.np = c->np; fc->C.nv = c->nv; fc->C.ntab = ntab;
         const double RCs[3] = {0.15505102572168222, 0.6449489742783178, 1.0};

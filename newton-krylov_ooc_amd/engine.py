@@ -364,6 +364,10 @@ class ModuleEngine:
         self._chk(self._lib.nk2d_get_counter(self._ctx, name.encode(), ctypes.byref(n)))
         return n.value
 
+    def cache_pending(self):
+        """the slab of a large schedule cache is being allocated (by a thread of the library): frozen years run launch by launch meanwhile"""
+        return self.counter("frozen_cache_pending") != 0
+
     def schedule_fingerprint(self):
         """what the steps this engine records now are stamped with (grid, module, tolerances, controller options, build)"""
         out = ctypes.c_double(0.0)

@@ -14,8 +14,8 @@ def _iage(n, ny=None):
 
     eng = iage_engine(Grid2d.default(n, ny or n))
     eng.set_option("device_ctl", 0)
-    eng.set_option("frozen_cache_after", 0)     # (a cache above 8 GB -- 104 x 104 -- is otherwise built for the fourth year of a schedule)
-    return eng
+    eng.set_option("frozen_alloc_async", 0)     # (a cache above 8 GB -- 104 x 104 -- is otherwise allocated by a thread of its own,
+    return eng                                  #  the years of the meantime running launch by launch)
 
 
 def _state(eng, seed=3):
@@ -168,7 +168,6 @@ def test_full_size_year_in_one_launch():
     rebuilds the cache in place"""
     n = 416
     eng = _iage(n)
-    eng.set_option("frozen_cache_after", 0)       # (default for a cache of this size: built for the fourth year of a schedule)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
     x = eng.upload(x0)
@@ -197,8 +196,8 @@ def test_full_size_year_in_one_launch():
     fx2, _, sched2 = eng.comp_fcn(xp, record=True)
     fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
     assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
-    # the default policy for a cache of 100 GB: the first three years of a schedule launch by launch, then the cache
-    eng.set_option("frozen_cache_after", -1)
+    # option "frozen_cache_after": that many years of a schedule launch by launch before its cache is built
+    eng.set_option("frozen_cache_after", 3)
     fx3, _, sched3 = eng.comp_fcn(x, record=True)       # (the first schedule again: its cache was replaced)
     years = eng.counter("frozen_persistent_years")
     for k in range(4):
@@ -206,6 +205,25 @@ def test_full_size_year_in_one_launch():
         assert np.array_equal(eng.download(fx3_p), eng.download(fx3))
         assert eng.counter("frozen_persistent_years") == years + (1 if k == 3 else 0)
     assert eng.counter("frozen_cache_builds") == 3
+    eng.close()
+    # the default for a cache of this size: its 120 GB are allocated by a thread of the library's own (hipMalloc of that size
+    # has been seen to take from 0.03 to 3 s), the years of the meantime run launch by launch -- the same bits either way
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = iage_engine(Grid2d.default(n, n))
+    eng.set_option("device_ctl", 0)
+    x = eng.upload(x0)
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    first = None
+    for k in range(60):
+        fx_k, st_k = eng.comp_fcn_frozen(x, sched)
+        assert np.array_equal(eng.download(fx_k), eng.download(fx))
+        if st_k["nlaunch"] < 20:
+            first = k
+            break
+    assert first is not None and first >= 1 and eng.counter("frozen_cache_builds") == 1
+    print(f"416^2: the cache was there for year {first + 1} of the schedule")
     eng.close()
 
 

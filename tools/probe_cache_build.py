@@ -43,6 +43,13 @@ if "hist" in extra:         # a year with history samples first (the 169 MB host
     t0 = time.perf_counter()
     eng.comp_fcn_hist(x, np.linspace(0.0, 365.0 * 86400.0, 61))
     print(f"comp_fcn_hist {1e3 * (time.perf_counter() - t0):.0f} ms", flush=True)
+if "churn" in extra or "churn_dev" in extra:        # what a solver leaves behind: hundreds of vectors allocated, some kept
+    keep = [eng.upload(np.zeros(eng.shape)) for _ in range(200)]
+    del keep[::2]
+    print("device churn done", len(keep), flush=True)
+if "churn" in extra or "churn_host" in extra:       # ... and host arrays
+    host = [np.ones((61,) + eng.shape) for _ in range(3)]
+    print("host churn done", sum(h.nbytes for h in host) / 1e6, "MB host", flush=True)
 t_first, _ = timed(x, sched)
 t_again, st_a = timed(x, sched)
 x2 = eng.axpby(1.0, x, 0.5, fx)
