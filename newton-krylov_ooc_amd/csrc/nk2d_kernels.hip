@@ -4381,26 +4381,38 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
             // ONE allocation for the whole cache, with room for the longer schedules of later Newton iterates: giving 100 GB
             // back and asking for them again costs seconds (measured inside a Newton run: 4.4 s), the first request 0.03 - 0.8 s
             NK2D_CHECK(c, hipStreamSynchronize(c->stream));
-            if (fc->slab) (void)hipFree(fc->slab);
-            if (fc->rows_dev) (void)hipFree(fc->rows_dev);
-            if (fc->frows_dev) (void)hipFree(fc->frows_dev);
-            fc->slab = nullptr; fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
             const size_t per_row = 3 * c->kv_len + 5 * c->np + 3 * c->nv + 3 * ntab;
+            // (what this cache holds now is given back first -- by the thread, where a thread allocates)
+            double* old_slab = fc->slab;
+            CacheRow* old_rows = fc->rows_dev;
+            FrozenRow* old_frows = fc->frows_dev;
+            const double held_b = 8.0 * (double)fc->cap_rows * (double)per_row;
+            fc->slab = nullptr; fc->rows_dev = nullptr; fc->frows_dev = nullptr; fc->cap_rows = 0;
+            fc->key = 0; fc->n = 0;
             size_t cap = (size_t)n + (size_t)n / 6 + 16;
             {
                 size_t free_b = 0, total_b = 0;
                 NK2D_CHECK(c, hipMemGetInfo(&free_b, &total_b));
-                const size_t fit = (size_t)(0.9 * (double)free_b / (8.0 * (double)per_row));
+                const size_t fit = (size_t)(0.9 * ((double)free_b + held_b) / (8.0 * (double)per_row));
                 cap = std::max((size_t)n, std::min(cap, fit));
             }
             const size_t slab_bytes = sizeof(double) * cap * per_row;
-            if (slab_bytes > (size_t)8e9 && c->frozen_alloc_async) {
-                // (the old slab and tables are gone, the new ones come from the thread: launch by launch until they are there)
+            const bool in_thread = slab_bytes > (size_t)8e9 && c->frozen_alloc_async;
+            if (!in_thread) {
+                if (old_slab) (void)hipFree(old_slab);
+                if (old_rows) (void)hipFree(old_rows);
+                if (old_frows) (void)hipFree(old_frows);
+            }
+            if (in_thread) {
+                // (the new slab and tables come from the thread: launch by launch until they are there)
                 if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
                 fc->alloc_state.store(1);
                 const int dev = c->dev;
-                fc->alloc_thread = std::thread([fc, dev, slab_bytes, cap]() {
+                fc->alloc_thread = std::thread([fc, dev, slab_bytes, cap, old_slab, old_rows, old_frows]() {
                     bool ok = hipSetDevice(dev) == hipSuccess;
+                    if (old_slab) (void)hipFree(old_slab);
+                    if (old_rows) (void)hipFree(old_rows);
+                    if (old_frows) (void)hipFree(old_frows);
                     fc->alloc_slab = nullptr; fc->alloc_rows = nullptr; fc->alloc_frows = nullptr;
                     ok = ok && hipMalloc((void**)&fc->alloc_slab, slab_bytes) == hipSuccess;
                     ok = ok && hipMalloc((void**)&fc->alloc_rows, sizeof(CacheRow) * cap) == hipSuccess;
