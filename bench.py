@@ -52,16 +52,18 @@ YEAR = 365.0 * 86400.0
 WARM_ITERS = 4
 
 
-def warm_until_cached(krylov_once, engines, max_extra=40):
+def warm_until_cached(krylov_once, engines, max_extra=40, agree=None):
     """untimed Krylov iterations until the frozen years of `engines` run as ONE launch: the schedule cache of a large grid
     (above 8 GB) is allocated by a thread of the library's own -- hipMalloc of 120 GB has been seen to take 0.03 to 3 s -- and
     the years of the meantime run launch by launch.  One-off set-up, like the preconditioner's factorisation: not timed.
-    Returns the iterations it took (0 where the years already are one launch, or never will be)."""
+    `agree` (several ranks whose iterations hold a collective): any-of over the ranks, so that all of them run the same count.
+    Returns the iterations it took (0 where the years already are one launch)."""
+    agree = agree or (lambda flag: flag)
     extra = 0
-    while any(eng.cache_pending() for eng in engines) and extra < max_extra:
+    while agree(any(eng.cache_pending() for eng in engines)) and extra < max_extra:
         krylov_once()
         extra += 1
-    if extra or any(eng.counter("frozen_persistent_years") == 0 for eng in engines):
+    if agree(bool(extra) or any(eng.counter("frozen_persistent_years") == 0 for eng in engines)):
         krylov_once()       # the year that adopts the slab and builds the cache (or: an engine that never takes that way)
         extra += 1
     return extra
@@ -764,7 +766,14 @@ def main():
         progress("warm-up and timed Krylov iterations")
         if args.warmup > 0:
             wl.krylov(args.warmup, "krylov_warm", device)
-        extra_warm = warm_until_cached(lambda: wl.krylov(1, "krylov_warm_more", device), [eng])
+        def any_rank(flag):
+            if world == 1:
+                return flag
+            buf = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.MAX)
+            return bool(buf.item())
+
+        extra_warm = warm_until_cached(lambda: wl.krylov(1, "krylov_warm_more", device), [eng], agree=any_rank)
         eng.profile_reset(1)
         eng._launch_us_base = eng.counter("frozen_launch_us")
         eng._launch_years_base = eng.counter("frozen_persistent_years")
