@@ -47,8 +47,8 @@ LADDER_SIZES = (26, 52, 104, 208)
 YEAR = 365.0 * 86400.0
 
 
-# untimed Krylov iterations ahead of the timed ones of the auxiliary legs: the schedule cache of the one-launch frozen year is
-# built for the fourth year of a schedule where it is large (option frozen_cache_after), as in a long Krylov solve
+# untimed Krylov iterations ahead of the timed ones of the auxiliary legs: the slab of a large schedule cache is allocated by
+# a thread of the library while the first frozen years run launch by launch (warm_until_cached waits for it where it can)
 WARM_ITERS = 4
 
 
@@ -698,8 +698,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=4,
-                    help="untimed Krylov iterations (4: the schedule cache of the one-launch frozen year of a large grid is built "
-                         "for the fourth year of a schedule, option frozen_cache_after)")
+                    help="untimed Krylov iterations (then as many more as the allocation of a large grid's schedule cache takes, "
+                         "config.untimed_iterations_until_the_schedule_cache_was_allocated)")
     ap.add_argument("--grid", type=int, default=416, help="depth and ypos levels")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0)
     ap.add_argument("--no-files", action="store_true", help="skip the NetCDF trail (not the default)")
