@@ -4539,7 +4539,9 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     bool ran = false, timed = false;
     // ---- all of the year's workgroups on ONE XCD (option "frozen_xcd"; at most what an XCD's 32 CUs hold at once)
     // (one workgroup per CU is what the kernel's registers admit at two levels per lane: an XCD holds 32 of them at once)
-    if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28 && c->E <= 4) {   // (the XCD flavour exists up to four levels per lane)
+    // (up to two levels per lane: beyond, the cooperative flavour with the neighbour hand-over is the faster one -- 250 x 48: 91.5 ms
+    // on one XCD against 76 ms launch by launch)
+    if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28 && c->E <= 2) {
         // a workgroup that does not get its partners gives up after 20 ms (the year itself takes less than that per phase)
         A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
