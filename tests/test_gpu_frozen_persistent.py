@@ -161,6 +161,29 @@ def test_team_and_wave_per_column_flavours_agree(case):
     eng.close()
 
 
+@pytest.mark.parametrize("nz", [250, 320, 384, 512])
+def test_every_levels_per_lane_instantiation_of_the_one_launch_year(nz):
+    """four, five, six and eight levels per lane (a wave per column, cooperative launch, neighbour hand-over) on a narrow grid:
+    the one-launch year against the launch-per-phase year, recorded and perturbed state, bit for bit -- and faster"""
+    ny = 48
+    eng = _iage(nz, ny)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2).copy()
+    x = eng.upload(x0)
+    xp = eng.upload(x0 * (1.0 + 1.0e-4 * np.outer(np.sin(3.0 * np.linspace(0.0, 1.0, nz)), np.cos(2.0 * np.linspace(0.0, 1.0, ny)))[None]))
+    fx, _, sched = eng.comp_fcn(x, record=True)
+    eng.set_option("frozen_persistent", 0)
+    want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_l = eng.comp_fcn_frozen(xp, sched)
+    eng.set_option("frozen_persistent", 1)
+    got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_p = eng.comp_fcn_frozen(xp, sched)
+    assert eng.counter("frozen_persistent_years") == 3 and eng.counter("frozen_xcd_years") == 0
+    assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert st_p["nerr_checked"] > 0 and st_p["seconds"] < st_l["seconds"]
+    eng.close()
+
+
 def test_full_size_year_in_one_launch():
     """416 x 416 (seven levels per lane, a wave per column, workgroups hand over to their neighbours): the one-launch year on
     the schedule cache -- 2 600 steps' planes and factorisations, 100 GB of the 288 -- against the launch-per-phase year: bit for
