@@ -4302,8 +4302,9 @@ static hipError_t launch_frozen_e(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, Fr
     switch (c->E) {
         case 1: return launch_frozen_one<1, KIND, XCD, TEAM>(c, coop, grid, P, A);
         case 2: return launch_frozen_one<2, KIND, XCD, TEAM>(c, coop, grid, P, A);
-        case 3: if constexpr (!TEAM) return launch_frozen_one<3, KIND, XCD, 0>(c, coop, grid, P, A); else break;
-        case 4: if constexpr (!TEAM) return launch_frozen_one<4, KIND, XCD, 0>(c, coop, grid, P, A); else break;
+        // three and four levels per lane: a wave per column, cooperative flavour (all module kinds)
+        case 3: if constexpr (!TEAM && !XCD) return launch_frozen_one<3, KIND, 0, 0>(c, coop, grid, P, A); else break;
+        case 4: if constexpr (!TEAM && !XCD) return launch_frozen_one<4, KIND, 0, 0>(c, coop, grid, P, A); else break;
         // five to eight levels per lane (up to 512 levels): a wave per column, cooperative flavour, linear sources
         case 5: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<5, 0, 0, 0>(c, coop, grid, P, A); else break;
         case 6: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<6, 0, 0, 0>(c, coop, grid, P, A); else break;
