@@ -84,7 +84,9 @@ class AuxDeadline:
     rehearse over RCCL -- the one-GPU boxes run them over gloo -- and a rank that fails inside one of them leaves the others
     waiting in a collective that RCCL never gives up on: the headline measured before them would be lost with the job.  So
     the legs get a wall-clock budget (--aux-budget), started on all ranks behind a barrier: when it runs out rank 0 prints
-    the line with what it has (the leg that was running named in `aux_legs_timed_out`) and every rank leaves with status 0."""
+    the line with what it has (the leg that was running named in `aux_legs_timed_out`) and every rank leaves with status 3:
+    the headline is on stdout, and the run is still recorded as one that did not finish -- a rank stuck in a collective is a
+    hang to be diagnosed from the per-leg progress lines on stderr, not a success."""
 
     def __init__(self, seconds, rank, out):
         import threading
@@ -100,9 +102,11 @@ class AuxDeadline:
                 line = dict(self.out)
                 line["aux_legs_timed_out"] = {"running": self.leg, "budget_s": self.seconds}
                 print(json.dumps(line), flush=True)
-            progress(f"auxiliary legs over their budget of {self.seconds:.0f} s in {self.leg}: leaving")
+            progress(f"auxiliary legs over their budget of {self.seconds:.0f} s in {self.leg}: leaving with status 3")
+            if self.rank != 0:
+                time.sleep(2.0)     # (the launcher ends every rank when the first one fails: rank 0's line goes out first)
         finally:
-            os._exit(0)
+            os._exit(3)
 
     def cancel(self):
         self._timer.cancel()

@@ -2,6 +2,7 @@
 // conversion, region-weighted state algebra (dot / axpby / lin_comb / MGS) and thin
 // wrappers over the model kernels.
 #include "nk2d_common.h"
+#include "nk2d_build_id.h"
 
 #include <algorithm>
 #include <cmath>
@@ -347,11 +348,15 @@ template <class T>
 static uint64_t fnv_val(uint64_t h, const T& v) { return fnv1a(h, &v, sizeof(T)); }
 
 // everything a recorded schedule depends on besides the state (nk2d_schedule_fingerprint): the grid and module
-// description hashed at create, the tolerances, the controller options and the library version
+// description hashed at create, the tolerances, the controller options that change the discrete map, and the BUILD of the
+// library (NK2D_BUILD_ID: a checksum of its sources, csrc/Makefile -- a schedule from a side file another build wrote is
+// refused, not replayed by kernels that may compute something else).  Options that select between bit-identical flavours of
+// the same launches ("team", "final_fuse", "frozen_persistent", ...: each tested bit for bit against the others) are not part.
 double nk2d_fingerprint(const nk2d_ctx* c) {
     uint64_t h = c->grid_hash;
     const char* ver = nk2d_version();
     h = fnv1a(h, ver, std::strlen(ver));
+    h = fnv1a(h, NK2D_BUILD_ID, std::strlen(NK2D_BUILD_ID));
     h = fnv_val(h, c->d.rtol); h = fnv_val(h, c->d.atol); h = fnv_val(h, c->d.max_step_frac);
     h = fnv_val(h, c->d.t0); h = fnv_val(h, c->d.t1); h = fnv_val(h, c->d.lin_tol);
     h = fnv_val(h, c->jac_fresh); h = fnv_val(h, c->jac_stage); h = fnv_val(h, c->jac_stage_state);

@@ -1211,9 +1211,19 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         }
         if (stepped) {}
         else if (replay) {
+            // what a year books before it is known to stand: counters, algorithmic bytes and launch tallies
+            const nk2d_stats st0 = c->st;
+            const double bytes0 = c->fused_bytes_all;
+            const int64_t launches0 = c->sweep_launches;
             int rrc = run_replay(s, replay, replay_n, replay_own);
             if (rrc == 3) {
-                // the one-launch year of a small grid was given up: the same year from x, launch by launch
+                // the one-launch year of a small grid was given up: the same year from x, launch by launch.  What the
+                // discarded year had booked is taken back (round-3 ADVICE: it was counted twice), the reason stays
+                const int64_t timeouts = c->st.nbarrier_timeouts, resumed = c->st.nresumed;
+                c->st = st0;
+                c->st.nbarrier_timeouts = timeouts; c->st.nresumed = resumed;
+                c->fused_bytes_all = bytes0;
+                c->sweep_launches = launches0;
                 s.no_persistent = true;
                 s.t = c->d.t0;
                 s.have_lu = false; s.have_dense = false; s.pre_setup = false;

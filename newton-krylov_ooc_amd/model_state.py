@@ -643,6 +643,13 @@ class ModelState:
                         dims.setdefault(dimname, dimlen)
                     variables[name] = (tuple(vdims), ">f8", vattrs, vals)
             else:
+                if hist_fname is not None and wanted != ["time"]:
+                    # (round-3 ADVICE) the history is written behind the step log: a process killed in that window resumes
+                    # with later steps logged and no file.  The time axis alone can be restated; history VARIABLES cannot
+                    raise RuntimeError(f"gen_precond_jacobian: history file {hist_fname} is missing although its forward year "
+                                       "is logged as complete (the run ended while the file was being written?): remove "
+                                       f"'{step}' and the comp_fcn step before it from the solver state, or rerun the "
+                                       "Newton iteration (--rewind), so that the year is integrated again")
                 time = np.linspace(self.time_range[0], self.time_range[1], 61)
                 dims["time"] = len(time)
                 variables["time"] = (("time",), ">f8", time_attrs, time)

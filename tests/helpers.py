@@ -35,3 +35,18 @@ def free_years(eng, x, **kw):
         eng.set_option("growth_cap", DEFAULT_GROWTH_CAP)
         eng.set_option("jac_stage", DEFAULT_JAC_STAGE)
     return faithful, eng.comp_fcn(x, **kw)
+
+
+def oracle_year_job(args):
+    """one CPU year of the oracle on one BLAS thread, for worker processes of the parity tests (spawned: they never touch
+    the GPU): args = (nz, ny, x, rows) -- a replay of the accepted steps `rows` from x, or (rows None) a free-running year"""
+    from threadpoolctl import threadpool_limits
+
+    from oracle import radau
+
+    nz, ny, x, rows = args
+    _, tm = oracle_iage(nz, ny)
+    with threadpool_limits(limits=1):
+        if rows is None:
+            return radau.comp_fcn(tm, x)
+        return radau.comp_fcn(tm, x, replay=rows)

@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(args, port, timeout=400):
+def _launch(args, port, timeout=400, expect_ok=True):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NK2D_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    if expect_ok:
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     return res
 
 
@@ -90,9 +91,11 @@ def test_bench_two_ranks():
 
 def test_bench_two_ranks_keeps_its_line_when_the_auxiliary_legs_run_out_of_time():
     """--aux-budget: the legs behind the headline get a wall-clock budget on all ranks; when it runs out (here at once) rank 0
-    prints the line without them and every rank leaves with status 0 -- a leg stuck in a collective cannot cost the record"""
+    prints the line without them -- a leg stuck in a collective cannot cost the record -- and the ranks leave with a NON-ZERO
+    status (round-3 ADVICE): the launcher reports a run that did not finish, the hang is not recorded as a success"""
     res = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "26",
-                   "--cpu-baseline-seconds", "0", "--shard-grid", "12", "--aux-budget", "0.05"], 29543)
+                   "--cpu-baseline-seconds", "0", "--shard-grid", "12", "--aux-budget", "0.05"], 29543, expect_ok=False)
+    assert res.returncode != 0
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
