@@ -14,7 +14,7 @@ namespace {
 template <typename T>
 int dev_alloc(nk2d_ctx* c, T** p, size_t n) {
     NK2D_CHECK(c, hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
-    NK2D_CHECK(c, hipMemsetAsync(*p, 0, sizeof(T) * std::max<size_t>(n, 1), c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(*p, 0, sizeof(T) * std::max<size_t>(n, 1), nk2d_s(c)));
     return 0;
 }
 
@@ -23,7 +23,7 @@ int dev_alloc(nk2d_ctx* c, T** p, size_t n) {
 // the runtime pin the pages on the fly (milliseconds per call), so they go through hSTAGE.
 int ensure_stage(nk2d_ctx* c, size_t n) {
     if (n <= c->stage_elems) return 0;
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     if (c->STAGE) NK2D_CHECK(c, hipFree(c->STAGE));
     if (c->hSTAGE) NK2D_CHECK(c, hipHostFree(c->hSTAGE));
     c->STAGE = c->hSTAGE = nullptr;
@@ -37,16 +37,16 @@ int ensure_stage(nk2d_ctx* c, size_t n) {
 // host (pageable) -> STAGE
 int stage_in(nk2d_ctx* c, const double* host, size_t n) {
     NK2D_TRY(ensure_stage(c, n));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));  // hSTAGE may still feed an earlier copy
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));  // hSTAGE may still feed an earlier copy
     std::memcpy(c->hSTAGE, host, sizeof(double) * n);
-    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, c->hSTAGE, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->STAGE, c->hSTAGE, sizeof(double) * n, hipMemcpyHostToDevice, nk2d_s(c)));
     return 0;
 }
 
 // STAGE -> host (pageable); returns with the copy complete
 int stage_out(nk2d_ctx* c, double* host, size_t n) {
-    NK2D_CHECK(c, hipMemcpyAsync(c->hSTAGE, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->hSTAGE, c->STAGE, sizeof(double) * n, hipMemcpyDeviceToHost, nk2d_s(c)));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     std::memcpy(host, c->hSTAGE, sizeof(double) * n);
     return 0;
 }
@@ -56,7 +56,7 @@ int upload_plane(nk2d_ctx* c, const double* host, int nrows, int ncols, double* 
     const size_t n = (size_t)nrows * ncols;
     NK2D_TRY(stage_in(c, host, n));
     NK2D_TRY(nk2d_k_pack_plane(c, c->STAGE, nrows, ncols, dst, fill));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -114,7 +114,7 @@ extern "C" const char* nk2d_version(void) { return "nk2d 0.1 (gfx950)"; }
 
 extern "C" const char* nk2d_last_error(const nk2d_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)nk2d_s(ctx) : nullptr; }
 
 extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     const std::string key(name ? name : "");
@@ -151,6 +151,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
     if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
+    if (key == "stream_years") { c->stream_years = (int)value; c->stream_lost = 0; return 0; }
     if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
     if (key == "frozen_alloc_async") { c->frozen_alloc_async = value != 0.0; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
@@ -204,7 +205,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
 
 extern "C" int nk2d_sync(nk2d_ctx* c) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -214,7 +215,7 @@ extern "C" int nk2d_sync(nk2d_ctx* c) {
 // ---------------------------------------------------------------------------------
 extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     const size_t want = every_n > 0 ? 2 * 8192 : 0;
     while (c->prof_ev.size() < want) {
         hipEvent_t e;
@@ -226,10 +227,10 @@ extern "C" int nk2d_profile_reset(nk2d_ctx* c, int32_t every_n) {
     if (every_n > 0) {
         const int ncal = 64;
         for (int i = 0; i < ncal; ++i) {
-            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i], c->stream));
-            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i + 1], c->stream));
+            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i], nk2d_s(c)));
+            NK2D_CHECK(c, hipEventRecord(c->prof_ev[2 * i + 1], nk2d_s(c)));
         }
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         double sum = 0.0;
         for (int i = 0; i < ncal; ++i) {
             float ms = 0.f;
@@ -274,14 +275,14 @@ extern "C" int nk2d_timer_begin(nk2d_ctx* c) {
         NK2D_CHECK(c, hipEventCreate(&c->timer_ev[1]));
         c->timer_ready = 1;
     }
-    NK2D_CHECK(c, hipEventRecord(c->timer_ev[0], c->stream));
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[0], nk2d_s(c)));
     return 0;
 }
 
 extern "C" int nk2d_timer_end(nk2d_ctx* c, double* elapsed_ms) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     if (!c->timer_ready) return nk2d_fail(c, "nk2d_timer_end: nk2d_timer_begin was not called");
-    NK2D_CHECK(c, hipEventRecord(c->timer_ev[1], c->stream));
+    NK2D_CHECK(c, hipEventRecord(c->timer_ev[1], nk2d_s(c)));
     NK2D_CHECK(c, hipEventSynchronize(c->timer_ev[1]));
     float ms = 0.f;
     NK2D_CHECK(c, hipEventElapsedTime(&ms, c->timer_ev[0], c->timer_ev[1]));
@@ -325,7 +326,7 @@ extern "C" int nk2d_set_norm_hook_vec(nk2d_ctx* c, nk2d_norm_hook_vec_fn fn, voi
 extern "C" int nk2d_profile_read(nk2d_ctx* c, double* avg_us, int64_t* samples, int64_t* launches, double* bytes,
                                  double* overhead_us, int64_t* windows) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     NK2D_TRY(nk2d_profile_collect(c));
     // per launch: (sum of window times - one empty-pair reading per window) / launches in the windows
     const double net_ms = c->prof_ms_sum - (double)c->prof_windows * c->prof_overhead_ms;
@@ -403,7 +404,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->nreg = 0;
     c->dev = desc->device_id;
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    NK2D_CHECK(c, hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking));
     const int nz = c->nz, ny = c->ny;
     {
         uint64_t h = 14695981039346656037ull;
@@ -522,6 +523,11 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_team = 1;
     c->frozen_nbsync = 1;
     c->frozen_cache_after = 0;
+    c->strm = nullptr;
+    c->stream_years = 0;
+    c->stream_on = 0;
+    c->stream_lost = 0;
+    c->stream_cmds = c->stream_launches = c->stream_timeouts = c->stream_years_run = 0;
     c->frozen_wpb = 2;
     c->frozen_alloc_async = 1;
     c->frozen_xcd_failed = 0;
@@ -625,7 +631,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     if (!desc || !out) return -2;
     nk2d_ctx* c = new (std::nothrow) nk2d_ctx();
     if (!c) return -2;
-    c->stream = nullptr;
+    c->stream_ = nullptr;
     c->STAGE = nullptr;
     c->hSTAGE = nullptr;
     c->stage_elems = 0;
@@ -663,7 +669,8 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
 extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    nk2d_stream_free(c);
+    if (c->stream_) (void)hipStreamSynchronize(c->stream_);
     nk2d_precond_free(c);
     nk2d_frozen_cache_free(c);
     double* bufs[] = {c->VV, c->KH, c->WT, c->WB, c->DZR, c->ZM0, c->ZM1, c->DM, c->DMR, c->DYR, c->BLDMAX, c->WN,
@@ -706,7 +713,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     }
     if (c->DCTL) (void)hipFree(c->DCTL);
     if (c->ICTL) (void)hipFree(c->ICTL);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_) (void)hipStreamDestroy(c->stream_);
     delete c;
 }
 
@@ -739,10 +746,10 @@ extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* w
     }
     NK2D_TRY(upload_plane(c, wn.data(), c->nz, c->ny, c->WN));
     NK2D_TRY(upload_plane(c, mk.data(), c->nz, c->ny, c->TMP));  // TMP has at least np elements
-    hipLaunchKernelGGL(k_to_int, dim3((unsigned)((c->np + 255) / 256)), dim3(256), 0, c->stream, c->TMP, c->MASK, c->np);
+    hipLaunchKernelGGL(k_to_int, dim3((unsigned)((c->np + 255) / 256)), dim3(256), 0, nk2d_s(c), c->TMP, c->MASK, c->np);
     NK2D_CHECK(c, hipGetLastError());
     if (nreg != c->nreg) {
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         NK2D_CHECK(c, hipFree(c->PART));
         c->PART = nullptr;
         NK2D_TRY(dev_alloc(c, &c->PART, (size_t)c->ncol * nreg));
@@ -755,7 +762,7 @@ extern "C" int nk2d_set_region(nk2d_ctx* c, const int32_t* mask, const double* w
         if ((size_t)nreg * 2 > 4096) return nk2d_fail(c, "nk2d_set_region: too many regions");
     }
     c->nreg = nreg;
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -778,7 +785,7 @@ extern "C" int nk2d_vec_alloc(nk2d_ctx* c, nk2d_vec* out) {
         }
     }
     if (p) {
-        NK2D_CHECK(c, hipMemsetAsync(p, 0, sizeof(double) * c->nv, c->stream));
+        NK2D_CHECK(c, hipMemsetAsync(p, 0, sizeof(double) * c->nv, nk2d_s(c)));
     } else {
         NK2D_TRY(dev_alloc(c, &p, c->nv));
     }
@@ -797,7 +804,7 @@ extern "C" int nk2d_vec_free(nk2d_ctx* c, nk2d_vec v) {
             return 0;
         }
     }
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     NK2D_CHECK(c, hipFree(v));
     return 0;
 }
@@ -806,7 +813,7 @@ extern "C" int nk2d_vec_upload(nk2d_ctx* c, nk2d_vec v, const double* host) {
     const size_t n = (size_t)c->tc * c->nz * c->ny;
     NK2D_TRY(stage_in(c, host, n));
     NK2D_TRY(nk2d_k_pack_state(c, c->STAGE, (double*)v));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 extern "C" int nk2d_vec_download(nk2d_ctx* c, nk2d_vec v, double* host) {
@@ -818,12 +825,12 @@ extern "C" int nk2d_vec_download(nk2d_ctx* c, nk2d_vec v, double* host) {
 }
 extern "C" int nk2d_vec_copy(nk2d_ctx* c, nk2d_vec dst, nk2d_vec src) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipMemcpyAsync(dst, src, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(dst, src, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
     return 0;
 }
 extern "C" int nk2d_vec_zero(nk2d_ctx* c, nk2d_vec v) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_CHECK(c, hipMemsetAsync(v, 0, sizeof(double) * c->nv, c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(v, 0, sizeof(double) * c->nv, nk2d_s(c)));
     return 0;
 }
 
@@ -854,7 +861,7 @@ static const double* lin_state(nk2d_ctx* c) { return (c->kind != 0 && c->ylin_se
 extern "C" int nk2d_set_lin_state(nk2d_ctx* c, nk2d_vec y) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     if (!c->YLIN) NK2D_TRY(dev_alloc(c, &c->YLIN, c->nv));
-    NK2D_CHECK(c, hipMemcpyAsync(c->YLIN, y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->YLIN, y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
     c->ylin_set = 1;
     return 0;
 }
@@ -919,12 +926,12 @@ extern "C" int nk2d_shifted_solve(nk2d_ctx* c, double t_jac, double h, double mu
         src = 1 - src;
     }
     if (!cplxsys) {
-        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
     } else {
-        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XCR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
-        NK2D_CHECK(c, hipMemcpyAsync(x_im, c->XCI[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(x_re, c->XCR[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+        NK2D_CHECK(c, hipMemcpyAsync(x_im, c->XCI[src], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
     }
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     if (sweeps_out) *sweeps_out = m;
     return 0;
 }
@@ -963,6 +970,10 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     else if (key == "frozen_cache_builds") v = c->frozen_cache_builds;
     else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
     else if (key == "frozen_team_years") v = c->frozen_team_years;
+    else if (key == "stream_years_run") v = c->stream_years_run;
+    else if (key == "stream_commands") v = c->stream_cmds;
+    else if (key == "stream_launches") v = c->stream_launches;
+    else if (key == "stream_timeouts") v = c->stream_timeouts;
     else if (key == "frozen_launch_us") v = c->frozen_launch_us;
     else if (key == "frozen_cache_pending") v = nk2d_frozen_cache_pending(c);
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
@@ -1175,12 +1186,12 @@ __global__ void k_mask(int ncol, int ny, double* __restrict__ v, const int32_t* 
 static int stage_coef(nk2d_ctx* c, const void* host, size_t n, size_t offset) {
     if (offset + n > c->rcoef_elems) return nk2d_fail(c, "region coefficient staging overflow");
     std::memcpy(c->hRCOEF + offset, host, sizeof(double) * n);
-    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + offset, c->hRCOEF + offset, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(c->RCOEF + offset, c->hRCOEF + offset, sizeof(double) * n, hipMemcpyHostToDevice, nk2d_s(c)));
     return 0;
 }
 
 static int launch_dot(nk2d_ctx* c, const double* a, const double* b) {
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_dot<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_dot<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->ncol,
                                                c->ny, c->nreg, a, b, c->WN, c->MASK, c->PART));
     NK2D_CHECK(c, hipGetLastError());
     return 0;
@@ -1196,11 +1207,11 @@ extern "C" int nk2d_axpby(nk2d_ctx* c, nk2d_vec out, const double* a, nk2d_vec x
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_TRY(stage_coef(c, a, c->nreg, 0));
     NK2D_TRY(stage_coef(c, b, c->nreg, c->nreg));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_axpby<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_axpby<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->ncol,
                                                c->ny, c->RCOEF, (const double*)x, c->RCOEF + c->nreg, (const double*)y,
                                                c->MASK, (double*)out));
     NK2D_CHECK(c, hipGetLastError());
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));  // RCOEF is reused by the next call
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));  // RCOEF is reused by the next call
     return 0;
 }
 
@@ -1211,11 +1222,11 @@ extern "C" int nk2d_scale(nk2d_ctx* c, nk2d_vec out, nk2d_vec x, const double* s
 extern "C" int nk2d_diff_scale(nk2d_ctx* c, nk2d_vec out, nk2d_vec x, nk2d_vec y, const double* s) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
     NK2D_TRY(stage_coef(c, s, c->nreg, 0));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_diff_scale<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_diff_scale<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                                c->ncol, c->ny, (const double*)x, (const double*)y, c->RCOEF, c->MASK,
                                                (double*)out));
     NK2D_CHECK(c, hipGetLastError());
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -1227,11 +1238,11 @@ extern "C" int nk2d_lin_comb(nk2d_ctx* c, nk2d_vec out, int32_t n, const nk2d_ve
     if (ncoef + (size_t)n > c->rcoef_elems) return nk2d_fail(c, "nk2d_lin_comb: too many vectors");
     NK2D_TRY(stage_coef(c, coef, ncoef, 0));
     NK2D_TRY(stage_coef(c, vecs, (size_t)n, ncoef));  // pointers are 8-byte slots like the coefficients
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_lin_comb<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_lin_comb<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                                c->ncol, c->ny, n, c->nreg, (const double* const*)(c->RCOEF + ncoef),
                                                c->RCOEF, c->MASK, (double*)out));
     NK2D_CHECK(c, hipGetLastError());
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -1244,15 +1255,15 @@ extern "C" int nk2d_mgs(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec* basi
         // reduce into RED[(i+1)*nreg ...]; slot 0 is scratch of nk2d_k_reduce
         NK2D_TRY(nk2d_k_reduce(c, c->ncol, c->nreg, nullptr));
         NK2D_CHECK(c, hipMemcpyAsync(c->RED + (size_t)(i + 1) * c->nreg, c->RED, sizeof(double) * c->nreg,
-                                     hipMemcpyDeviceToDevice, c->stream));
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mgs_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+                                     hipMemcpyDeviceToDevice, nk2d_s(c)));
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mgs_update<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                                    c->ncol, c->ny, (double*)w, (const double*)basis[i],
                                                    c->RED + (size_t)(i + 1) * c->nreg, c->MASK));
         NK2D_CHECK(c, hipGetLastError());
     }
     if (n > 0) {
-        NK2D_CHECK(c, hipMemcpyAsync(c->hRED, c->RED + c->nreg, sizeof(double) * n * c->nreg, hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(c->hRED, c->RED + c->nreg, sizeof(double) * n * c->nreg, hipMemcpyDeviceToHost, nk2d_s(c)));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         std::memcpy(h_out, c->hRED, sizeof(double) * n * c->nreg);
     }
     return 0;
@@ -1260,7 +1271,7 @@ extern "C" int nk2d_mgs(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec* basi
 
 extern "C" int nk2d_apply_region_mask(nk2d_ctx* c, nk2d_vec v) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mask<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_mask<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->ncol,
                                                c->ny, (double*)v, c->MASK));
     NK2D_CHECK(c, hipGetLastError());
     return 0;

@@ -44,8 +44,15 @@ struct nk2d_ctx {
     size_t nv;  // doubles per state vector  (tc*ny*nzp)
     size_t np;  // doubles per (depth, ypos) plane (ny*nzp)
     int dev;
-    hipStream_t stream;
+    hipStream_t stream_;   // the context's stream: through nk2d_s(c), which first ends a running command-stream kernel
     std::string err;
+    // the year as a command stream (nk2d_stream.hip): ONE resident kernel executes the launches of the host-controlled year
+    // as commands, workgroups handing over to their lateral neighbours instead of meeting at launch boundaries
+    struct nk2d_stream_state* strm;
+    int stream_years;      // option "stream_years": 1 = forward years of eligible contexts run as command streams
+    int stream_on;         // set by the integrator for the span of a year that may run as a command stream
+    int stream_lost;       // years in a row whose kernel gave up (two: the context stops trying)
+    int64_t stream_cmds, stream_launches, stream_timeouts, stream_years_run;   // counters (nk2d_get_counter)
 
     // static, packed planes (device)
     double* VV;      // vvel at ypos faces, (ny+1) columns
@@ -258,6 +265,23 @@ struct nk2d_ctx {
         int rc_ = (expr);         \
         if (rc_ != 0) return rc_; \
     } while (0)
+
+// nk2d_stream.hip (the year as a command stream, nk2d_stream.h)
+#define NK2D_RC_STREAM_LOST 17   /* the command-stream kernel gave up (a wait timed out): the caller reruns the year by launches */
+int nk2d_stream_pause(nk2d_ctx* c);
+bool nk2d_stream_running(const nk2d_ctx* c);
+int nk2d_stream_eligible(const nk2d_ctx* c);
+int nk2d_stream_end(nk2d_ctx* c);       // ends the kernel, waits for it; NK2D_RC_STREAM_LOST if it had given up on the way
+void nk2d_stream_free(nk2d_ctx* c);
+void nk2d_stream_poison(double* part, int n);
+int nk2d_stream_wait_part(nk2d_ctx* c, const double* part, int n);
+// the stream every launch, copy and synchronisation of a context goes to: whatever is queued there must come AFTER the
+// commands pushed so far, so a resident command-stream kernel is told to finish first (the caller's launch is then ordered
+// behind it by the stream; nothing is waited for here)
+static inline hipStream_t nk2d_s(nk2d_ctx* c) {
+    if (c->strm && nk2d_stream_running(c)) (void)nk2d_stream_pause(c);
+    return c->stream_;
+}
 
 static inline int nk2d_fail(nk2d_ctx* c, const std::string& msg, int code = -2) {
     c->err = msg;

@@ -302,12 +302,12 @@ static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, 
                 // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
                 const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
                 const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
-                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), args, 0, c->stream);
+                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), args, 0, nk2d_s(c));
             }
         }
-        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), args, 0, c->stream);
+        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), args, 0, nk2d_s(c));
     }
-    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM, 0>), grid, dim3(NK2D_BLOCK), 0, c->stream, P, A);
+    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A);
     return hipGetLastError();
 }
 template <int KIND, int XCD, int TEAM>
@@ -397,7 +397,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         if (fc->cap_rows < (size_t)n) {
             // ONE allocation for the whole cache, with room for the longer schedules of later Newton iterates: giving 100 GB
             // back and asking for them again costs seconds (measured inside a Newton run: 4.4 s), the first request 0.03 - 0.8 s
-            NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+            NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
             const size_t per_row = 3 * c->kv_len + 5 * c->np + 3 * c->nv + 3 * ntab;
             // (what this cache holds now is given back first -- by the thread, where a thread allocates)
             double* old_slab = fc->slab;
@@ -498,17 +498,17 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
                 F.x2 = ((t_new + h2 * RCs[2]) - t) / (t_new - t);
             }
         }
-        NK2D_CHECK(c, hipMemcpyAsync(fc->rows_dev, rows.data(), sizeof(CacheRow) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        NK2D_CHECK(c, hipMemcpyAsync(fc->frows_dev, fc->frows.data(), sizeof(FrozenRow) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));    // `rows` leaves scope
+        NK2D_CHECK(c, hipMemcpyAsync(fc->rows_dev, rows.data(), sizeof(CacheRow) * (size_t)n, hipMemcpyHostToDevice, nk2d_s(c)));
+        NK2D_CHECK(c, hipMemcpyAsync(fc->frows_dev, fc->frows.data(), sizeof(FrozenRow) * (size_t)n, hipMemcpyHostToDevice, nk2d_s(c)));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));    // `rows` leaves scope
         {
             const long long tasks = 4LL * c->ny * n;
-            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_cache_planes<EE>, dim3((unsigned)((tasks + 3) / 4)), dim3(NK2D_BLOCK), 0, c->stream,
+            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_cache_planes<EE>, dim3((unsigned)((tasks + 3) / 4)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                                       P, fc->rows_dev, fc->C, (int)n));
             NK2D_CHECK(c, hipGetLastError());
             const long long ftasks = 2LL * c->ncol * n;
             NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_cache_factor<EE, KK>), dim3((unsigned)((ftasks + 3) / 4)), dim3(NK2D_BLOCK), 0,
-                                                               c->stream, P, fc->rows_dev, fc->C, (int)n));
+                                                               nk2d_s(c), P, fc->rows_dev, fc->C, (int)n));
             NK2D_CHECK(c, hipGetLastError());
             c->st.nlaunch += 2;
         }
@@ -529,7 +529,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         c->yr_rec_cap = 0;
         c->YR_REC = nullptr;
     }
-    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), nk2d_s(c)));
     FrozenArgs A = {};
     A.Y = c->Y; A.YOLD = c->YOLD; A.Z = c->Z; A.ZN = c->ZN; A.W = c->W; A.F = c->F;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
@@ -561,14 +561,14 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28 && c->E <= 2) {
         // a workgroup that does not get its partners gives up after 20 ms (the year itself takes less than that per phase)
         A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
-        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
+        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
         const dim3 grid(8 * nblk + 64);
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
         NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
         NK2D_CHECK(c, hipGetLastError());
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
-        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));
+        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, nk2d_s(c)));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         ran = (int)o[0] == 0 && (int64_t)o[1] == n;
         timed = true;
         if (!ran) {
@@ -582,18 +582,18 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     if (!ran) {
         A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
         hipError_t rc = hipErrorInvalidValue;
-        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, c->stream));
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
+        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
         {
             std::lock_guard<std::mutex> coop(coop_launch_mutex());
             rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
         }
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
+        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));
         timed = true;
-        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, nk2d_s(c)));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         if ((int)o[0] != 0 || (int64_t)o[1] != n) return 2;
     }
     if (team) c->frozen_team_years++;

@@ -130,7 +130,7 @@ int stage_ptrs(nk2d_ctx* c, Scratch& s, int n, const nk2d_vec* vecs, const doubl
     const size_t nco = (size_t)n * c->nreg;
     if (h) std::memcpy(s.hcoef, h, sizeof(double) * nco);
     std::memcpy(s.hcoef + nco, vecs, sizeof(double) * n);
-    NK2D_CHECK(c, hipMemcpyAsync(s.coef, s.hcoef, sizeof(double) * (nco + n), hipMemcpyHostToDevice, c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(s.coef, s.hcoef, sizeof(double) * (nco + n), hipMemcpyHostToDevice, nk2d_s(c)));
     return 0;
 }
 
@@ -164,13 +164,13 @@ extern "C" int nk2d_multi_dot(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_vec
     NK2D_TRY(scratch_alloc(c, s, n));
     NK2D_TRY(stage_ptrs(c, s, n, basis, nullptr));
     const size_t nco = (size_t)n * c->nreg;
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_multi_dot<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_multi_dot<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nreg, n, (const double*)w,
                                               (const double* const*)(s.coef + nco), c->WN, c->MASK, s.part));
-    hipLaunchKernelGGL(k_reduce_cols, dim3((unsigned)nco), dim3(NK2D_BLOCK), 0, c->stream, s.part, c->ncol, (int)nco, s.red);
+    hipLaunchKernelGGL(k_reduce_cols, dim3((unsigned)nco), dim3(NK2D_BLOCK), 0, nk2d_s(c), s.part, c->ncol, (int)nco, s.red);
     NK2D_CHECK(c, hipGetLastError());
-    NK2D_CHECK(c, hipMemcpyAsync(s.hred, s.red, sizeof(double) * nco, hipMemcpyDeviceToHost, c->stream));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipMemcpyAsync(s.hred, s.red, sizeof(double) * nco, hipMemcpyDeviceToHost, nk2d_s(c)));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     std::memcpy(out, s.hred, sizeof(double) * nco);
     return 0;
 }
@@ -182,11 +182,11 @@ extern "C" int nk2d_multi_axpy(nk2d_ctx* c, nk2d_vec w, int32_t n, const nk2d_ve
     NK2D_TRY(scratch_alloc(c, s, n));
     NK2D_TRY(stage_ptrs(c, s, n, basis, h));
     const size_t nco = (size_t)n * c->nreg;
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_multi_axpy<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_multi_axpy<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nreg, n, (double*)w,
                                               (const double* const*)(s.coef + nco), s.coef, c->MASK, fill));
     NK2D_CHECK(c, hipGetLastError());
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -320,6 +320,6 @@ extern "C" int nk2d_gmres_solve(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, double rel
         NK2D_TRY(nk2d_scale(c, w, w, rh.data()));
         V.push_back(w);
     }
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }

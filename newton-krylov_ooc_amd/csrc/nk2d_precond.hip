@@ -715,31 +715,31 @@ int precond_eliminate(nk2d_ctx* c) {
         // the Schur inverse of the column before: inside SINV ([nsys][nb][m][m]), or -- single precision storage -- the
         // double precision copy kept of that one column ([nsys][m][m])
         const double* prev = (j > 0) ? (pc->fp32 ? pc->PREV : pc->SINV + (size_t)(j - 1) * mm) : nullptr;
-        hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, c->stream, D, j, prev, pc->fp32 ? mm : (size_t)pc->nb * mm, pc->BUF);
+        hipLaunchKernelGGL(k_pc_schur, grd, blk, 0, nk2d_s(c), D, j, prev, pc->fp32 ? mm : (size_t)pc->nb * mm, pc->BUF);
         int src = 0;
         for (int p0 = 0; p0 < m; p0 += PC_NB) {
             const int nbk = std::min(PC_NB, m - p0);
             const double* from = pc->BUF + (size_t)src * nsys * mm;
             double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
-            hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, c->stream, m, p0, nbk, from,
+            hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, nk2d_s(c), m, p0, nbk, from,
                                pc->ROWS);
             if (c->pc_valu)
-                hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream, m, p0,
+                hipLaunchKernelGGL(k_pc_gj_update, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, nk2d_s(c), m, p0,
                                    nbk, from, pc->ROWS, to);
             else
-                hipLaunchKernelGGL(k_pc_gj_update_mfma, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(k_pc_gj_update_mfma, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, nk2d_s(c),
                                    m, p0, nbk, from, pc->ROWS, to);
             src = 1 - src;
         }
         for (int sys = 0; sys < nsys; ++sys) {
             const double* inv = pc->BUF + ((size_t)src * nsys + sys) * mm;
             if (pc->fp32) {
-                hipLaunchKernelGGL(k_pc_to_f32, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, c->stream, inv,
+                hipLaunchKernelGGL(k_pc_to_f32, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, nk2d_s(c), inv,
                                    pc->SINV32 + ((size_t)sys * pc->nb + j) * mm, mm);
-                NK2D_CHECK(c, hipMemcpyAsync(pc->PREV + (size_t)sys * mm, inv, sizeof(double) * mm, hipMemcpyDeviceToDevice, c->stream));
+                NK2D_CHECK(c, hipMemcpyAsync(pc->PREV + (size_t)sys * mm, inv, sizeof(double) * mm, hipMemcpyDeviceToDevice, nk2d_s(c)));
             } else {
                 NK2D_CHECK(c, hipMemcpyAsync(pc->SINV + ((size_t)sys * pc->nb + j) * mm, inv, sizeof(double) * mm,
-                                             hipMemcpyDeviceToDevice, c->stream));
+                                             hipMemcpyDeviceToDevice, nk2d_s(c)));
             }
         }
         NK2D_CHECK(c, hipGetLastError());
@@ -748,9 +748,9 @@ int precond_eliminate(nk2d_ctx* c) {
         // profiler's dispatch interceptor (SIGSEGV in librocprofiler-sdk.so reached from this loop's
         // hipLaunchKernel, with or without torch in the process: gpurun_out/r02_pc_fetch.log resolved against
         // the probe's /proc/self/maps).  The GPU is never idle for it: a column is 1.3 ms of work.
-        if ((j & 3) == 3) NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        if ((j & 3) == 3) NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     }
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     return 0;
 }
 
@@ -773,33 +773,33 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     // y_0 = r_0
     for (int sys = 0; sys < nsys; ++sys)
         NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
-                                     hipMemcpyDeviceToDevice, c->stream));
+                                     hipMemcpyDeviceToDevice, nk2d_s(c)));
     for (int j = 1; j < nb; ++j) {
         if (pc->fp32)
-            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, c->stream, D, 0, j, sinv32 + (size_t)(j - 1) * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, nk2d_s(c), D, 0, j, sinv32 + (size_t)(j - 1) * mm, mstride,
                                yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
                                (double*)nullptr);
         else if (wide)
-            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, nk2d_s(c), D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
                                yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
                                (double*)nullptr);
         else
-            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, nk2d_s(c), D, 0, j, sinv + (size_t)(j - 1) * mm, mstride,
                                yv + (size_t)(j - 1) * m, xv + (size_t)j * m, vstride, yv + (size_t)j * m,
                                (double*)nullptr);
     }
     // backward: x_j = Sinv_j (y_j - U_j x_{j+1}); each launch leaves y_{j-1} - U_{j-1} x_j behind for the next
     for (int j = nb - 1; j >= 0; --j) {
         if (pc->fp32)
-            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, c->stream, D, 1, j, sinv32 + (size_t)j * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv32, grd, blk, 0, nk2d_s(c), D, 1, j, sinv32 + (size_t)j * mm, mstride,
                                yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
                                (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
         else if (wide)
-            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv2, grd, blk, 0, nk2d_s(c), D, 1, j, sinv + (size_t)j * mm, mstride,
                                yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
                                (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
         else
-            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, c->stream, D, 1, j, sinv + (size_t)j * mm, mstride,
+            hipLaunchKernelGGL(k_pc_gemv, grd, blk, 0, nk2d_s(c), D, 1, j, sinv + (size_t)j * mm, mstride,
                                yv + (size_t)j * m, (const double*)nullptr, vstride, xv + (size_t)j * m,
                                (j > 0) ? yv + (size_t)(j - 1) * m : (double*)nullptr);
     }
@@ -859,10 +859,10 @@ extern "C" int nk2d_shift_solve(nk2d_ctx* c, int32_t i, nk2d_vec v, nk2d_vec out
     if (!pc || pc->mode != 1) return nk2d_fail(c, "nk2d_shift_solve: call nk2d_shift_factor first");
     if (i < 0 || i >= pc->nsys) return nk2d_fail(c, "nk2d_shift_solve: no such system");
     const size_t vstride = (size_t)pc->nb * pc->m;
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nz, pc->m, (const double*)v, pc->XV + (size_t)i * vstride));
     NK2D_TRY(precond_substitute(c, i, 1));
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nz, pc->m, pc->XV + (size_t)i * vstride, (double*)out));
     NK2D_CHECK(c, hipGetLastError());
     return 0;
@@ -874,26 +874,26 @@ extern "C" int nk2d_precond_apply(nk2d_ctx* c, nk2d_vec v, nk2d_vec out) {
     if (!pc || pc->mode != 0) return nk2d_fail(c, "nk2d_precond_apply: call nk2d_precond_setup first");
     const int m = pc->m;
     // right-hand sides into XV (used as r_j), forward sweep writes YV
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream, c->ncol,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->ncol,
                                               c->ny, c->nz, m, (const double*)v, pc->XV));
     if (pc->fp32) {
         // single precision inverses: x0 = S32^-1 rhs, then "pc_refine" corrections x += S32^-1 (rhs - A x) against the exact
         // operator -- each multiplies the error by that of the single precision inverses
         const size_t nvec = (size_t)pc->nsys * pc->nb * m;
         PcDev D = make_pcdev(c, pc);
-        NK2D_CHECK(c, hipMemcpyAsync(pc->RV, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, c->stream));
+        NK2D_CHECK(c, hipMemcpyAsync(pc->RV, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, nk2d_s(c)));
         NK2D_TRY(precond_substitute(c, 0, pc->nsys));
         for (int it = 0; it < c->pc_refine; ++it) {
-            NK2D_CHECK(c, hipMemcpyAsync(pc->X0, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(k_pc_residual, dim3((m + 255) / 256, pc->nb, pc->nsys), dim3(256), 0, c->stream, D, pc->RV,
+            NK2D_CHECK(c, hipMemcpyAsync(pc->X0, pc->XV, sizeof(double) * nvec, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            hipLaunchKernelGGL(k_pc_residual, dim3((m + 255) / 256, pc->nb, pc->nsys), dim3(256), 0, nk2d_s(c), D, pc->RV,
                                pc->X0, pc->XV);
             NK2D_TRY(precond_substitute(c, 0, pc->nsys));
-            hipLaunchKernelGGL(k_pc_add, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, c->stream, pc->XV, pc->X0, nvec);
+            hipLaunchKernelGGL(k_pc_add, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, nk2d_s(c), pc->XV, pc->X0, nvec);
         }
     } else {
         NK2D_TRY(precond_substitute(c, 0, pc->nsys));
     }
-    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, c->stream,
+    NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nz, m, (const double*)v, pc->XV, (double*)out));
     NK2D_CHECK(c, hipGetLastError());
     return 0;

@@ -128,8 +128,8 @@ int solve_systems(Ctl& s, bool do_real, bool do_cplx, int* buf) {
 int predict(Ctl& s, double t, double h) {
     nk2d_ctx* c = s.c;
     if (!s.have_dense) {
-        NK2D_CHECK(c, hipMemsetAsync(c->Z, 0, sizeof(double) * 3 * c->nv, c->stream));
-        NK2D_CHECK(c, hipMemsetAsync(c->W, 0, sizeof(double) * 3 * c->nv, c->stream));
+        NK2D_CHECK(c, hipMemsetAsync(c->Z, 0, sizeof(double) * 3 * c->nv, nk2d_s(c)));
+        NK2D_CHECK(c, hipMemsetAsync(c->W, 0, sizeof(double) * 3 * c->nv, nk2d_s(c)));
         return 0;
     }
     double x[3];
@@ -205,6 +205,20 @@ int newton_back(Ctl& s, double mreal, double mcr, double mci) {
     return 0;
 }
 
+// "the launch that carries these partials is queued" / "wait for it".  By launches: an event on the context's stream.
+// As a command stream (nk2d_stream.h): nothing to record -- the partials were marked before their command went out and say
+// themselves when they have arrived.
+inline int mark_queued(nk2d_ctx* c, hipEvent_t ev) {
+    if (c->stream_on) return 0;
+    NK2D_CHECK(c, hipEventRecord(ev, nk2d_s(c)));
+    return 0;
+}
+inline int await_partials(nk2d_ctx* c, hipEvent_t ev, const double* part) {
+    if (c->stream_on) return nk2d_stream_wait_part(c, part, c->ncol);
+    NK2D_CHECK(c, hipEventSynchronize(ev));
+    return 0;
+}
+
 // simplified Newton iterations on the collocation system (radau.py:48-136), decisions on
 // the host: one read-back of the per-column norm partials per iteration.  While the host waits
 // for them the device already runs the front launches of the NEXT iteration; if the iteration
@@ -263,7 +277,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             c->part_cur = c->part_on_host ? part_of(k) : nullptr;
             NK2D_TRY(newton_back(s, mreal, mcr, mci));
             if (timed) NK2D_TRY(nk2d_prof_window_end(c));
-            if (speculate) NK2D_CHECK(c, hipEventRecord(event_of(k), c->stream));
+            if (speculate) NK2D_TRY(mark_queued(c, event_of(k)));
             launched = k;
         }
         c->st.nfev += 3;
@@ -302,7 +316,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
                 if (!single) NK2D_TRY(newton_front(s, mreal, mcr, mci));
                 c->part_cur = part_of(j);
                 NK2D_TRY(newton_back(s, mreal, mcr, mci));
-                NK2D_CHECK(c, hipEventRecord(event_of(j), c->stream));
+                NK2D_TRY(mark_queued(c, event_of(j)));
                 launched = j;
             }
             if (!whole && last_pred > k && k + 1 < kmax) {
@@ -312,7 +326,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             if (want_err) {
                 c->cnt_err_queued++;
                 NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, c->hPART2));
-                NK2D_CHECK(c, hipEventRecord(c->snap_ev[1], c->stream));
+                NK2D_TRY(mark_queued(c, c->snap_ev[1]));
                 err_behind = k + depth;
             }
             if (pairing && (depth > 0 || want_err)) {
@@ -329,7 +343,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
                 if (want_err) { held_err = v[n - 1]; have_held_err = true; }
                 coupled = true;
             } else {
-                NK2D_CHECK(c, hipEventSynchronize(event_of(k)));
+                NK2D_TRY(await_partials(c, event_of(k), part_of(k)));
                 NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, part_of(k)));
             }
         } else {
@@ -618,7 +632,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                     sum = err_coupled;
                     sum_coupled = true;
                 } else {
-                    NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[1]));
+                    NK2D_TRY(await_partials(c, c->snap_ev[1], c->hPART2));
                     NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, c->hPART2));
                 }
             } else if (s.device_ctl != 1) {
@@ -635,7 +649,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             err = rms_from_sum(sum, s.n_total);
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             if (rejected && err > 1) {
-                NK2D_CHECK(c, hipMemcpyAsync(c->TMP, c->XR[buf], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+                NK2D_CHECK(c, hipMemcpyAsync(c->TMP, c->XR[buf], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
                 NK2D_TRY(nk2d_r_err_rhs2(c, c->TMP, h));
                 c->st.nfev++;
                 NK2D_TRY(solve_systems(s, true, false, &buf));
@@ -804,9 +818,9 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
                 c->ckpt.push_back(buf);
             }
             double* buf = c->ckpt[slot];
-            NK2D_CHECK(c, hipMemcpyAsync(buf, c->Y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
-            NK2D_CHECK(c, hipMemcpyAsync(buf + c->nv, c->YOLD, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
-            NK2D_CHECK(c, hipMemcpyAsync(buf + 2 * c->nv, c->ZP, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(buf, c->Y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            NK2D_CHECK(c, hipMemcpyAsync(buf + c->nv, c->YOLD, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            NK2D_CHECK(c, hipMemcpyAsync(buf + 2 * c->nv, c->ZP, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
         }
         // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
         // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
@@ -941,7 +955,7 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
         // counter-collecting profiler of this ROCm falls over behind a few thousand unsynchronised dispatches, as it
         // did behind the preconditioner's elimination) -- the host is far ahead at that point
         // and a drain every 64 steps costs forty hand-overs a year
-        if ((i & 63) == 63) NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        if ((i & 63) == 63) NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     }
     return 0;
 }
@@ -962,7 +976,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
                                 "build of the library (fingerprint of step " + std::to_string(i) + ")", -8);
     if (c->step_part_rows < (size_t)(3 * n)) {
         // norm partials of the last two Newton iterations and of the error estimate of every step, one row of ncol each
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         if (c->STEP_PART) NK2D_CHECK(c, hipFree(c->STEP_PART));
         c->STEP_PART = nullptr;
         c->step_part_rows = 0;
@@ -1002,8 +1016,8 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
     auto fetch_sums = [&](int64_t from) -> int {
         NK2D_TRY(nk2d_r_rows_sum(c, c->STEP_PART + (size_t)(3 * from) * c->ncol, 3 * (n - from), c->STEP_NORM));
         NK2D_CHECK(c, hipMemcpyAsync(sums.data() + 3 * from, c->STEP_NORM, sizeof(double) * 3 * (n - from),
-                                     hipMemcpyDeviceToHost, c->stream));
-        NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+                                     hipMemcpyDeviceToHost, nk2d_s(c)));
+        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         return 0;
     };
     // ---- small grids: the whole year in one launch on the schedule cache (k_frozen_persistent).  Its steps are checked like
@@ -1062,9 +1076,9 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
             // resume at row `start` (a multiple of NK2D_CKPT_EVERY): state and collocation polynomial from the checkpoint;
             // planes, predicted stage values, Jacobian and factorisation are recomputed by the launches of a first row
             const double* buf = c->ckpt[(size_t)(start / NK2D_CKPT_EVERY)];
-            NK2D_CHECK(c, hipMemcpyAsync(c->Y, buf, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
-            NK2D_CHECK(c, hipMemcpyAsync(c->YOLD, buf + c->nv, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
-            NK2D_CHECK(c, hipMemcpyAsync(c->ZP, buf + 2 * c->nv, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(c->Y, buf, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            NK2D_CHECK(c, hipMemcpyAsync(c->YOLD, buf + c->nv, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            NK2D_CHECK(c, hipMemcpyAsync(c->ZP, buf + 2 * c->nv, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
             const double* r = cur + start * NK2D_SCHED_WIDTH;
             s.t = r[0];
             s.have_dense = start > 0;
@@ -1183,7 +1197,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     if (s.t1 > s.t) {
         // y = x; f = fun(t0, y0); first step size; J = jac(t0, y0)
         auto start_year = [&]() -> int {
-            NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, c->stream));
+            NK2D_CHECK(c, hipMemcpyAsync(c->Y, x, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
             NK2D_TRY(eval_kv(c, s.t, 3));
             NK2D_TRY(nk2d_k_tend(c, c->Y, c->KV[3], c->F));
             c->st.nfev++;
@@ -1232,12 +1246,48 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
             }
             if (rrc != 0) return rrc;
         }
-        else NK2D_TRY(run_free(s, record, record_cap, record_n));
+        else {
+            // The free-running year as a command stream (nk2d_stream.h): the launches of run_free become commands of ONE
+            // resident kernel, the waits for events become waits for the partials themselves.  A kernel that gives up (a
+            // wait over its time limit: a co-tenant on the chip, workgroups that did not all become resident) hands the year
+            // back: the same year again from x, by launches -- counted, not failed.
+            const bool as_stream = nk2d_stream_eligible(c) && s.device_ctl == 0 && c->part_on_host && c->speculate;
+            struct StreamGuard {
+                nk2d_ctx* c;
+                ~StreamGuard() {
+                    c->stream_on = 0;
+                    if (c->strm && nk2d_stream_running(c)) (void)nk2d_stream_end(c);
+                }
+            } stream_guard{c};
+            c->stream_on = as_stream ? 1 : 0;
+            int frc = run_free(s, record, record_cap, record_n);
+            c->stream_on = 0;
+            if (as_stream && (frc == 0 || frc == NK2D_RC_STREAM_LOST)) {
+                const int erc = nk2d_stream_end(c);
+                if (erc != 0 && erc != NK2D_RC_STREAM_LOST) return erc;
+                if (erc == NK2D_RC_STREAM_LOST) frc = NK2D_RC_STREAM_LOST;
+            }
+            if (frc == NK2D_RC_STREAM_LOST) {
+                if (++c->stream_lost >= 2) c->stream_years = 0;     // (not a third time on this context)
+                c->st = nk2d_stats();
+                c->st.nbarrier_timeouts = 1;
+                s.t = c->d.t0;
+                s.have_lu = false; s.have_dense = false; s.pre_setup = false;
+                s.has_old_h = s.has_old_err = false;
+                if (c->hist_n > 0) c->hist_next = 0;
+                NK2D_TRY(start_year());
+                frc = run_free(s, record, record_cap, record_n);
+            } else if (frc == 0 && as_stream) {
+                c->stream_years_run++;
+                c->stream_lost = 0;
+            }
+            if (frc != 0) return frc;
+        }
         NK2D_TRY(nk2d_r_final(c, (const double*)x, (double*)fx));
     } else {
-        NK2D_CHECK(c, hipMemsetAsync(fx, 0, sizeof(double) * c->nv, c->stream));
+        NK2D_CHECK(c, hipMemsetAsync(fx, 0, sizeof(double) * c->nv, nk2d_s(c)));
     }
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     NK2D_TRY(nk2d_profile_collect(c));
     if (!replay && record && record_n && *record_n <= record_cap)
         c->last_sched.assign(record, record + (size_t)(*record_n) * NK2D_SCHED_WIDTH);

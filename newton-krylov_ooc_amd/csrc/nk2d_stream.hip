@@ -1,0 +1,479 @@
+// nk2d_stream.hip -- the forward year as a command stream: one resident kernel executes the launches of the host-controlled
+// Radau year (nk2d_radau.hip) as commands; see nk2d_stream.h.  Replaces, for the year that produces F(x)
+// (/root/reference/nk_ooc/py_driver_2d/model_state.py:102-114, scipy/integrate/_ivp/radau.py:399-539), the launch per phase
+// and the stream synchronisation per Newton iteration -- not the controller, which is the host's, decision for decision.
+#include "nk2d_stream.h"
+
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ld_pair_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_pair_dev(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The relay: ONE wave (workgroup 0) polls the host's ring over PCIe -- one reader, whatever the number of workgroups -- and
+// forwards every complete command into the ring in HBM, which the workgroups poll.  It leaves behind the EXIT command, or
+// when nothing has come for the length of the time limit (the host is gone), raising the abort flag.
+__device__ __forceinline__ void stream_relay(const StreamArgs& A, int lane) {
+    unsigned seq = A.seq0;
+    long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    long long spins = 0;
+    for (;;) {
+        const size_t slot = (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
+        const unsigned long long a = ld_pair_sys(A.h_ring + slot + lane);
+        const unsigned long long b = ld_pair_sys(A.h_ring + slot + 64 + lane);
+        if (__all((int)((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq))) {
+            __hip_atomic_store(A.d_ring + slot + lane, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.d_ring + slot + 64 + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int op = __builtin_amdgcn_readlane((int)(unsigned)a, 0);
+            if (op == NK2D_OP_EXIT) return;
+            ++seq;
+            t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+            spins = 0;
+            continue;
+        }
+        const int ab = __builtin_amdgcn_readfirstlane(
+            (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+        const bool late = ((++spins & 15) == 0 || A.spin_ticks == 0) &&
+                          (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
+        if (late || ab != 0) {
+            if (lane == 0) {
+                __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.h_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+}
+
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
+    __shared__ int lds_ok;
+    __shared__ StreamCmd cmd;
+    const int lane = threadIdx.x & 63;
+    const int tw = uni_i((int)(threadIdx.x >> 6));          // the wave's place in its workgroup = its tracer
+    if (blockIdx.x == 0) {
+        if (tw == 0) stream_relay(A, lane);
+        return;
+    }
+    const int wg = (int)blockIdx.x - 1;
+    const int nw = (int)(blockDim.x >> 6);
+    const int j0 = wg * A.cpw, j1 = min(j0 + A.cpw, P.ny);   // this workgroup's ypos columns, every tracer of them
+    const int left = (wg > 0) ? wg - 1 : -1, right = (wg < A.nwg - 1) ? wg + 1 : -1;
+    unsigned seq = A.seq0;
+    int status = 0;
+    for (;;) {
+        // ---- the command: wave 0 polls the ring in HBM until every pair of the slot carries this command's stamp
+        if (tw == 0) {
+            const size_t slot = (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
+            int good = 1;
+            long long spins = 0;
+            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned long long a = ld_pair_dev(A.d_ring + slot + lane);
+                const unsigned long long b = ld_pair_dev(A.d_ring + slot + 64 + lane);
+                if (__all((int)((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq))) {
+                    unsigned* dw = reinterpret_cast<unsigned*>(&cmd);
+                    if (lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[lane] = (unsigned)a;
+                    if (64 + lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[64 + lane] = (unsigned)b;
+                    break;
+                }
+                const int ab = __builtin_amdgcn_readfirstlane(
+                    (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+                const bool late = ((++spins & 63) == 0 || A.spin_ticks == 0) &&
+                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
+                if (late || ab != 0) {
+                    if (lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) lds_ok = good;
+        }
+        __syncthreads();
+        if (lds_ok == 0) { status = 1; break; }
+        const int op = uni_i(cmd.op), flags = uni_i(cmd.flags);
+        if (op == NK2D_OP_EXIT) {
+            if (threadIdx.x == 0)
+                __hip_atomic_store(A.flags + (size_t)wg * 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        // ---- its work on this workgroup's columns: wave tw takes tracer tw (a one-wave workgroup every tracer in turn)
+        if (op == NK2D_OP_NEWTON) {
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) {
+                    if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                    else newton_fused_body<E, KIND, 0, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                }
+        } else if (op == NK2D_OP_ERR) {
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) err_fused_body<E, KIND, 1>(P, cmd.u.err, tr * P.ny + j, lane);
+        } else if (op == NK2D_OP_SETUP) {
+            // the mixing planes of the attempt's three stage times for this workgroup's columns (the wave that computes the
+            // plane of the Jacobian's stage derives the Jacobian planes of the column from it), then the predicted stage values
+            const StreamSetup& S = cmd.u.su;
+            for (int ti = tw; ti < 3; ti += nw)
+                for (int j = j0; j < j1; ++j) {
+                    double kv[E];
+                    vmix_body_kv<E, 1>(P, S.V, ti * P.ny + j, lane, kv);
+                    if (ti == S.J.stage)
+                        jac_core<E, 1>(P, kv, S.V.out[ti], S.J.JL, S.J.JU, S.J.JS, S.J.JN, S.J.JC, nullptr, nullptr, j, lane);
+                }
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) predict_body<E, 1>(S.A, tr * P.ny + j, lane);
+        } else if (op == NK2D_OP_BOUNDARY) {
+            const StreamBoundary& S = cmd.u.bd;
+            for (int ti = tw; ti < 3; ti += nw)
+                for (int j = j0; j < j1; ++j) {
+                    double kv[E];
+                    vmix_body_kv<E, 1>(P, S.V, ti * P.ny + j, lane, kv);
+                    if (ti == S.B.jac_stage)
+                        jac_core<E, 1>(P, kv, S.V.out[ti], S.B.JL, S.B.JU, S.B.JS, S.B.JN, S.B.JC, nullptr, nullptr, j, lane);
+                }
+            if (S.B.do_jac && tw == nw - 1)
+                for (int j = j0; j < j1; ++j) jac_body<E, 1>(P, S.B.kv_new, S.B.JL, S.B.JU, S.B.JS, S.B.JN, S.B.JC, nullptr, nullptr, j, lane);
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) {
+                    const int task = tr * P.ny + j;
+                    if (S.B.with_tend) {
+                        commit_tend_body<E, KIND, 1>(P, S.B.y, S.B.z2, S.B.kv_new, S.B.ynew, S.B.f, task, lane);
+                    } else {
+                        double c[E], t0[E];
+                        load_col<E, 1>(S.B.y, task, lane, c);
+                        load_col<E, 1>(S.B.z2, task, lane, t0);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) c[e] = c[e] + t0[e];
+                        store_col<E, 1>(S.B.ynew, task, lane, c);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's y_new is in memory before it reads it back
+                    predict_body<E, 1>(S.A, task, lane);
+                }
+        }
+        // ---- hand-over: every wave has drained its write-through stores, the workgroup publishes the command it has
+        // completed (and, where the host waits for it, stamps pinned memory) and waits for its two lateral neighbours
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (A.fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tw == 0) {
+            if (lane == 0) {
+                __hip_atomic_store(A.flags + (size_t)wg * 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (flags & NK2D_CMD_NOTIFY) __hip_atomic_store(A.h_done + wg, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const int other = (lane == 0) ? left : ((lane == 1) ? right : -1);
+            int good = 1;
+            long long spins = 0;
+            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                unsigned v = seq;
+                if (other >= 0) v = __hip_atomic_load(A.flags + (size_t)other * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)((int)(v - seq) >= 0))) break;
+                const int ab = __builtin_amdgcn_readfirstlane(
+                    (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+                const bool late = ((++spins & 63) == 0 || A.spin_ticks == 0) &&
+                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
+                if (late || ab != 0) {
+                    if (lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) lds_ok = good;
+        }
+        __syncthreads();
+        if (A.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lds_ok == 0) { status = 1; break; }
+        ++seq;
+    }
+    if (status != 0 && threadIdx.x == 0) {
+        A.out[0] = (double)status;
+        __hip_atomic_store(A.h_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (wg == 0 && threadIdx.x == 0) A.out[1] = (double)seq;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------------
+struct nk2d_stream_state {
+    unsigned long long* h_ring = nullptr;   // pinned
+    unsigned* h_done = nullptr;             // pinned [nwg]
+    unsigned* h_status = nullptr;           // pinned [16]
+    unsigned long long* d_ring = nullptr;
+    char* d_sync = nullptr;                 // abort flag at 0, workgroup flags from 4096 (one 128-byte line each)
+    double* d_out = nullptr;
+    double* h_out = nullptr;                // pinned [8]
+    unsigned seq = 0;                       // stamp of the last command pushed
+    unsigned done_upto = 0;                 // every workgroup is known to have completed this command
+    std::deque<unsigned> notifies;          // commands flagged NOTIFY that have not been waited for yet
+    bool running = false, lost = false;
+    int nwg = 0, cpw = 1, nw = 1;
+    int64_t launches = 0;
+};
+
+// ONE command-stream kernel at a time in a process: two of them do not fit the chip together (a kernel holds a SIMD per
+// wave), and a kernel that is only partly resident waits for workgroups that cannot start.  Held from the launch to the
+// EXIT command; contexts driven by other host threads wait their turn (their years then run back to back).
+namespace {
+std::mutex g_turn_mutex;
+std::condition_variable g_turn_cv;
+bool g_turn_taken = false;
+void turn_take() {
+    std::unique_lock<std::mutex> lk(g_turn_mutex);
+    g_turn_cv.wait(lk, [] { return !g_turn_taken; });
+    g_turn_taken = true;
+}
+void turn_give() {
+    {
+        std::lock_guard<std::mutex> lk(g_turn_mutex);
+        g_turn_taken = false;
+    }
+    g_turn_cv.notify_one();
+}
+}  // namespace
+
+bool nk2d_stream_running(const nk2d_ctx* c) { return c->strm && c->strm->running; }
+unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq : 0u; }
+
+// which contexts run their years as command streams: linear sources for now (iage, forced without forcing files), host-side
+// decisions, double precision factor tables, and a grid whose workgroups are all resident at once
+int nk2d_stream_eligible(const nk2d_ctx* c) {
+    if (!c->stream_years || c->stream_lost >= 2 || c->kind != 0 || c->norm_hook || c->factor_fp32 || c->device_ctl != 0) return 0;
+    if (c->team != 0 || c->xcd_map || c->prefactor) return 0;
+    return 1;
+}
+
+template <int E, int KIND>
+static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks) {
+    if (max_blocks) {
+        int nb = 0;
+        hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<E, KIND>, (int)block.x, 0);
+        if (rc != hipSuccess) return rc;
+        *max_blocks = nb;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL((k_stream<E, KIND>), grid, block, 0, c->stream_, P, A);
+    return hipGetLastError();
+}
+static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks) {
+    hipError_t rc = hipErrorInvalidValue;
+    NK2D_DISPATCH_E(c->E, rc = stream_launch_one<EE, 0>(c, grid, block, P, A, max_blocks));
+    return rc;
+}
+
+static int stream_alloc(nk2d_ctx* c) {
+    if (c->strm) return 0;
+    nk2d_stream_state* S = new nk2d_stream_state();
+    c->strm = S;
+    S->nw = std::min(c->tc, NK2D_WAVES_PER_BLOCK);
+    // ypos columns per workgroup: one where the chip holds a workgroup per column, more where it does not
+    int per_cu = 0;
+    DevP P = make_devp(c);
+    StreamArgs A = {};
+    NK2D_CHECK(c, stream_launch(c, dim3(1), dim3(64 * S->nw), P, A, &per_cu));
+    hipDeviceProp_t prop;
+    NK2D_CHECK(c, hipGetDeviceProperties(&prop, c->dev));
+    const int capacity = per_cu * prop.multiProcessorCount - 1;     // (one workgroup is the relay's)
+    if (capacity < 1) return nk2d_fail(c, "command stream: the kernel does not fit a compute unit");
+    S->cpw = (c->ny + capacity - 1) / capacity;
+    S->nwg = (c->ny + S->cpw - 1) / S->cpw;
+    NK2D_CHECK(c, hipHostMalloc((void**)&S->h_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
+    NK2D_CHECK(c, hipHostMalloc((void**)&S->h_done, sizeof(unsigned) * S->nwg));
+    NK2D_CHECK(c, hipHostMalloc((void**)&S->h_status, sizeof(unsigned) * 16));
+    NK2D_CHECK(c, hipHostMalloc((void**)&S->h_out, sizeof(double) * 8));
+    NK2D_CHECK(c, hipMalloc((void**)&S->d_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
+    NK2D_CHECK(c, hipMalloc((void**)&S->d_sync, 4096 + (size_t)S->nwg * 128));
+    NK2D_CHECK(c, hipMalloc((void**)&S->d_out, sizeof(double) * 8));
+    std::memset(S->h_ring, 0, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS);
+    std::memset(S->h_done, 0, sizeof(unsigned) * S->nwg);
+    std::memset(S->h_status, 0, sizeof(unsigned) * 16);
+    NK2D_CHECK(c, hipMemset(S->d_ring, 0, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
+    NK2D_CHECK(c, hipMemset(S->d_sync, 0, 4096 + (size_t)S->nwg * 128));
+    NK2D_CHECK(c, hipMemset(S->d_out, 0, sizeof(double) * 8));
+    return 0;
+}
+
+void nk2d_stream_free(nk2d_ctx* c) {
+    nk2d_stream_state* S = c->strm;
+    if (!S) return;
+    if (S->running) (void)nk2d_stream_pause(c);
+    (void)hipStreamSynchronize(c->stream_);
+    if (S->h_ring) (void)hipHostFree(S->h_ring);
+    if (S->h_done) (void)hipHostFree(S->h_done);
+    if (S->h_status) (void)hipHostFree(S->h_status);
+    if (S->h_out) (void)hipHostFree(S->h_out);
+    if (S->d_ring) (void)hipFree(S->d_ring);
+    if (S->d_sync) (void)hipFree(S->d_sync);
+    if (S->d_out) (void)hipFree(S->d_out);
+    delete S;
+    c->strm = nullptr;
+}
+
+static void ring_write(nk2d_stream_state* S, unsigned seq, const StreamCmd& cmd) {
+    unsigned dw[NK2D_CMD_DWORDS] = {0};
+    std::memcpy(dw, &cmd, sizeof(StreamCmd));
+    unsigned long long* slot = S->h_ring + (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
+    for (int k = 0; k < NK2D_CMD_DWORDS; ++k)
+        __atomic_store_n(slot + k, ((unsigned long long)seq << 32) | dw[k], __ATOMIC_RELAXED);
+}
+
+// start the kernel (it will find the commands pushed from now on)
+static int stream_start(nk2d_ctx* c) {
+    nk2d_stream_state* S = c->strm;
+    turn_take();
+    StreamArgs A = {};
+    A.h_ring = S->h_ring; A.d_ring = S->d_ring;
+    A.abort_flag = (int*)S->d_sync;
+    A.flags = (unsigned*)(S->d_sync + 4096);
+    A.h_done = S->h_done; A.h_status = S->h_status; A.out = S->d_out;
+    A.seq0 = S->seq + 1;
+    A.nwg = S->nwg; A.cpw = S->cpw;
+    A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
+    A.fences = c->year_fences;
+    DevP P = make_devp(c);
+    P.guard = nullptr;
+    const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr);
+    if (rc != hipSuccess) {
+        turn_give();
+        NK2D_CHECK(c, rc);
+    }
+    S->running = true;
+    S->launches++;
+    c->stream_launches++;
+    c->st.nlaunch++;
+    return 0;
+}
+
+// wait until every workgroup has completed command `seq` (one flagged NOTIFY), bounded by the time limit of the kernel's
+// own waits plus a second
+int nk2d_stream_wait(nk2d_ctx* c, unsigned seq) {
+    nk2d_stream_state* S = c->strm;
+    if (!S || S->lost) return NK2D_RC_STREAM_LOST;
+    if ((int)(S->done_upto - seq) >= 0) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit_s = 1.0e-3 * c->barrier_timeout_ms + 1.0;
+    long long spins = 0;
+    for (int wg = 0; wg < S->nwg; ++wg) {
+        for (;;) {
+            const unsigned v = __atomic_load_n(S->h_done + wg, __ATOMIC_ACQUIRE);
+            if ((int)(v - seq) >= 0) break;
+            if ((++spins & 255) == 0) {
+                const bool gave_up = __atomic_load_n(S->h_status, __ATOMIC_RELAXED) != 0;
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (gave_up || waited > limit_s) {
+                    // tell the kernel to leave (the relay sees the EXIT, a workgroup stuck in a wait its own time limit),
+                    // wait for it, and hand the year back
+                    S->lost = true;
+                    c->stream_timeouts++;
+                    (void)nk2d_stream_pause(c);
+                    (void)hipStreamSynchronize(c->stream_);
+                    return NK2D_RC_STREAM_LOST;
+                }
+            }
+        }
+    }
+    S->done_upto = seq;
+    while (!S->notifies.empty() && (int)(seq - S->notifies.front()) >= 0) S->notifies.pop_front();
+    return 0;
+}
+
+// Norm partials come back through pinned host memory, one double per column, written by the waves of the command that
+// computes them.  The host marks every slot before it pushes that command (a NaN no computation produces) and reads a slot
+// once the mark is gone: the value itself says that it has arrived -- no flag whose write would have to be ordered behind
+// 832 waves' stores on their way over PCIe.
+static const unsigned long long kPoison = 0x7FF8DEADBEEFCAFEull;
+
+void nk2d_stream_poison(double* part, int n) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(part);
+    for (int i = 0; i < n; ++i) __atomic_store_n(p + i, kPoison, __ATOMIC_RELAXED);
+}
+
+int nk2d_stream_wait_part(nk2d_ctx* c, const double* part, int n) {
+    nk2d_stream_state* S = c->strm;
+    if (!S || S->lost) return NK2D_RC_STREAM_LOST;
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(part);
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit_s = 1.0e-3 * c->barrier_timeout_ms + 1.0;
+    long long spins = 0;
+    for (int i = 0; i < n; ++i) {
+        while (__atomic_load_n(p + i, __ATOMIC_ACQUIRE) == kPoison) {
+            if ((++spins & 255) == 0) {
+                const bool gave_up = __atomic_load_n(S->h_status, __ATOMIC_RELAXED) != 0;
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (gave_up || waited > limit_s) {
+                    S->lost = true;
+                    c->stream_timeouts++;
+                    (void)nk2d_stream_pause(c);
+                    (void)hipStreamSynchronize(c->stream_);
+                    return NK2D_RC_STREAM_LOST;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int nk2d_stream_push(nk2d_ctx* c, StreamCmd& cmd, bool notify, unsigned* seq_out) {
+    NK2D_TRY(stream_alloc(c));
+    nk2d_stream_state* S = c->strm;
+    if (S->lost) return NK2D_RC_STREAM_LOST;
+    if (!S->running) NK2D_TRY(stream_start(c));
+    const unsigned seq = S->seq + 1;
+    // flow control: a slot is rewritten NK2D_RING_SLOTS commands later -- by then every workgroup must be past it.  Every
+    // 32nd command asks for completion stamps; the host never runs more than half a ring ahead of the oldest of them
+    if ((seq & 31u) == 0) notify = true;
+    while (seq - S->done_upto > NK2D_RING_SLOTS / 2 && !S->notifies.empty()) NK2D_TRY(nk2d_stream_wait(c, S->notifies.front()));
+    cmd.flags = (cmd.flags & ~NK2D_CMD_NOTIFY) | (notify ? NK2D_CMD_NOTIFY : 0);
+    ring_write(S, seq, cmd);
+    S->seq = seq;
+    if (notify) S->notifies.push_back(seq);
+    if (seq_out) *seq_out = seq;
+    c->stream_cmds++;
+    return 0;
+}
+
+// tell the kernel to finish behind the commands pushed so far; nothing is waited for (what the caller queues on the
+// context's stream next is ordered behind the kernel by the stream)
+int nk2d_stream_pause(nk2d_ctx* c) {
+    nk2d_stream_state* S = c->strm;
+    if (!S || !S->running) return 0;
+    StreamCmd cmd = {};
+    cmd.op = NK2D_OP_EXIT;
+    const unsigned seq = S->seq + 1;
+    ring_write(S, seq, cmd);
+    S->seq = seq;
+    S->running = false;
+    // (the kernel's workgroups all pass the EXIT command: everything before it is complete once the kernel has ended)
+    S->notifies.clear();
+    turn_give();
+    return 0;
+}
+
+// the end of a year: the kernel ends, the host waits for it and learns whether it had given up on the way
+int nk2d_stream_end(nk2d_ctx* c) {
+    nk2d_stream_state* S = c->strm;
+    if (!S) return 0;
+    (void)nk2d_stream_pause(c);
+    NK2D_CHECK(c, hipMemcpyAsync(S->h_out, S->d_out, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream_));
+    NK2D_CHECK(c, hipStreamSynchronize(c->stream_));
+    S->done_upto = S->seq;
+    const bool lost = S->lost || S->h_out[0] != 0.0 || __atomic_load_n(S->h_status, __ATOMIC_RELAXED) != 0;
+    if (lost) {
+        // leave everything as a fresh start would find it
+        if (!S->lost) c->stream_timeouts++;
+        S->lost = false;
+        std::memset(S->h_status, 0, sizeof(unsigned) * 16);
+        NK2D_CHECK(c, hipMemset(S->d_sync, 0, 4096));
+        NK2D_CHECK(c, hipMemset(S->d_out, 0, sizeof(double) * 8));
+        return NK2D_RC_STREAM_LOST;
+    }
+    return 0;
+}

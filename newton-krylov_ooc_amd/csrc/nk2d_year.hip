@@ -465,7 +465,7 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
         NK2D_CHECK(c, hipMalloc((void**)&c->YR_REC, sizeof(double) * NK2D_SCHED_WIDTH * record_cap));
         c->yr_rec_cap = record_cap;
     }
-    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), c->stream));
+    NK2D_CHECK(c, hipMemsetAsync(c->YR_SYNC, 0, yr_sync_bytes(c), nk2d_s(c)));
     YearArgs A = {};
     A.Y = c->Y; A.YOLD = c->YOLD; A.F = c->F; A.Z = c->Z; A.ZP = c->ZP; A.ZN = c->ZN; A.W = c->W;
     A.BR = c->BR; A.BCR = c->BCR; A.BCI = c->BCI;
@@ -491,17 +491,17 @@ int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double m
     P.guard = nullptr;
     void* args[2] = {&P, &A};
     hipError_t rc = hipErrorInvalidValue;
-    NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], c->stream));
+    NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
     {
         std::lock_guard<std::mutex> coop(coop_launch_mutex());
         NK2D_DISPATCH_E(c->E, rc = hipLaunchCooperativeKernel((const void*)k_year_persistent<EE, 0>, dim3(nblk), dim3(NK2D_BLOCK),
-                                                               args, 0, c->stream));
+                                                               args, 0, nk2d_s(c)));
     }
     if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
     NK2D_CHECK(c, rc);
-    NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], c->stream));
-    NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, c->stream));
-    NK2D_CHECK(c, hipStreamSynchronize(c->stream));
+    NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));
+    NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, nk2d_s(c)));
+    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     const double* o = c->hYR_OUT;
     const int status = (int)o[0];
     // the buffers swapped roles on the device an odd or even number of times

@@ -1,0 +1,103 @@
+"""The forward year as a command stream (csrc/nk2d_stream.hip, nk2d_stream.h): ONE resident kernel executes the launches of
+the host-controlled year as commands, workgroups handing over to their lateral neighbours.  The controller is the host's
+own -- same decisions -- and the commands run the device functions of the launches they replace, so the year is the
+host-controlled year BIT FOR BIT: F(x), every accepted step of its schedule, every counter.  (Against the CPU oracle the
+launch path is pinned in test_gpu_comp_fcn.py / test_gpu_oracle_deep.py; what equals it bit for bit is pinned with it.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _iage(nz, ny):
+    from nk_ooc_amd.engine import iage_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    eng = iage_engine(Grid2d.default(nz, ny))
+    eng.set_option("device_ctl", 0)
+    return eng
+
+
+def _state(eng, seed=5):
+    rng = np.random.default_rng(seed)
+    tc, nz, ny = eng.shape
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    return np.stack([np.broadcast_to(col[:, None], (nz, ny))] * tc) + 0.01 * rng.standard_normal(eng.shape)
+
+
+@pytest.mark.parametrize("nz,ny", [(26, 26), (52, 52), (130, 20), (250, 12), (416, 8), (512, 6)])
+@pytest.mark.parametrize("mode", ["default", "scipy_decisions"])
+def test_stream_year_is_the_host_controlled_year(nz, ny, mode):
+    if mode == "scipy_decisions" and nz > 130:
+        pytest.skip("SciPy's decisions: the two shallow grids and one of three levels per lane")
+    eng = _iage(nz, ny)
+    if mode == "scipy_decisions":
+        eng.set_option("jac_stage", -1)
+        eng.set_option("jac_fresh", 0)
+    x = eng.upload(_state(eng))
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    want = eng.download(fx)
+    eng.set_option("stream_years", 1)
+    fx_s, st_s, sched_s = eng.comp_fcn(x, record=True)
+    assert eng.counter("stream_years_run") == 1 and eng.counter("stream_timeouts") == 0
+    assert np.array_equal(sched_s, sched)                       # every accepted step, Newton count, Jacobian time, error
+    assert np.array_equal(eng.download(fx_s), want)
+    for key in ("nsteps", "nrejected", "nnewton", "nfev", "njev", "nlu", "nsolve", "nsweeps"):
+        assert st_s[key] == st[key], key
+    # a year is a handful of launches: the kernel, and whatever has no command (first attempt, several-sweep estimates)
+    assert st_s["nlaunch"] < 0.2 * st["nlaunch"]
+    assert eng.counter("stream_commands") > st["nnewton"]
+    # and again (the ring's stamps go on, the flags are not reset): the same year
+    fx_2, _, _ = eng.comp_fcn(x)
+    assert np.array_equal(eng.download(fx_2), want) and eng.counter("stream_years_run") == 2
+    eng.close()
+
+
+def test_year_with_history_samples_as_a_stream():
+    """the 61 samples of a history file have no command: each ends the kernel, runs its launches, the next command starts the
+    kernel again -- same year, same samples"""
+    n = 52
+    eng = _iage(n, n)
+    x = eng.upload(_state(eng))
+    t_eval = np.linspace(0.0, 365.0 * 86400.0, 61)
+    fx, st, hist = eng.comp_fcn_hist(x, t_eval)
+    eng.set_option("stream_years", 1)
+    fx_s, st_s, hist_s = eng.comp_fcn_hist(x, t_eval)
+    assert np.array_equal(eng.download(fx_s), eng.download(fx)) and np.array_equal(hist_s, hist)
+    assert eng.counter("stream_years_run") == 1 and eng.counter("stream_launches") >= 50
+    eng.close()
+
+
+def test_a_kernel_that_gives_up_hands_the_year_back():
+    """time limit zero: the first wait of the kernel gives up; the year is rerun by launches, counted, and is the same year"""
+    eng = _iage(52, 52)
+    x = eng.upload(_state(eng))
+    fx, st, _ = eng.comp_fcn(x)
+    eng.set_option("stream_years", 1)
+    eng.set_option("barrier_timeout_ms", 0)
+    fx_s, st_s, _ = eng.comp_fcn(x)
+    assert np.array_equal(eng.download(fx_s), eng.download(fx))
+    assert st_s["nbarrier_timeouts"] == 1 and eng.counter("stream_timeouts") >= 1 and eng.counter("stream_years_run") == 0
+    eng.set_option("barrier_timeout_ms", 2000)
+    fx_s, st_s, _ = eng.comp_fcn(x)
+    assert np.array_equal(eng.download(fx_s), eng.download(fx)) and eng.counter("stream_years_run") == 1
+    eng.close()
+
+
+def test_full_size_stream_year():
+    """416 x 416: the year that produces F(x), bit for bit, and faster than by launches"""
+    n = 416
+    eng = _iage(n, n)
+    col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+    x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    eng.set_option("stream_years", 1)
+    fx_s, st_s, sched_s = eng.comp_fcn(x, record=True)
+    fx_s, st_s, sched_s = eng.comp_fcn(x, record=True)
+    assert np.array_equal(sched_s, sched) and np.array_equal(eng.download(fx_s), eng.download(fx))
+    assert eng.counter("stream_years_run") == 2 and eng.counter("stream_timeouts") == 0
+    print(f"416^2 free-running year: {st['seconds']:.3f} s by launches ({st['nlaunch']} launches), "
+          f"{st_s['seconds']:.3f} s as a command stream ({st_s['nlaunch']} launches, {eng.counter('stream_commands') // 2} commands)")
+    assert st_s["seconds"] < st["seconds"]
+    eng.close()
