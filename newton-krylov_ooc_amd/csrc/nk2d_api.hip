@@ -151,6 +151,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
     if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
+    if (key == "spec_bias") { c->spec_bias = value > 0.0 ? value : 1.0; return 0; }
     if (key == "stream_years") { c->stream_years = (int)value; c->stream_lost = 0; return 0; }
     if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
     if (key == "frozen_alloc_async") { c->frozen_alloc_async = value != 0.0; return 0; }
@@ -524,6 +525,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_nbsync = 1;
     c->frozen_cache_after = 0;
     c->strm = nullptr;
+    c->spec_bias = 1.0;
     c->stream_years = 0;
     c->stream_on = 0;
     c->stream_lost = 0;
@@ -974,6 +976,13 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     else if (key == "stream_commands") v = c->stream_cmds;
     else if (key == "stream_launches") v = c->stream_launches;
     else if (key == "stream_timeouts") v = c->stream_timeouts;
+    else if (key.rfind("stream_prof_", 0) == 0) {
+        // stream_prof_0 .. stream_prof_11: see nk2d_stream_profile
+        double pr[12];
+        NK2D_TRY(nk2d_stream_profile(c, pr));
+        const int i = std::atoi(key.c_str() + 12);
+        v = (i >= 0 && i < 12) ? (int64_t)pr[i] : 0;
+    }
     else if (key == "frozen_launch_us") v = c->frozen_launch_us;
     else if (key == "frozen_cache_pending") v = nk2d_frozen_cache_pending(c);
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;

@@ -180,6 +180,7 @@ struct nk2d_ctx {
     int factor_pending;          // set by the integrator's "LU" event, consumed by the next fused launch
     double lu_cre, lu_ccr, lu_cci;  // shifts of the current line factorisation
     int speculate;   // 1: queue the next Newton iteration's front launches before reading the norm
+    double spec_bias;   // option "spec_bias": the iteration in flight is EXPECTED to pass SciPy's convergence test when its predicted test value is below this many tolerances (what is queued behind it: the error estimate or another iteration; never a decision)
     // freed state vectors kept for reuse (nk2d_vec_alloc / nk2d_vec_free)
     std::vector<double*> vec_pool;
     std::mutex pool_mutex;
@@ -271,9 +272,13 @@ struct nk2d_ctx {
 int nk2d_stream_pause(nk2d_ctx* c);
 bool nk2d_stream_running(const nk2d_ctx* c);
 int nk2d_stream_eligible(const nk2d_ctx* c);
+int nk2d_stream_ready(nk2d_ctx* c);     // buffers of the command stream in place (first use)
 int nk2d_stream_end(nk2d_ctx* c);       // ends the kernel, waits for it; NK2D_RC_STREAM_LOST if it had given up on the way
 void nk2d_stream_free(nk2d_ctx* c);
-void nk2d_stream_poison(double* part, int n);
+int nk2d_stream_profile(nk2d_ctx* c, double* out12);
+double* nk2d_stream_part_take(nk2d_ctx* c, const double* name);
+const double* nk2d_stream_part_named(const nk2d_ctx* c, const double* name);
+void nk2d_stream_part_forget(nk2d_ctx* c, const double* name);
 int nk2d_stream_wait_part(nk2d_ctx* c, const double* part, int n);
 // the stream every launch, copy and synchronisation of a context goes to: whatever is queued there must come AFTER the
 // commands pushed so far, so a resident command-stream kernel is told to finish first (the caller's launch is then ordered
@@ -642,6 +647,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
 int nk2d_r_err_rhs(nk2d_ctx* c, double h);
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h);
 int nk2d_r_err_norm(nk2d_ctx* c, const double* err);
+int nk2d_r_copy(nk2d_ctx* c, double* dst, const double* src);
 int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys);
 int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out);
 int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out);

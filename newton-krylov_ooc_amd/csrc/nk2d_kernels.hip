@@ -260,6 +260,15 @@ int nk2d_k_sweep(nk2d_ctx* c, bool do_real, bool do_cplx, bool first, double cre
     A.ntasks = A.nreal + (do_cplx ? c->ncol : 0);
     A.first = first ? 1 : 0;
     if (A.ntasks == 0) return 0;
+    if (c->stream_on) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_SWEEP;
+        cmd.u.sw = A;
+        cmd.u.sw.f32 = 0;
+        NK2D_TRY(nk2d_stream_push(c, cmd, false));
+        c->st.nsweeps++;
+        return 0;
+    }
     DevP P = make_devp(c);
     const bool sample = false;  // the profiled kernel is k_newton_fused
     if (sample) NK2D_CHECK(c, hipEventRecord(c->prof_ev[c->prof_used], nk2d_s(c)));
@@ -338,6 +347,7 @@ __global__ void k_reduce(const double* __restrict__ part, int ntasks, int nout, 
 // binary tree), so that the host- and the device-controlled integrators see bit-identical norms.
 int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part) {
     if (part == nullptr) part = c->hPART;
+    if (c->strm) part = nk2d_stream_part_named(c, part);    // (the pinned buffer a command wrote them to under this name)
     *out = nk2d_hm_part_sum(part, ntasks, NK2D_BLOCK);
     return 0;
 }
@@ -345,8 +355,8 @@ int nk2d_part_sum(nk2d_ctx* c, int ntasks, double* out, const double* part) {
 int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
     if (c->part_on_host && host_out && nout == 1) {
         // host-controlled integrator: no reduction launch
-        if (c->stream_on && nk2d_stream_running(c)) {
-            // the partials are those of the last command pushed (marked before it went out): wait for them, not for the kernel
+        if (c->strm && nk2d_stream_part_named(c, c->hPART) != c->hPART) {
+            // the partials are a command's (marked before it went out): wait for them, not for the kernel
             NK2D_TRY(nk2d_stream_wait_part(c, c->hPART, ntasks));
         } else {
             NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
@@ -908,7 +918,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
         cmd.flags = do_factor ? NK2D_CMD_FACTOR : 0;
         cmd.u.nf = A;
         // the norm partials of the update come back through pinned memory: marked before the command goes out
-        if (do_update && c->part_on_host) nk2d_stream_poison(A.part, c->ncol);
+        if (do_update && c->part_on_host) cmd.u.nf.part = nk2d_stream_part_take(c, A.part);
         NK2D_TRY(nk2d_stream_push(c, cmd, false));
         c->st.nlaunch--;     // (a command, not a launch)
     } else {
@@ -1091,6 +1101,12 @@ int nk2d_prof_window_end(nk2d_ctx* c) {
 }
 
 int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
+    if (c->stream_on && c->cur_guard == nullptr) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_ERR_RHS;
+        cmd.u.col.a = c->F; cmd.u.col.b = c->Z; cmd.u.col.nv = c->nv; cmd.u.col.h = h; cmd.u.col.out = c->BR;
+        return nk2d_stream_push(c, cmd, false);
+    }
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                                c->ncol, c->F, c->Z, c->nv, h, c->BR, c->cur_guard));
     NK2D_CHECK(c, hipGetLastError());
@@ -1117,7 +1133,7 @@ int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part) {
             StreamCmd cmd = {};
             cmd.op = NK2D_OP_ERR;
             cmd.u.err = A;
-            if (A.last && c->part_on_host) nk2d_stream_poison(A.part, c->ncol);
+            if (A.last && c->part_on_host) cmd.u.err.part = nk2d_stream_part_take(c, A.part);
             NK2D_TRY(nk2d_stream_push(c, cmd, false));
             c->st.nsweeps++;
             src = 1 - src;
@@ -1135,6 +1151,13 @@ int nk2d_r_err_fused(nk2d_ctx* c, double h, int m, int* buf, double* part) {
 }
 
 int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
+    if (c->stream_on) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_ERR_RHS2;
+        cmd.u.col.a = c->Y; cmd.u.col.b = err; cmd.u.col.c = c->KV[3]; cmd.u.col.d = c->Z;
+        cmd.u.col.nv = c->nv; cmd.u.col.h = h; cmd.u.col.out = c->BR;
+        return nk2d_stream_push(c, cmd, false);
+    }
     DevP P = make_devp(c);
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_err_rhs2<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P,
                                                c->Y, err, c->KV[3], c->Z, c->nv, h, c->BR));
@@ -1152,8 +1175,28 @@ int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv) {
     c->st.nlaunch++;
     return 0;
 }
+// dst <- src, a state vector (the copy of the error vector before the second estimate of a rejected step)
+int nk2d_r_copy(nk2d_ctx* c, double* dst, const double* src) {
+    if (c->stream_on) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_COPY;
+        cmd.u.col.a = src; cmd.u.col.out = dst;
+        return nk2d_stream_push(c, cmd, false);
+    }
+    NK2D_CHECK(c, hipMemcpyAsync(dst, src, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+    return 0;
+}
+
 int nk2d_r_err_norm(nk2d_ctx* c, const double* err) {
+    if (c->stream_on && c->part_on_host) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_ERR_NORM;
+        cmd.u.col.a = c->Y; cmd.u.col.b = c->Z + 2 * c->nv; cmd.u.col.c = err;
+        cmd.u.col.part = nk2d_stream_part_take(c, c->hPART);
+        return nk2d_stream_push(c, cmd, false);
+    }
     DevP P = make_devp(c);
+    if (c->strm && c->part_on_host) nk2d_stream_part_forget(c, c->hPART);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_norm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P,
                                                c->Y, c->Z + 2 * c->nv, err, c->part_on_host ? c->hPART : c->PART));
     NK2D_CHECK(c, hipGetLastError());
@@ -1162,6 +1205,7 @@ int nk2d_r_err_norm(nk2d_ctx* c, const double* err) {
 }
 int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, double cb, const double* ys) {
     DevP P = make_devp(c);
+    if (c->strm && c->part_on_host) nk2d_stream_part_forget(c, c->hPART);
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_wnorm<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, a,
                                                b, ca, cb, ys, c->part_on_host ? c->hPART : c->PART));
     NK2D_CHECK(c, hipGetLastError());

@@ -298,7 +298,7 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
             if (has_rate && rate < 1.0) {
                 double next_norm = rate * dW_norm_old;
                 for (int j = 0; j <= 2; ++j, next_norm *= rate)
-                    if (rate / (1.0 - rate) * next_norm < s.newton_tol) { last_pred = k + j; break; }
+                    if (rate / (1.0 - rate) * next_norm < c->spec_bias * s.newton_tol) { last_pred = k + j; break; }
             } else if (pairing && !has_rate) {
                 last_pred = s.n_iter_prev > 0 ? std::max(k, s.n_iter_prev - 1) : k + 1;
             }
@@ -649,7 +649,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             err = rms_from_sum(sum, s.n_total);
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter);
             if (rejected && err > 1) {
-                NK2D_CHECK(c, hipMemcpyAsync(c->TMP, c->XR[buf], sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+                NK2D_TRY(nk2d_r_copy(c, c->TMP, c->XR[buf]));
                 NK2D_TRY(nk2d_r_err_rhs2(c, c->TMP, h));
                 c->st.nfev++;
                 NK2D_TRY(solve_systems(s, true, false, &buf));
@@ -1131,6 +1131,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
                     double* record, int64_t record_cap, int64_t* record_n, bool replay_own) {
     const auto wall0 = std::chrono::steady_clock::now();
     c->st = nk2d_stats();
+    if (c->strm) nk2d_stream_part_forget(c, nullptr);     // (every partial buffer stands for itself until a command takes its name)
     c->prefactored = 0;
     // every free-running year leaves its accepted steps behind (nk2d_last_schedule): recorded into the caller's
     // buffer, or into the context's own
@@ -1259,6 +1260,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
                     if (c->strm && nk2d_stream_running(c)) (void)nk2d_stream_end(c);
                 }
             } stream_guard{c};
+            if (as_stream) NK2D_TRY(nk2d_stream_ready(c));
             c->stream_on = as_stream ? 1 : 0;
             int frc = run_free(s, record, record_cap, record_n);
             c->stream_on = 0;
@@ -1269,6 +1271,7 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
             }
             if (frc == NK2D_RC_STREAM_LOST) {
                 if (++c->stream_lost >= 2) c->stream_years = 0;     // (not a third time on this context)
+                nk2d_stream_part_forget(c, nullptr);
                 c->st = nk2d_stats();
                 c->st.nbarrier_timeouts = 1;
                 s.t = c->d.t0;

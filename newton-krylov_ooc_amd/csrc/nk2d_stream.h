@@ -17,7 +17,9 @@
 
 #include "nk2d_bodies.h"
 
-enum { NK2D_OP_EXIT = 1, NK2D_OP_SETUP = 2, NK2D_OP_NEWTON = 3, NK2D_OP_ERR = 4, NK2D_OP_BOUNDARY = 5 };
+enum { NK2D_OP_EXIT = 1, NK2D_OP_SETUP = 2, NK2D_OP_NEWTON = 3, NK2D_OP_ERR = 4, NK2D_OP_BOUNDARY = 5,
+       // the several-sweep error estimate and the second estimate of a rejected step, launch for launch
+       NK2D_OP_SWEEP = 6, NK2D_OP_ERR_RHS = 7, NK2D_OP_ERR_RHS2 = 8, NK2D_OP_ERR_NORM = 9, NK2D_OP_COPY = 10 };
 #define NK2D_CMD_NOTIFY 1   /* the host waits for this command: completion stamp of every workgroup to pinned memory */
 #define NK2D_CMD_FACTOR 2   /* OP_NEWTON: the launch that computes the line factorisation of its column (first after an "LU" event) */
 
@@ -31,9 +33,17 @@ struct StreamBoundary {     // nk2d_r_step_boundary
     BoundaryArgs B;
     PredictArgs A;
 };
+struct StreamColumns {      // nk2d_r_err_rhs / _err_rhs2 / _err_norm, a column-wise copy: operands by position
+    const double *a, *b, *c, *d;
+    double *out, *part;
+    size_t nv;
+    double h;
+};
 struct StreamCmd {
     int op, flags;
     union {
+        SweepArgs sw;       // nk2d_k_sweep
+        StreamColumns col;
         FusedArgs nf;       // nk2d_r_newton_fused
         ErrArgs err;        // one launch of nk2d_r_err_fused
         StreamSetup su;
@@ -60,6 +70,7 @@ struct StreamArgs {
     int nwg, cpw;                       // workgroups, ypos columns per workgroup
     long long spin_ticks;               // longest wait (ticks of s_memrealtime, 100 MHz)
     int fences;
+    unsigned long long* prof;           // [nwg][12]: ticks waiting for a command, executing, waiting for neighbours; commands; per op
 };
 
 // host side (nk2d_stream.hip; what the integrator itself calls is declared in nk2d_common.h)

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <vector>
+
+#define NK2D_PART_RING 16
 
 // ---------------------------------------------------------------------------------------------------------------------
 // device
@@ -60,7 +63,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
     const int lane = threadIdx.x & 63;
     const int tw = uni_i((int)(threadIdx.x >> 6));          // the wave's place in its workgroup = its tracer
     if (blockIdx.x == 0) {
-        if (tw == 0) stream_relay(A, lane);
+        // (no relay where the host writes its commands straight into the ring in HBM)
+        if (tw == 0 && A.h_ring != nullptr) stream_relay(A, lane);
         return;
     }
     const int wg = (int)blockIdx.x - 1;
@@ -69,37 +73,56 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
     const int left = (wg > 0) ? wg - 1 : -1, right = (wg < A.nwg - 1) ? wg + 1 : -1;
     unsigned seq = A.seq0;
     int status = 0;
-    for (;;) {
-        // ---- the command: wave 0 polls the ring in HBM until every pair of the slot carries this command's stamp
-        if (tw == 0) {
-            const size_t slot = (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
-            int good = 1;
-            long long spins = 0;
-            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                const unsigned long long a = ld_pair_dev(A.d_ring + slot + lane);
-                const unsigned long long b = ld_pair_dev(A.d_ring + slot + 64 + lane);
-                if (__all((int)((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq))) {
-                    unsigned* dw = reinterpret_cast<unsigned*>(&cmd);
-                    if (lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[lane] = (unsigned)a;
-                    if (64 + lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[64 + lane] = (unsigned)b;
-                    break;
-                }
-                const int ab = __builtin_amdgcn_readfirstlane(
-                    (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
-                const bool late = ((++spins & 63) == 0 || A.spin_ticks == 0) &&
-                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
-                if (late || ab != 0) {
-                    if (lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    good = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+    long long t_cmd = 0, t_exec = 0, t_nb = 0, n_cmd = 0;     // where the time of this workgroup goes (wave 0's clock)
+    long long t_op[4] = {0, 0, 0, 0}, n_op[4] = {0, 0, 0, 0};
+    // Wave 0 waits for two things between two commands, with ONE polling loop: that both lateral neighbours have completed
+    // the command this workgroup has just completed, and that the next command is in the ring (every pair of its slot carries
+    // its stamp) -- which it then copies into LDS for the workgroup.  Before the first command there is nobody to wait for.
+    // Returns (to wave 0's lanes) 1, or 0 when a wait ran over the time limit or another workgroup has given up.
+    auto wait_and_fetch = [&](unsigned done_seq, bool with_neighbours, long long& ticks_nb, long long& ticks_cmd) -> int {
+        const unsigned next = done_seq + 1u;
+        const size_t slot = (size_t)(next % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
+        const int other = with_neighbours ? ((lane == 0) ? left : ((lane == 1) ? right : -1)) : -1;
+        bool nb_ok = !with_neighbours;
+        long long spins = 0;
+        const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+        long long t_nb_ok = t_begin;
+        for (;;) {
+            const unsigned long long a = ld_pair_dev(A.d_ring + slot + lane);
+            const unsigned long long b = ld_pair_dev(A.d_ring + slot + 64 + lane);
+            if (!nb_ok) {
+                unsigned v = done_seq;
+                if (other >= 0) v = __hip_atomic_load(A.flags + (size_t)other * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)((int)(v - done_seq) >= 0))) { nb_ok = true; t_nb_ok = (long long)__builtin_amdgcn_s_memrealtime(); }
             }
-            if (lane == 0) lds_ok = good;
+            if (nb_ok && __all((int)((unsigned)(a >> 32) == next && (unsigned)(b >> 32) == next))) {
+                unsigned* dw = reinterpret_cast<unsigned*>(&cmd);
+                if (lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[lane] = (unsigned)a;
+                if (64 + lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[64 + lane] = (unsigned)b;
+                const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
+                ticks_nb += t_nb_ok - t_begin;
+                ticks_cmd += t_end - t_nb_ok;
+                return 1;
+            }
+            const int ab = __builtin_amdgcn_readfirstlane(
+                (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+            const bool late = ((++spins & 63) == 0 || A.spin_ticks == 0) &&
+                              (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
+            if (late || ab != 0) {
+                if (lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(1);
         }
-        __syncthreads();
-        if (lds_ok == 0) { status = 1; break; }
+    };
+    if (tw == 0) {
+        const int good = wait_and_fetch(seq - 1u, false, t_nb, t_cmd);
+        if (lane == 0) lds_ok = good;
+    }
+    __syncthreads();
+    if (lds_ok == 0) status = 1;
+    while (status == 0) {
+        const long long t1 = (long long)__builtin_amdgcn_s_memrealtime();
         const int op = uni_i(cmd.op), flags = uni_i(cmd.flags);
         if (op == NK2D_OP_EXIT) {
             if (threadIdx.x == 0)
@@ -157,41 +180,56 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
                     predict_body<E, 1>(S.A, task, lane);
                 }
         }
+        else if (op == NK2D_OP_SWEEP) {
+            const SweepArgs& S = cmd.u.sw;
+            const int nvar = S.ntasks / P.ny, nre = S.nreal / P.ny;
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) {
+                    if (nre > 0) sweep_body<E, KIND, 1>(P, S, j * nvar + tr, lane);
+                    if (nvar > nre) sweep_body<E, KIND, 1>(P, S, j * nvar + nre + tr, lane);
+                }
+        } else if (op >= NK2D_OP_ERR_RHS && op <= NK2D_OP_COPY) {
+            const StreamColumns& S = cmd.u.col;
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) {
+                    const int task = tr * P.ny + j;
+                    if (op == NK2D_OP_ERR_RHS) err_rhs_body<E, 1>(S.a, S.b, S.nv, S.h, S.out, task, lane);
+                    else if (op == NK2D_OP_ERR_RHS2) err_rhs2_body<E, KIND, 1>(P, S.a, S.b, S.c, S.d, S.nv, S.h, S.out, task, lane);
+                    else if (op == NK2D_OP_ERR_NORM) err_norm_body<E, 1>(P, S.a, S.b, S.c, S.part, task, lane);
+                    else {
+                        double v[E];
+                        load_col<E, 1>(S.a, task, lane, v);
+                        store_col<E, 1>(S.out, task, lane, v);
+                    }
+                }
+        }
         // ---- hand-over: every wave has drained its write-through stores, the workgroup publishes the command it has
-        // completed (and, where the host waits for it, stamps pinned memory) and waits for its two lateral neighbours
+        // completed (and, where the host waits for it, stamps pinned memory), waits for its two lateral neighbours and
+        // for the next command
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (A.fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
+        const long long t2 = (long long)__builtin_amdgcn_s_memrealtime();
         if (tw == 0) {
             if (lane == 0) {
                 __hip_atomic_store(A.flags + (size_t)wg * 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (flags & NK2D_CMD_NOTIFY) __hip_atomic_store(A.h_done + wg, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            const int other = (lane == 0) ? left : ((lane == 1) ? right : -1);
-            int good = 1;
-            long long spins = 0;
-            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                unsigned v = seq;
-                if (other >= 0) v = __hip_atomic_load(A.flags + (size_t)other * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((int)((int)(v - seq) >= 0))) break;
-                const int ab = __builtin_amdgcn_readfirstlane(
-                    (lane == 0) ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
-                const bool late = ((++spins & 63) == 0 || A.spin_ticks == 0) &&
-                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
-                if (late || ab != 0) {
-                    if (lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    good = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
+            const int good = wait_and_fetch(seq, true, t_nb, t_cmd);
             if (lane == 0) lds_ok = good;
         }
         __syncthreads();
         if (A.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lds_ok == 0) { status = 1; break; }
+        t_exec += t2 - t1; ++n_cmd;
+        if (op >= 2 && op <= 5) { t_op[op - 2] += t2 - t1; ++n_op[op - 2]; }
         ++seq;
+    }
+    if (A.prof && threadIdx.x == 0) {
+        unsigned long long* pr = A.prof + (size_t)wg * 12;
+        pr[0] += (unsigned long long)t_cmd; pr[1] += (unsigned long long)t_exec; pr[2] += (unsigned long long)t_nb;
+        pr[3] += (unsigned long long)n_cmd;
+        for (int i = 0; i < 4; ++i) { pr[4 + i] += (unsigned long long)t_op[i]; pr[8 + i] += (unsigned long long)n_op[i]; }
     }
     if (status != 0 && threadIdx.x == 0) {
         A.out[0] = (double)status;
@@ -210,13 +248,23 @@ struct nk2d_stream_state {
     unsigned long long* d_ring = nullptr;
     char* d_sync = nullptr;                 // abort flag at 0, workgroup flags from 4096 (one 128-byte line each)
     double* d_out = nullptr;
+    unsigned long long* d_prof = nullptr;   // [nwg][4], see StreamArgs
     double* h_out = nullptr;                // pinned [8]
     unsigned seq = 0;                       // stamp of the last command pushed
     unsigned done_upto = 0;                 // every workgroup is known to have completed this command
     std::deque<unsigned> notifies;          // commands flagged NOTIFY that have not been waited for yet
     bool running = false, lost = false;
+    bool direct = false;                    // the host writes its commands straight into d_ring (large BAR): no relay hop
     int nwg = 0, cpw = 1, nw = 1;
     int64_t launches = 0;
+    // pinned buffers for the norm partials, handed out in turn: the controller names its buffers (hPART, hPARTB, ...) and
+    // reuses a name as soon as IT is done with it -- also when a command writing there was dropped unread (an iteration
+    // queued ahead of a verdict) and may not have run yet.  A launch boundary used to order that; here every command with
+    // partials gets the next buffer of a ring, its name resolves to that buffer until the name is used again, and a buffer
+    // comes round again only NK2D_PART_RING commands with partials later.
+    double* pbuf[NK2D_PART_RING] = {nullptr};
+    int pnext = 0;
+    struct { const double* name; double* buf; } pmap[NK2D_PART_RING] = {};
 };
 
 // ONE command-stream kernel at a time in a process: two of them do not fit the chip together (a kernel holds a SIMD per
@@ -247,7 +295,7 @@ unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq
 // decisions, double precision factor tables, and a grid whose workgroups are all resident at once
 int nk2d_stream_eligible(const nk2d_ctx* c) {
     if (!c->stream_years || c->stream_lost >= 2 || c->kind != 0 || c->norm_hook || c->factor_fp32 || c->device_ctl != 0) return 0;
-    if (c->team != 0 || c->xcd_map || c->prefactor) return 0;
+    if (c->xcd_map || c->prefactor) return 0;     // (the launch shape -- option "team" -- is not the stream kernel's concern)
     return 1;
 }
 
@@ -289,9 +337,21 @@ static int stream_alloc(nk2d_ctx* c) {
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_done, sizeof(unsigned) * S->nwg));
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_status, sizeof(unsigned) * 16));
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_out, sizeof(double) * 8));
-    NK2D_CHECK(c, hipMalloc((void**)&S->d_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
+    for (int i = 0; i < NK2D_PART_RING; ++i) NK2D_CHECK(c, hipHostMalloc((void**)&S->pbuf[i], sizeof(double) * c->ncol));
+    // Where the device's memory is visible to the host (large BAR), the ring in HBM is a fine-grained allocation the host
+    // writes its commands into directly: the pairs cross PCIe once, as posted writes, instead of being fetched by the relay
+    // wave's reads.  Otherwise (or with NK2D_STREAM_RELAY=1) the relay.
+    S->direct = prop.isLargeBar != 0 && std::getenv("NK2D_STREAM_RELAY") == nullptr;
+    if (S->direct) {
+        const hipError_t rc = hipExtMallocWithFlags((void**)&S->d_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS,
+                                                    hipDeviceMallocFinegrained);
+        if (rc != hipSuccess) { (void)hipGetLastError(); S->direct = false; S->d_ring = nullptr; }
+    }
+    if (!S->direct) NK2D_CHECK(c, hipMalloc((void**)&S->d_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
     NK2D_CHECK(c, hipMalloc((void**)&S->d_sync, 4096 + (size_t)S->nwg * 128));
     NK2D_CHECK(c, hipMalloc((void**)&S->d_out, sizeof(double) * 8));
+    NK2D_CHECK(c, hipMalloc((void**)&S->d_prof, sizeof(unsigned long long) * 12 * S->nwg));
+    NK2D_CHECK(c, hipMemset(S->d_prof, 0, sizeof(unsigned long long) * 12 * S->nwg));
     std::memset(S->h_ring, 0, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS);
     std::memset(S->h_done, 0, sizeof(unsigned) * S->nwg);
     std::memset(S->h_status, 0, sizeof(unsigned) * 16);
@@ -300,6 +360,8 @@ static int stream_alloc(nk2d_ctx* c) {
     NK2D_CHECK(c, hipMemset(S->d_out, 0, sizeof(double) * 8));
     return 0;
 }
+
+int nk2d_stream_ready(nk2d_ctx* c) { return stream_alloc(c); }
 
 void nk2d_stream_free(nk2d_ctx* c) {
     nk2d_stream_state* S = c->strm;
@@ -310,9 +372,12 @@ void nk2d_stream_free(nk2d_ctx* c) {
     if (S->h_done) (void)hipHostFree(S->h_done);
     if (S->h_status) (void)hipHostFree(S->h_status);
     if (S->h_out) (void)hipHostFree(S->h_out);
+    for (int i = 0; i < NK2D_PART_RING; ++i)
+        if (S->pbuf[i]) (void)hipHostFree(S->pbuf[i]);
     if (S->d_ring) (void)hipFree(S->d_ring);
     if (S->d_sync) (void)hipFree(S->d_sync);
     if (S->d_out) (void)hipFree(S->d_out);
+    if (S->d_prof) (void)hipFree(S->d_prof);
     delete S;
     c->strm = nullptr;
 }
@@ -320,9 +385,10 @@ void nk2d_stream_free(nk2d_ctx* c) {
 static void ring_write(nk2d_stream_state* S, unsigned seq, const StreamCmd& cmd) {
     unsigned dw[NK2D_CMD_DWORDS] = {0};
     std::memcpy(dw, &cmd, sizeof(StreamCmd));
-    unsigned long long* slot = S->h_ring + (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
+    unsigned long long* slot = (S->direct ? S->d_ring : S->h_ring) + (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
     for (int k = 0; k < NK2D_CMD_DWORDS; ++k)
         __atomic_store_n(slot + k, ((unsigned long long)seq << 32) | dw[k], __ATOMIC_RELAXED);
+    if (S->direct) __builtin_ia32_sfence();      // (write-combined stores over the BAR: out of the CPU's buffers now)
 }
 
 // start the kernel (it will find the commands pushed from now on)
@@ -330,7 +396,7 @@ static int stream_start(nk2d_ctx* c) {
     nk2d_stream_state* S = c->strm;
     turn_take();
     StreamArgs A = {};
-    A.h_ring = S->h_ring; A.d_ring = S->d_ring;
+    A.h_ring = S->direct ? nullptr : S->h_ring; A.d_ring = S->d_ring;
     A.abort_flag = (int*)S->d_sync;
     A.flags = (unsigned*)(S->d_sync + 4096);
     A.h_done = S->h_done; A.h_status = S->h_status; A.out = S->d_out;
@@ -338,6 +404,7 @@ static int stream_start(nk2d_ctx* c) {
     A.nwg = S->nwg; A.cpw = S->cpw;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
+    A.prof = S->d_prof;
     DevP P = make_devp(c);
     P.guard = nullptr;
     const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr);
@@ -391,15 +458,47 @@ int nk2d_stream_wait(nk2d_ctx* c, unsigned seq) {
 // 832 waves' stores on their way over PCIe.
 static const unsigned long long kPoison = 0x7FF8DEADBEEFCAFEull;
 
-void nk2d_stream_poison(double* part, int n) {
-    unsigned long long* p = reinterpret_cast<unsigned long long*>(part);
-    for (int i = 0; i < n; ++i) __atomic_store_n(p + i, kPoison, __ATOMIC_RELAXED);
+// the buffer the next command with partials writes to, under the controller's name for it; marked
+double* nk2d_stream_part_take(nk2d_ctx* c, const double* name) {
+    nk2d_stream_state* S = c->strm;
+    double* buf = S->pbuf[S->pnext];
+    S->pnext = (S->pnext + 1) % NK2D_PART_RING;
+    int slot = -1;
+    for (int i = 0; i < NK2D_PART_RING; ++i) {
+        if (S->pmap[i].buf == buf) { S->pmap[i].name = nullptr; S->pmap[i].buf = nullptr; }   // (whoever held it has long read it)
+        if (S->pmap[i].name == name) slot = i;
+    }
+    if (slot < 0)
+        for (int i = 0; i < NK2D_PART_RING && slot < 0; ++i)
+            if (S->pmap[i].name == nullptr) slot = i;
+    S->pmap[slot].name = name;
+    S->pmap[slot].buf = buf;
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    for (int i = 0; i < c->ncol; ++i) __atomic_store_n(p + i, kPoison, __ATOMIC_RELAXED);
+    return buf;
 }
 
-int nk2d_stream_wait_part(nk2d_ctx* c, const double* part, int n) {
+// the buffer the controller's name stands for right now (the name itself where no command has taken it)
+const double* nk2d_stream_part_named(const nk2d_ctx* c, const double* name) {
+    const nk2d_stream_state* S = c->strm;
+    if (S)
+        for (int i = 0; i < NK2D_PART_RING; ++i)
+            if (S->pmap[i].name == name && S->pmap[i].buf) return S->pmap[i].buf;
+    return name;
+}
+
+// a launch writes partials to the name itself: the name stands for itself again
+void nk2d_stream_part_forget(nk2d_ctx* c, const double* name) {
+    nk2d_stream_state* S = c->strm;
+    if (!S) return;
+    for (int i = 0; i < NK2D_PART_RING; ++i)
+        if (S->pmap[i].name == name || name == nullptr) { S->pmap[i].name = nullptr; S->pmap[i].buf = nullptr; }   // (null: every name)
+}
+
+int nk2d_stream_wait_part(nk2d_ctx* c, const double* name, int n) {
     nk2d_stream_state* S = c->strm;
     if (!S || S->lost) return NK2D_RC_STREAM_LOST;
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(part);
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(nk2d_stream_part_named(c, name));
     const auto t0 = std::chrono::steady_clock::now();
     const double limit_s = 1.0e-3 * c->barrier_timeout_ms + 1.0;
     long long spins = 0;
@@ -475,5 +574,20 @@ int nk2d_stream_end(nk2d_ctx* c) {
         NK2D_CHECK(c, hipMemset(S->d_out, 0, sizeof(double) * 8));
         return NK2D_RC_STREAM_LOST;
     }
+    return 0;
+}
+
+// where the workgroups' time went since the context was created: microseconds per workgroup (mean over the workgroups)
+// waiting for commands, executing them, waiting for the lateral neighbours; commands per workgroup
+// out[12]: 0..2 as above, 3 commands, 4..7 microseconds executing SETUP / NEWTON / ERR / BOUNDARY commands, 8..11 their counts
+int nk2d_stream_profile(nk2d_ctx* c, double* out12) {
+    nk2d_stream_state* S = c->strm;
+    for (int i = 0; i < 12; ++i) out12[i] = 0.0;
+    if (!S) return 0;
+    std::vector<unsigned long long> h((size_t)12 * S->nwg);
+    NK2D_CHECK(c, hipMemcpy(h.data(), S->d_prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    for (int wg = 0; wg < S->nwg; ++wg)
+        for (int i = 0; i < 12; ++i) out12[i] += (double)h[(size_t)12 * wg + i];
+    for (int i = 0; i < 12; ++i) out12[i] *= ((i < 3 || (i >= 4 && i < 8)) ? 0.01 : 1.0) / S->nwg;      // ticks of 10 ns -> us
     return 0;
 }

@@ -30,6 +30,19 @@ for n in sizes:
         wall, st, cmds, kl = best
         print(f"{n}^2 stream_years={mode}: {wall:.4f} s  steps {st['nsteps']} rejected {st['nrejected']} newton {st['nnewton']} "
               f"launches {st['nlaunch']} commands {cmds} kernel starts {kl} timeouts {eng.counter('stream_timeouts')}", flush=True)
+    pr = [eng.counter(f"stream_prof_{i}") for i in range(12)]
+    print(f"{n}^2 per workgroup over the stream years: waiting for commands {pr[0] / 1e3:.1f} ms, executing {pr[1] / 1e3:.1f} ms, "
+          f"waiting for neighbours {pr[2] / 1e3:.1f} ms, {pr[3]} commands", flush=True)
+    for k, name in enumerate(("SETUP", "NEWTON", "ERR", "BOUNDARY")):
+        if pr[8 + k]:
+            print(f"    {name}: {pr[8 + k]} commands, {pr[4 + k] / max(pr[8 + k], 1):.2f} us each", flush=True)
+    print("    host controller: " + ", ".join(f"{k} {eng.counter(k)}" for k in ("spec_launches_dropped", "spec_front_launches_dropped",
+                                                                               "err_estimates_queued", "err_estimates_dropped")), flush=True)
     same = np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     print(f"{n}^2 bit-identical: {same}; speed-up {res[0][0][0] / res[1][0][0]:.2f}x", flush=True)
+    if n <= 128:
+        eng.set_option("stream_years", 0)
+        eng.set_option("device_ctl", 3)
+        best = min(eng.comp_fcn(x)[1]["seconds"] for _ in range(3))
+        print(f"{n}^2 the one-launch year with the controller on the device (device_ctl 3): {best:.4f} s", flush=True)
     eng.close()
