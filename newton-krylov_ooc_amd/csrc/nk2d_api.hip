@@ -119,9 +119,9 @@ extern "C" void* nk2d_stream(nk2d_ctx* ctx) { return ctx ? (void*)nk2d_s(ctx) : 
 extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     const std::string key(name ? name : "");
     if (key == "device_ctl") {
-        if (value != 0.0 && value != 1.0 && value != 2.0 && value != 3.0)
-            return nk2d_fail(c, "nk2d_set_option: device_ctl must be 0, 1, 2 or 3");
-        c->device_ctl = (int)value;
+        // (rounds 1-3 had Newton decisions on the device -- 1, 2 -- and a one-launch year with the whole controller on the
+        // device -- 3; all three lost to the host's controller driving ONE resident kernel, nk2d_stream.h, and are gone)
+        if ((int)value != 0) return nk2d_fail(c, "nk2d_set_option: device_ctl 1, 2 and 3 no longer exist (the controller is the host's; see option stream_years)");
         return 0;
     }
     if (key == "jac_fresh") { c->jac_fresh = value != 0.0; return 0; }
@@ -526,7 +526,7 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_cache_after = 0;
     c->strm = nullptr;
     c->spec_bias = 1.0;
-    c->stream_years = 0;
+    c->stream_years = 1;      // free-running years as command streams where eligible (bit 2: frozen years too)
     c->stream_on = 0;
     c->stream_lost = 0;
     c->stream_cmds = c->stream_launches = c->stream_timeouts = c->stream_years_run = 0;
@@ -539,13 +539,9 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->STEP_PART = nullptr;
     c->step_part_rows = 0;
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
-    NK2D_TRY(dev_alloc(c, &c->DCTL, (size_t)8));
-    NK2D_TRY(dev_alloc(c, &c->ICTL, (size_t)8));
-    NK2D_CHECK(c, hipHostMalloc((void**)&c->hCTL, 128));
-    NK2D_CHECK(c, hipHostMalloc((void**)&c->hSNAP, 8 * 128));
     for (int i = 0; i < 8; ++i) NK2D_CHECK(c, hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming));
+    c->snap_ready = 1;
     c->cur_guard = nullptr;
-    c->device_ctl = 0;
     c->jac_fresh = 1;     // (0 = SciPy's reuse heuristic)
     c->growth_cap = 0.0;
     c->hist_n = 0;
@@ -643,8 +639,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->pc_refine = 1;
     c->st = nk2d_stats();
     c->prof_every = 0;
-    c->hSNAP = nullptr;
-    c->hCTL = nullptr;
+    c->snap_ready = 0;
     c->prof_used = 0;
     c->prof_ms_sum = 0.0;
     c->prof_overhead_ms = 0.0;
@@ -708,13 +703,9 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->hPARTC) (void)hipHostFree(c->hPARTC);
     if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
     if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
-    if (c->hCTL) (void)hipHostFree(c->hCTL);
-    if (c->hSNAP) {
-        (void)hipHostFree(c->hSNAP);
+    if (c->snap_ready) {
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->snap_ev[i]);
     }
-    if (c->DCTL) (void)hipFree(c->DCTL);
-    if (c->ICTL) (void)hipFree(c->ICTL);
     if (c->stream_) (void)hipStreamDestroy(c->stream_);
     delete c;
 }
@@ -985,6 +976,7 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     }
     else if (key == "frozen_launch_us") v = c->frozen_launch_us;
     else if (key == "frozen_cache_pending") v = nk2d_frozen_cache_pending(c);
+    else if (key == "frozen_cache_bytes") v = nk2d_frozen_cache_bytes(c);
     else if (key == "frozen_fallbacks") v = c->frozen_fallbacks;
     else if (key == "frozen_resumes") v = c->frozen_resumes;
     else if (key == "spec_launches_dropped") v = c->cnt_spec_dropped;

@@ -1854,29 +1854,6 @@ static inline void fill_fused_args(nk2d_ctx* c, FusedArgs& A, bool do_stage, boo
 // =================================================================================================
 #define NK2D_SPIN_LIMIT 4000000
 
-struct YearArgs {
-    double *Y, *YOLD, *F, *Z, *ZP, *ZN, *W;
-    double *BR, *BCR, *BCI, *XR[2], *XCR[2], *XCI[2], *TMP;
-    double* KV[4];
-    SweepArgs fac;             // Jacobian planes + factor pointers (the other members are set per phase)
-    double* PART;              // [2][ncol]: norm partials, the two halves alternate from one reduction to the next
-    double t0, t1, h_abs0, max_step, newton_tol, n_total, growth_cap;
-    int jac_fresh, f32;
-    int jac_stage;             // >= 0: Jacobian of an attempt from the plane of this stage time (option "jac_stage")
-    double bld_t[4], bld_f[4], bldmin, vy0, vy1, hw;
-    const int* m_tab;          // sweeps for the shift bucket k (host: nk2d_sweeps_for), n_tab entries
-    int n_tab;
-    double rho_c0, rho_dlog;
-    unsigned* arrive;          // grid barrier arrival counter (zeroed by the host)
-    int* abort_flag;
-    double* out;               // [32]: status, t, counters, swap parities, bytes
-    double* record;            // accepted steps [cap][NK2D_SCHED_WIDTH] or null
-    double fingerprint;        // of the context (recorded with every step)
-    long long record_cap;
-    long long spin_ticks;      // longest wait at a grid barrier, in ticks of s_memrealtime (100 MHz)
-    int fences;                // 1: agent-scope release / acquire fences around every grid barrier (option "year_fences")
-};
-
 // Arrival counter in NK2D_BAR_SHARDS shards, each on a 128-byte line of its own: an agent-scope atomic executes at
 // the memory side and adds to ONE address serialise (MI355X_MICROARCH.md, global atomics: ~50 ns each) -- with 200
 // workgroups on one counter the arrivals alone cost 10 us.  A workgroup adds to shard (blockIdx & 31); the polling
@@ -1994,49 +1971,6 @@ struct NeighbourSync {
         return *lds_ok != 0;
     }
 };
-
-// sum of the ncol per-column partials in the association of nk2d_part_sum / k_reduce (256 strided
-// accumulators, then a binary tree), identical in every wave
-__device__ __forceinline__ double year_part_sum(const double* part, int n, int lane) {
-    double acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        acc[q] = 0.0;
-        for (int i = lane + 64 * q; i < n; i += NK2D_BLOCK) acc[q] += ld_mp<1>(part + i);
-    }
-    acc[0] += acc[2];   // sh[t] += sh[t + 128]
-    acc[1] += acc[3];
-    double v = acc[0] + acc[1];   // sh[t] += sh[t + 64]
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return __shfl(v, 0, 64);
-}
-
-__device__ __forceinline__ double year_interp4(const double* xp, const double* fp, double x) {
-    if (x > xp[3]) return fp[3];
-    if (x < xp[0]) return fp[0];
-    int j = 0;
-    while (j + 1 < 4 && xp[j + 1] <= x) ++j;
-    if (j == 3 || xp[j] == x) return fp[j];
-    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-    return slope * (x - xp[j]) + fp[j];
-}
-
-__device__ __forceinline__ int year_sweeps_for(const YearArgs& A, double c_real) {
-    if (A.n_tab <= 0) return 1;
-    const double pos = log10(c_real / A.rho_c0) / A.rho_dlog;
-    int k = (int)floor(pos);
-    if (k < 0) return 400;
-    if (k >= A.n_tab) k = A.n_tab - 1;
-    return A.m_tab[k];
-}
-
-__device__ __forceinline__ double year_predict_factor(double h_abs, bool has_h_old, double h_abs_old, double err,
-                                                      bool has_err_old, double err_old) {
-    double mult = 1.0;
-    if (has_err_old && has_h_old && err != 0.0) mult = h_abs / h_abs_old * pow(err_old / err, 0.25);
-    return fmin(1.0, mult) * pow(err, -0.25);
-}
 
 // values every lane of every wave holds identically: tell the compiler (scalar registers, uniform branches)
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -2312,3 +2246,4 @@ __device__ __forceinline__ void step_tail_body(const double* __restrict__ y, con
         store_col<E, MP>(wout + r * nv, task, lane, wv);
     }
 }
+

@@ -122,20 +122,13 @@ struct nk2d_ctx {
     // touches the contraction rate (nk2d_set_option "factor_fp32")
     float *FR32_INV, *FC32_INVR, *FC32_INVI, *FR32_TAB, *FC32_TABR, *FC32_TABI;
     int factor_fp32;
-    // device-side Newton control block (see nk2d_kernels.hip, k_reduce_newton):
-    //   DCTL: [0] dW_norm_old [1] rate [2] dW_norm [3] err_sum [4] newton_tol [5] 3n [6] n
-    //   ICTL: [0] k [1] has_old [2] has_rate [3] done [4] converged [5] skip_err [6] n_iter
-    double* DCTL;
-    int* ICTL;
-    double* hCTL;           // pinned mirror: 8 doubles followed by 8 ints
-    double* hSNAP;          // pinned snapshots of the control block, one per Newton iteration
-    hipEvent_t snap_ev[8];
+    hipEvent_t snap_ev[8];  // "the launch that carries these partials is queued" (host-side decisions by launches)
+    int snap_ready;
     const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
     int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
     int jac_fresh;          // 1: re-evaluate the Jacobian at every step start (see nk2d_set_option)
     double growth_cap;      // > 0: largest step growth factor after a step whose Newton iteration failed at first
                             // (nk2d_set_option "growth_cap"; 0 = SciPy: no memory of the failure)
-    int device_ctl;         // 1: Newton convergence decisions on the device (nk2d_set_option)
     // reductions
     double* PART;    // per-task partials
     double* PART2;   // second buffer [ncol]
@@ -441,7 +434,7 @@ __device__ __forceinline__ void shift_next(const double (&a)[E], double (&o)[E],
 // Memory policy MP of the column accessors.  0: plain loads and stores -- one kernel launch per phase, the
 // launch boundary orders everything.  1: agent-coherent accesses (relaxed agent-scope atomics = `sc1` loads and
 // stores on gfx950: the load bypasses the CU's L1, the store is written through) for data that OTHER workgroups
-// of a persistent launch read or write between two grid barriers (k_year_persistent): an array accessed with
+// of a persistent launch read or write between two grid barriers (the one-launch years and the command stream): an array accessed with
 // MP = 1 anywhere in such a launch must be accessed with MP = 1 everywhere in it.
 // MP = 1: data other workgroups anywhere on the chip exchange inside a launch -- write-through (sc1) stores, L1-bypassing
 // (sc1) loads.  MP = 2: the same between workgroups that all sit on ONE XCD -- plain stores (they reach, and stay in, the
@@ -634,6 +627,7 @@ int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, d
 double nk2d_fingerprint(const nk2d_ctx* c);
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows = nullptr);
 int nk2d_frozen_cache_pending(const nk2d_ctx* c);
+int64_t nk2d_frozen_cache_bytes(const nk2d_ctx* c);
 void nk2d_frozen_cache_free(nk2d_ctx* c);
 int nk2d_prof_window_begin(nk2d_ctx* c);
 int nk2d_prof_window_end(nk2d_ctx* c);
@@ -652,14 +646,6 @@ int nk2d_r_wnorm(nk2d_ctx* c, const double* a, const double* b, double ca, doubl
 int nk2d_r_axpy(nk2d_ctx* c, const double* a, double s, const double* b, double* out);
 int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out);
 int nk2d_r_dense(nk2d_ctx* c, double x, double* out);
-int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total);
-int nk2d_r_reduce_newton(nk2d_ctx* c);
-int nk2d_r_reduce_err(nk2d_ctx* c);
-int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8);
-int nk2d_r_ctl_snapshot(nk2d_ctx* c, int slot);
-int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8);
-int nk2d_year_persistent(nk2d_ctx* c, double h_abs0, double newton_tol, double max_step, double n_total,
-                         double* record, int64_t record_cap, int64_t* record_n);
 // nk2d_radau.hip
 int nk2d_hist_sample(nk2d_ctx* c, double t_old, double t_new, bool first);
 int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, const double* replay,

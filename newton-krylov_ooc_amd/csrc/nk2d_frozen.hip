@@ -272,6 +272,14 @@ int nk2d_frozen_cache_pending(const nk2d_ctx* c) {
     return (fc && fc->alloc_state.load() == 1) ? 1 : 0;
 }
 
+// bytes of HBM the schedule cache of this context holds right now
+int64_t nk2d_frozen_cache_bytes(const nk2d_ctx* c) {
+    const nk2d_frozen_cache* fc = (const nk2d_frozen_cache*)c->frozen_cache;
+    if (!fc || !fc->slab) return 0;
+    const size_t ntab = (size_t)c->ncol * NK2D_TAB * 64;
+    return (int64_t)(8 * fc->cap_rows * (3 * c->kv_len + 5 * c->np + 3 * c->nv + 3 * ntab));
+}
+
 void nk2d_frozen_cache_free(nk2d_ctx* c) {
     nk2d_frozen_cache* fc = (nk2d_frozen_cache*)c->frozen_cache;
     if (!fc) return;

@@ -376,92 +376,6 @@ int nk2d_k_reduce(nk2d_ctx* c, int ntasks, int nout, double* host_out) {
     return 0;
 }
 
-__global__ void k_ctl_reset(double* __restrict__ d, int* __restrict__ ic, double tol, double n_total) {
-    if (threadIdx.x == 0) {
-        d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 0.0; d[4] = tol; d[5] = 3.0 * n_total; d[6] = n_total;
-        ic[0] = 0; ic[1] = 0; ic[2] = 0; ic[3] = 0; ic[4] = 0; ic[5] = 1; ic[6] = 0;
-    }
-}
-
-__global__ void k_reduce_newton(const double* __restrict__ part, int ntasks, double* __restrict__ d, int* __restrict__ ic) {
-    __shared__ double sh[NK2D_BLOCK];
-    if (ic[3] != 0) return;  // already decided
-    const double sum = block_sum(part, ntasks, sh);
-    if (threadIdx.x != 0) return;
-    const int k = ic[0];
-    const double tol = d[4];
-    const double dW_norm = sqrt(sum) / sqrt(d[5]);
-    d[2] = dW_norm;
-    bool has_rate = ic[2] != 0;
-    double rate = d[1];
-    if (!(dW_norm == dW_norm)) { ic[3] = 1; ic[6] = k + 1; return; }  // NaN: diverged
-    if (ic[1] != 0) { rate = dW_norm / d[0]; has_rate = true; d[1] = rate; ic[2] = 1; }
-    if (has_rate) {
-        double pw = 1.0;
-        for (int i = 0; i < 6 - k; ++i) pw *= rate;  // rate ** (NEWTON_MAXITER - k)
-        if (rate >= 1.0 || pw / (1.0 - rate) * dW_norm > tol) { ic[3] = 1; ic[6] = k + 1; return; }
-    }
-    if (dW_norm == 0.0 || (has_rate && rate / (1.0 - rate) * dW_norm < tol)) {
-        ic[3] = 1; ic[4] = 1; ic[5] = 0; ic[6] = k + 1;
-        return;
-    }
-    d[0] = dW_norm;
-    ic[1] = 1;
-    ic[0] = k + 1;
-    if (k + 1 >= 6) { ic[3] = 1; ic[6] = 6; }
-}
-
-__global__ void k_reduce_err(const double* __restrict__ part, int ntasks, double* __restrict__ d, const int* __restrict__ ic) {
-    __shared__ double sh[NK2D_BLOCK];
-    if (ic[5] != 0) return;
-    const double sum = block_sum(part, ntasks, sh);
-    if (threadIdx.x == 0) d[3] = sum;
-}
-
-int nk2d_r_ctl_reset(nk2d_ctx* c, double newton_tol, double n_total) {
-    hipLaunchKernelGGL(k_ctl_reset, dim3(1), dim3(64), 0, nk2d_s(c), c->DCTL, c->ICTL, newton_tol, n_total);
-    NK2D_CHECK(c, hipGetLastError());
-    c->st.nlaunch++;
-    return 0;
-}
-int nk2d_r_reduce_newton(nk2d_ctx* c) {
-    hipLaunchKernelGGL(k_reduce_newton, dim3(1), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->PART, c->ncol, c->DCTL, c->ICTL);
-    NK2D_CHECK(c, hipGetLastError());
-    c->st.nlaunch++;
-    return 0;
-}
-int nk2d_r_reduce_err(nk2d_ctx* c) {
-    hipLaunchKernelGGL(k_reduce_err, dim3(1), dim3(NK2D_BLOCK), 0, nk2d_s(c), c->PART, c->ncol, c->DCTL, c->ICTL);
-    NK2D_CHECK(c, hipGetLastError());
-    c->st.nlaunch++;
-    return 0;
-}
-int nk2d_r_ctl_read(nk2d_ctx* c, double* dctl8, int* ictl8) {
-    NK2D_CHECK(c, hipMemcpyAsync(c->hCTL, c->DCTL, 64, hipMemcpyDeviceToHost, nk2d_s(c)));
-    NK2D_CHECK(c, hipMemcpyAsync(c->hCTL + 8, c->ICTL, 32, hipMemcpyDeviceToHost, nk2d_s(c)));
-    NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
-    std::memcpy(dctl8, c->hCTL, 64);
-    std::memcpy(ictl8, c->hCTL + 8, 32);
-    return 0;
-}
-
-// copy of the control block into pinned slot `slot`, in stream order, plus an event the host
-// can wait on while later (speculative) work is already queued
-int nk2d_r_ctl_snapshot(nk2d_ctx* c, int slot) {
-    double* dst = c->hSNAP + (size_t)slot * 16;
-    NK2D_CHECK(c, hipMemcpyAsync(dst, c->DCTL, 64, hipMemcpyDeviceToHost, nk2d_s(c)));
-    NK2D_CHECK(c, hipMemcpyAsync(dst + 8, c->ICTL, 32, hipMemcpyDeviceToHost, nk2d_s(c)));
-    NK2D_CHECK(c, hipEventRecord(c->snap_ev[slot], nk2d_s(c)));
-    return 0;
-}
-int nk2d_r_ctl_wait(nk2d_ctx* c, int slot, double* dctl8, int* ictl8) {
-    NK2D_CHECK(c, hipEventSynchronize(c->snap_ev[slot]));
-    const double* src = c->hSNAP + (size_t)slot * 16;
-    std::memcpy(dctl8, src, 64);
-    std::memcpy(ictl8, src + 8, 32);
-    return 0;
-}
-
 template <int E>
 __global__ void k_predict(int ncol, PredictArgs A) {
     TASK_PROLOGUE(ncol)
@@ -988,6 +902,15 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
         const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
         c->fused_bytes_all += 8.0 * (3.0 * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N);     // planes read, tables written
     }
+    if (c->stream_on) {
+        if (F.mode != 0) return nk2d_fail(c, "nk2d_r_newton_final: option \"prefactor\" is not for command streams");
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_NEWTON_FINAL;
+        cmd.flags = do_factor ? NK2D_CMD_FACTOR : 0;
+        cmd.u.fn.nf = A; cmd.u.fn.fin = Fin; cmd.u.fn.V = V; cmd.u.fn.J = J;
+        NK2D_TRY(nk2d_stream_push(c, cmd, false));
+        c->st.nlaunch--;
+    } else {
     const dim3 grid(Fin.nblk_cols + (F.mode == 0 ? nk2d_grid(c->ny * 3) : (F.mode == 2 ? nk2d_grid(2 * c->ncol) : 0)));
 #define NK2D_FINAL_LAUNCH(KK)                                                                                              \
     if (do_factor) {                                                                                                       \
@@ -1013,6 +936,7 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     } else if (c->kind == 2) { NK2D_FINAL_LAUNCH(2) } else { NK2D_FINAL_LAUNCH(0) }
 #undef NK2D_FINAL_LAUNCH
     NK2D_CHECK(c, hipGetLastError());
+    }
     std::swap(c->Y, c->YOLD);
     if (do_stage) std::swap(c->Z, c->ZN);
     for (int i = 0; i < 3; ++i) std::swap(c->KV[i], c->KVN[i]);
@@ -1226,3 +1150,4 @@ int nk2d_r_final(nk2d_ctx* c, const double* y0, double* out) {
     c->st.nlaunch++;
     return 0;
 }
+

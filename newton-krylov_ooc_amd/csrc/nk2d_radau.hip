@@ -45,7 +45,6 @@ struct Ctl {
     double dense_t_old, dense_h;
     double newton_tol, max_step;
     int m_real, m_cplx;  // sweeps per solve for the current h_lu
-    int device_ctl;      // 0 host decisions, 1 device decisions + one read-back per attempt, 2 pipelined
     double n_total;      // number of unknowns (tc*nz*ny)
     // the set-up of the next step's first attempt (stage planes, predicted stage values) and, where due, the Jacobian
     // at its start were already queued with the commit of the step before (nk2d_r_step_boundary): for this (t, h)
@@ -391,94 +390,6 @@ int newton(Ctl& s, double h, int force_iters, bool* converged, int* n_iter, doub
     return 0;
 }
 
-// One step attempt queued without any host round trip (radau.py:445-483): Z0 from the
-// dense output, up to NEWTON_MAXITER simplified-Newton iterations whose convergence /
-// divergence tests run on the device (k_reduce_newton), and -- if the iteration converged --
-// the error estimate.  Kernels after the decision return at entry.  ONE read-back at the
-// end delivers (converged, n_iter, rate, sum((error/scale)^2)).
-int attempt(Ctl& s, double t, double h, bool* converged, int* n_iter, double* rate, bool* have_rate,
-            double* err_sum, int* err_buf) {
-    nk2d_ctx* c = s.c;
-    const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
-    c->cur_guard = nullptr;
-    NK2D_TRY(predict(s, t, h));
-    NK2D_TRY(nk2d_r_ctl_reset(c, s.newton_tol, s.n_total));
-    c->cur_guard = c->ICTL + 3;  // done
-    for (int k = 0; k < NEWTON_MAXITER; ++k) {
-        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
-        NK2D_TRY(nk2d_r_reduce_newton(c));
-    }
-    c->cur_guard = c->ICTL + 5;  // skip_err (cleared by a converged Newton iteration)
-    if (s.m_real <= 2) {
-        NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, err_buf, nullptr));
-    } else {
-        NK2D_TRY(nk2d_r_err_rhs(c, h));
-        NK2D_TRY(solve_systems(s, true, false, err_buf));
-        NK2D_TRY(nk2d_r_err_norm(c, c->XR[*err_buf]));
-    }
-    NK2D_TRY(nk2d_r_reduce_err(c));
-    c->cur_guard = nullptr;
-    double d[8];
-    int ic[8];
-    NK2D_TRY(nk2d_r_ctl_read(c, d, ic));
-    *converged = ic[4] != 0;
-    *n_iter = ic[6];
-    *rate = d[1];
-    *have_rate = ic[2] != 0;
-    *err_sum = d[3];
-    c->st.nfev += 3 * (int64_t)ic[6];
-    c->st.nnewton += ic[6];
-    return 0;
-}
-
-// Pipelined variant: the decisions stay on the device, but the host follows them one Newton
-// iteration behind -- iteration k+1 is queued (guarded by the `done` flag) BEFORE the host waits
-// for the verdict on iteration k, so the wake-up latency of the read-back is hidden behind
-// GPU work and at most one iteration's worth of launches returns at entry.
-int attempt_pipelined(Ctl& s, double t, double h, bool* converged, int* n_iter, double* rate, bool* have_rate) {
-    nk2d_ctx* c = s.c;
-    const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
-    c->cur_guard = nullptr;
-    NK2D_TRY(predict(s, t, h));
-    NK2D_TRY(nk2d_r_ctl_reset(c, s.newton_tol, s.n_total));
-    c->cur_guard = c->ICTL + 3;  // done
-    double d[8];
-    int ic[8] = {0};
-    double spec_bytes = 0.0;
-    int64_t spec_launches = 0;
-    auto queue_iteration = [&](int k) -> int {
-        const double b0 = c->sweep_bytes;
-        const int64_t l0 = c->sweep_launches;
-        NK2D_TRY(newton_iteration(s, mreal, mcr, mci));
-        NK2D_TRY(nk2d_r_reduce_newton(c));
-        NK2D_TRY(nk2d_r_ctl_snapshot(c, k));
-        spec_bytes = c->sweep_bytes - b0;
-        spec_launches = c->sweep_launches - l0;
-        return 0;
-    };
-    NK2D_TRY(queue_iteration(0));
-    for (int k = 0; k < NEWTON_MAXITER; ++k) {
-        const bool queued_next = k + 1 < NEWTON_MAXITER;
-        if (queued_next) NK2D_TRY(queue_iteration(k + 1));
-        NK2D_TRY(nk2d_r_ctl_wait(c, k, d, ic));
-        if (ic[3] != 0) {
-            if (queued_next) {  // the iteration queued ahead returns at entry: not executed work
-                c->sweep_bytes -= spec_bytes;
-                c->st.nsolve -= 2;
-            }
-            break;
-        }
-    }
-    c->cur_guard = nullptr;
-    *converged = ic[4] != 0;
-    *n_iter = ic[6];
-    *rate = d[1];
-    *have_rate = ic[2] != 0;
-    c->st.nfev += 3 * (int64_t)ic[6];
-    c->st.nnewton += ic[6];
-    return 0;
-}
-
 double predict_factor(double h_abs, bool has_h_old, double h_abs_old, double err, bool has_err_old, double err_old) {
     double mult = 1.0;
     if (has_err_old && has_h_old && err != 0.0) mult = h_abs / h_abs_old * std::pow(err_old / err, 0.25);
@@ -544,7 +455,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         const bool jac_needs_state0 = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
         // (modules whose Jacobian reads the state: only with option "jac_stage_state" -- the mixing plane of the stage time,
         // the state of the step start, in a launch of its own)
-        const bool jac_at_stage = c->jac_stage >= 0 && c->jac_fresh && s.device_ctl == 0 && (!jac_needs_state0 || c->jac_stage_state);
+        const bool jac_at_stage = c->jac_stage >= 0 && c->jac_fresh && (!jac_needs_state0 || c->jac_stage_state);
         const int jst_inlaunch = (jac_at_stage && !jac_needs_state0) ? c->jac_stage : -1;
         if (c->jac_fresh && !s.current_jac && !jac_at_stage) {
             // evaluating J costs two small launches here (SciPy pays a Python double loop and two
@@ -574,7 +485,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             if (s.pre_setup && s.pre_t == t && s.pre_h == h) {
                 predicted = true;            // queued with the commit of the step before
                 jac_done = s.pre_jac;
-            } else if (s.device_ctl == 0 && s.have_dense) {
+            } else if (s.have_dense) {
                 NK2D_TRY(setup_attempt(s, t, h, jst_inlaunch));
                 predicted = true;
                 jac_done = jst_inlaunch >= 0;
@@ -599,15 +510,9 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
             bool err_is_coupled = false;
             while (!converged) {
                 if (!s.have_lu) NK2D_TRY(set_lu(s, h));
-                if (s.device_ctl == 1) {
-                    NK2D_TRY(attempt(s, t, h, &converged, &n_iter, &rate, &have_rate, &err_sum, &buf));
-                } else if (s.device_ctl == 2) {
-                    NK2D_TRY(attempt_pipelined(s, t, h, &converged, &n_iter, &rate, &have_rate));
-                } else {
-                    if (!predicted) NK2D_TRY(predict(s, t, h));
-                    predicted = false;
-                    NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate, &queued_err, &err_coupled, &err_is_coupled));
-                }
+                if (!predicted) NK2D_TRY(predict(s, t, h));
+                predicted = false;
+                NK2D_TRY(newton(s, h, -1, &converged, &n_iter, &rate, &have_rate, &queued_err, &err_coupled, &err_is_coupled));
                 if (!converged) {
                     if (s.current_jac) break;
                     NK2D_TRY(refresh_jac(s, t, true));  // KV[3] holds the plane at the current t
@@ -622,11 +527,10 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                 newton_failed = true;
                 continue;
             }
-            // error estimate (radau.py:477-487); with device control its first pass was queued
-            // together with the attempt
+            // error estimate (radau.py:477-487)
             double sum = err_sum;
             bool sum_coupled = false;
-            if (s.device_ctl == 0 && queued_err >= 0) {
+            if (queued_err >= 0) {
                 buf = queued_err;
                 if (err_is_coupled) {
                     sum = err_coupled;
@@ -635,7 +539,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
                     NK2D_TRY(await_partials(c, c->snap_ev[1], c->hPART2));
                     NK2D_TRY(nk2d_part_sum(c, c->ncol, &sum, c->hPART2));
                 }
-            } else if (s.device_ctl != 1) {
+            } else {
                 if (s.m_real <= 2) {
                     NK2D_TRY(nk2d_r_err_fused(c, h, s.m_real, &buf, nullptr));
                 } else {
@@ -694,7 +598,7 @@ int run_free(Ctl& s, double* record, int64_t record_cap, int64_t* record_n) {
         const bool jac_needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
         // (a year with history samples: only the steps that hold a sample time keep the separate launches)
         const bool sample_due = c->hist_n > 0 && c->hist_next < c->hist_n && c->hist_t[c->hist_next] <= t_new;
-        bool fused = s.device_ctl == 0 && !sample_due && t + h == t_new && t_new < s.t1;
+        bool fused = !sample_due && t + h == t_new && t_new < s.t1;
         double h2 = 0.0;
         if (fused) {
             // the next step's first attempt, as the top of this loop will compute it
@@ -795,7 +699,7 @@ inline bool err_checked(const nk2d_ctx* c, bool check, int64_t i) {
 int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, ReplayLocal& L) {
     nk2d_ctx* c = s.c;
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
-    const bool fast = s.device_ctl == 0 && c->hist_n == 0;
+    const bool fast = c->hist_n == 0;
     // stage of the attempt (t, h) whose time is t_jac, or -1
     auto stage_of = [&](double t, double h, double t_jac) {
         if ((needs_state && !c->jac_stage_state) || !fast) return -1;
@@ -818,9 +722,9 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
                 c->ckpt.push_back(buf);
             }
             double* buf = c->ckpt[slot];
-            NK2D_CHECK(c, hipMemcpyAsync(buf, c->Y, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
-            NK2D_CHECK(c, hipMemcpyAsync(buf + c->nv, c->YOLD, sizeof(double) * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
-            NK2D_CHECK(c, hipMemcpyAsync(buf + 2 * c->nv, c->ZP, sizeof(double) * 3 * c->nv, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            NK2D_TRY(nk2d_r_copy(c, buf, c->Y));
+            NK2D_TRY(nk2d_r_copy(c, buf + c->nv, c->YOLD));
+            for (int k = 0; k < 3; ++k) NK2D_TRY(nk2d_r_copy(c, buf + (2 + k) * c->nv, c->ZP + k * c->nv));
         }
         // a Jacobian that reads the state can only be refreshed where the state is: at a step start; the others are
         // functions of time alone (option "jac_stage": the recorded year took it at a stage time of the attempt)
@@ -955,7 +859,8 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
         // counter-collecting profiler of this ROCm falls over behind a few thousand unsynchronised dispatches, as it
         // did behind the preconditioner's elimination) -- the host is far ahead at that point
         // and a drain every 64 steps costs forty hand-overs a year
-        if ((i & 63) == 63) NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
+        // (a command stream bounds its own depth: the host never runs more than half a ring ahead of the slowest workgroup)
+        if ((i & 63) == 63 && !c->stream_on) NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
     }
     return 0;
 }
@@ -964,7 +869,18 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
     nk2d_ctx* c = s.c;
     if (!check) {
         ReplayLocal L;
-        return replay_rows(s, sched, n, 0, false, L);
+        NK2D_TRY(replay_rows(s, sched, n, 0, false, L));
+        if (c->stream_on) {
+            const int erc = nk2d_stream_end(c);
+            if (erc == NK2D_RC_STREAM_LOST) {
+                c->stream_on = 0;
+                if (++c->stream_lost >= 2) c->stream_years = 0;
+                c->st.nbarrier_timeouts++;
+                return 3;
+            }
+            if (erc != 0) return erc;
+        }
+        return 0;
     }
     // ---- a frozen year ------------------------------------------------------------------------------------------------
     if (n > NK2D_OWN_REC_CAP) return nk2d_fail(c, "nk2d_comp_fcn_frozen: schedule too long", -4);
@@ -1046,7 +962,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
                             std::to_string(n) + " exceeds what the recorded step was accepted with: the recorded steps "
                             "do not control the error for this state", -7);
     };
-    if (!s.no_persistent && s.device_ctl == 0) {
+    if (!s.no_persistent && !c->stream_on) {
         std::vector<char> sampled;
         const int prc = nk2d_frozen_persistent(c, sched, n, &sampled);
         if (prc < 0) return prc;
@@ -1093,6 +1009,18 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
             L.f_at_t = false;
         }
         NK2D_TRY(replay_rows(s, cur, n, start, true, L));
+        if (c->stream_on) {
+            // the year ran as a command stream: the kernel ends here; had it given up on the way, the year is handed back
+            // (return 3: the caller restarts it from x, launch by launch)
+            const int erc = nk2d_stream_end(c);
+            if (erc == NK2D_RC_STREAM_LOST) {
+                c->stream_on = 0;
+                if (++c->stream_lost >= 2) c->stream_years = 0;
+                c->st.nbarrier_timeouts++;
+                return 3;
+            }
+            if (erc != 0) return erc;
+        }
         // SciPy's convergence test (radau.py:120-129) on what the LAST recorded iteration of every step left, with
         // slack: the perturbed state of a finite-difference product converges like the state the schedule was
         // recorded for, give or take; a state that does not (the recorded year converged at once on a special
@@ -1107,7 +1035,7 @@ int run_replay(Ctl& s, const double* sched, int64_t n, bool check) {
         // one more Newton iteration at the first step that did not converge, from the checkpoint before it -- where that
         // can be done (host-launched replay, SciPy's cap of six iterations, two resumes per year)
         const int n_it = (int)cur[bad * NK2D_SCHED_WIDTH + 3];
-        const bool can = s.device_ctl == 0 && c->hist_n == 0 && round < 2 && n_it < NEWTON_MAXITER &&
+        const bool can = c->hist_n == 0 && round < 2 && n_it < NEWTON_MAXITER &&
                          c->ckpt.size() > (size_t)(bad / NK2D_CKPT_EVERY);
         if (!can) {
             c->frozen_fallbacks++;
@@ -1153,8 +1081,6 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.t1 = c->d.t1;
     s.max_step = (c->d.t1 - c->d.t0) * c->d.max_step_frac;
     s.n_total = (c->norm_hook && c->global_n > 0.0) ? c->global_n : (double)c->tc * c->nz * c->ny;
-    if (c->norm_hook && c->device_ctl != 0 && c->device_ctl != 3 && !replay)
-        return nk2d_fail(c, "nk2d_comp_fcn: a norm hook (sharded tracer module) needs host-side decisions (device_ctl 0)");
     s.newton_tol = std::max(10 * std::numeric_limits<double>::epsilon() / c->d.rtol, std::min(0.03, std::sqrt(c->d.rtol)));
     s.fingerprint = nk2d_fingerprint(c);
     s.has_old_h = s.has_old_err = false;
@@ -1162,10 +1088,6 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     s.have_lu = false; s.have_dense = false;
     s.h_lu = 0; s.dense_t_old = 0; s.dense_h = 0;
     s.m_real = s.m_cplx = 1;
-    // 3: the stepping loop runs in one persistent kernel (nk2d_year_persistent); history sampling, a norm
-    // hook (sharded module) and the state dependent modules keep the host-controlled loop
-    const bool persistent = c->device_ctl == 3 && !replay && c->hist_n == 0 && !c->norm_hook && c->kind == 0;
-    s.device_ctl = (c->device_ctl == 3) ? 0 : c->device_ctl;
     s.pre_setup = false;
     s.pre_jac = false;
     s.pre_t = s.pre_h = 0.0;
@@ -1175,15 +1097,15 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
         nk2d_ctx* c;
         ~PartGuard() { c->part_on_host = 0; }
     } part_guard{c};
-    c->part_on_host = (s.device_ctl == 0 && !replay) ? 1 : 0;
+    c->part_on_host = replay ? 0 : 1;
     // single-launch Newton iterations (one-sweep solves) swap stage buffers on the host: host-side decisions and
     // step replay only
     struct SwapGuard {
         nk2d_ctx* c;
         ~SwapGuard() { c->single_swap = 0; c->swap_updates = 0; c->part_cur = nullptr; }
     } swap_guard{c};
-    c->single_swap = (s.device_ctl == 0) ? 1 : 0;
-    c->swap_updates = (s.device_ctl == 0 && c->norm_hook_vec && c->ZS) ? 1 : 0;
+    c->single_swap = 1;
+    c->swap_updates = (c->norm_hook_vec && c->ZS) ? 1 : 0;
     // A free-running year checks the convergence of every simplified Newton iteration on the iterates
     // themselves, inexact inner solves included.  A replayed schedule dictates the iteration counts of an
     // integrator with direct solves, so there the inner solves must not be what limits the accuracy.
@@ -1209,23 +1131,21 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
             return 0;
         };
         NK2D_TRY(start_year());
-        bool stepped = false;
-        if (persistent) {
-            const int rc = nk2d_year_persistent(c, s.h_abs, s.newton_tol, s.max_step, s.n_total, record, record_cap, record_n);
-            if (rc < 0) return rc;
-            stepped = rc == 0;      // 1: the grid does not fit the chip at once -- host control below
-            if (rc == 2) {
-                // a grid barrier timed out: the same year again from x, under host control
-                c->st = nk2d_stats();
-                c->st.nbarrier_timeouts = 1;
-                s.t = c->d.t0;
-                s.have_lu = false; s.have_dense = false;
-                s.has_old_h = s.has_old_err = false;
-                NK2D_TRY(start_year());
+        if (replay) {
+            // the replayed year as a command stream (option "stream_years" bit 2; nk2d_stream.h): the launches of replay_rows
+            // become commands, nothing is read back before the year's end
+            struct StreamGuard {
+                nk2d_ctx* c;
+                ~StreamGuard() {
+                    c->stream_on = 0;
+                    if (c->strm && nk2d_stream_running(c)) (void)nk2d_stream_end(c);
+                }
+            } stream_guard{c};
+            if ((c->stream_years & 2) && nk2d_stream_eligible(c) && c->hist_n == 0) {
+                NK2D_TRY(nk2d_stream_ready(c));
+                c->stream_on = 1;
             }
-        }
-        if (stepped) {}
-        else if (replay) {
+            const bool was_stream = c->stream_on != 0;
             // what a year books before it is known to stand: counters, algorithmic bytes and launch tallies
             const nk2d_stats st0 = c->st;
             const double bytes0 = c->fused_bytes_all;
@@ -1246,13 +1166,14 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
                 rrc = run_replay(s, replay, replay_n, replay_own);
             }
             if (rrc != 0) return rrc;
+            if (was_stream && c->stream_on) { c->stream_years_run++; c->stream_lost = 0; }
         }
         else {
             // The free-running year as a command stream (nk2d_stream.h): the launches of run_free become commands of ONE
             // resident kernel, the waits for events become waits for the partials themselves.  A kernel that gives up (a
             // wait over its time limit: a co-tenant on the chip, workgroups that did not all become resident) hands the year
             // back: the same year again from x, by launches -- counted, not failed.
-            const bool as_stream = nk2d_stream_eligible(c) && s.device_ctl == 0 && c->part_on_host && c->speculate;
+            const bool as_stream = (c->stream_years & 1) && nk2d_stream_eligible(c) && c->part_on_host && c->speculate;
             struct StreamGuard {
                 nk2d_ctx* c;
                 ~StreamGuard() {

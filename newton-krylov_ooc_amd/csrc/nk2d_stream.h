@@ -19,7 +19,9 @@
 
 enum { NK2D_OP_EXIT = 1, NK2D_OP_SETUP = 2, NK2D_OP_NEWTON = 3, NK2D_OP_ERR = 4, NK2D_OP_BOUNDARY = 5,
        // the several-sweep error estimate and the second estimate of a rejected step, launch for launch
-       NK2D_OP_SWEEP = 6, NK2D_OP_ERR_RHS = 7, NK2D_OP_ERR_RHS2 = 8, NK2D_OP_ERR_NORM = 9, NK2D_OP_COPY = 10 };
+       NK2D_OP_SWEEP = 6, NK2D_OP_ERR_RHS = 7, NK2D_OP_ERR_RHS2 = 8, NK2D_OP_ERR_NORM = 9, NK2D_OP_COPY = 10,
+       // the launch that ends the last Newton iteration of a frozen step and the step (nk2d_r_newton_final)
+       NK2D_OP_NEWTON_FINAL = 11 };
 #define NK2D_CMD_NOTIFY 1   /* the host waits for this command: completion stamp of every workgroup to pinned memory */
 #define NK2D_CMD_FACTOR 2   /* OP_NEWTON: the launch that computes the line factorisation of its column (first after an "LU" event) */
 
@@ -39,9 +41,16 @@ struct StreamColumns {      // nk2d_r_err_rhs / _err_rhs2 / _err_norm, a column-
     size_t nv;
     double h;
 };
+struct StreamFinal {        // nk2d_r_newton_final
+    FusedArgs nf;
+    FinalArgs fin;
+    VmixArgs V;
+    JacOut J;
+};
 struct StreamCmd {
     int op, flags;
     union {
+        StreamFinal fn;
         SweepArgs sw;       // nk2d_k_sweep
         StreamColumns col;
         FusedArgs nf;       // nk2d_r_newton_fused
@@ -54,7 +63,7 @@ struct StreamCmd {
 // A ring slot is NK2D_CMD_DWORDS pairs (stamp << 32 | payload dword), each written and read with ONE 8-byte access: a
 // reader that finds the expected stamp in every pair has the whole command, whatever order the pairs arrived in -- no fence,
 // no flag to order against, on the PCIe hop (host -> relay wave) as on the device (relay wave -> workgroups).
-#define NK2D_CMD_DWORDS 128
+#define NK2D_CMD_DWORDS 192
 #define NK2D_RING_SLOTS 256
 static_assert(sizeof(StreamCmd) <= 4 * NK2D_CMD_DWORDS, "a command must fit a ring slot");
 

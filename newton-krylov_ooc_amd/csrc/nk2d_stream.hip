@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstddef>
 #include <deque>
 #include <vector>
 
@@ -32,10 +33,16 @@ __device__ __forceinline__ void stream_relay(const StreamArgs& A, int lane) {
         const size_t slot = (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
         const unsigned long long a = ld_pair_sys(A.h_ring + slot + lane);
         const unsigned long long b = ld_pair_sys(A.h_ring + slot + 64 + lane);
-        if (__all((int)((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq))) {
-            __hip_atomic_store(A.d_ring + slot + lane, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.d_ring + slot + 64 + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int op = __builtin_amdgcn_readlane((int)(unsigned)a, 0);
+        const unsigned long long d = ld_pair_sys(A.h_ring + slot + 128 + lane);
+        // (pair 0 says how many pairs the command has -- once ITS stamp is this command's)
+        const unsigned head = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)a, 0);
+        const int ndw = ((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(a >> 32), 0) == seq) ? (int)(head >> 16) : NK2D_CMD_DWORDS;
+        if (__all((int)(((unsigned)(a >> 32) == seq || lane >= ndw) && ((unsigned)(b >> 32) == seq || 64 + lane >= ndw) &&
+                        ((unsigned)(d >> 32) == seq || 128 + lane >= ndw)))) {
+            if (lane < ndw) __hip_atomic_store(A.d_ring + slot + lane, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (64 + lane < ndw) __hip_atomic_store(A.d_ring + slot + 64 + lane, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (128 + lane < ndw) __hip_atomic_store(A.d_ring + slot + 128 + lane, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int op = (int)(head & 0xffffu);
             if (op == NK2D_OP_EXIT) return;
             ++seq;
             t_begin = (long long)__builtin_amdgcn_s_memrealtime();
@@ -90,15 +97,20 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
         for (;;) {
             const unsigned long long a = ld_pair_dev(A.d_ring + slot + lane);
             const unsigned long long b = ld_pair_dev(A.d_ring + slot + 64 + lane);
+            const unsigned long long d = ld_pair_dev(A.d_ring + slot + 128 + lane);
             if (!nb_ok) {
                 unsigned v = done_seq;
                 if (other >= 0) v = __hip_atomic_load(A.flags + (size_t)other * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((int)((int)(v - done_seq) >= 0))) { nb_ok = true; t_nb_ok = (long long)__builtin_amdgcn_s_memrealtime(); }
             }
-            if (nb_ok && __all((int)((unsigned)(a >> 32) == next && (unsigned)(b >> 32) == next))) {
+            const unsigned head = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)a, 0);
+            const int ndw = ((unsigned)__builtin_amdgcn_readlane((int)(unsigned)(a >> 32), 0) == next) ? (int)(head >> 16) : NK2D_CMD_DWORDS;
+            if (nb_ok && __all((int)(((unsigned)(a >> 32) == next || lane >= ndw) && ((unsigned)(b >> 32) == next || 64 + lane >= ndw) &&
+                                     ((unsigned)(d >> 32) == next || 128 + lane >= ndw)))) {
                 unsigned* dw = reinterpret_cast<unsigned*>(&cmd);
-                if (lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[lane] = (unsigned)a;
-                if (64 + lane < (int)((sizeof(StreamCmd) + 3) / 4)) dw[64 + lane] = (unsigned)b;
+                if (lane < ndw) dw[lane] = (lane == 0) ? (head & 0xffffu) : (unsigned)a;
+                if (64 + lane < ndw) dw[64 + lane] = (unsigned)b;
+                if (128 + lane < ndw) dw[128 + lane] = (unsigned)d;
                 const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
                 ticks_nb += t_nb_ok - t_begin;
                 ticks_cmd += t_end - t_nb_ok;
@@ -135,6 +147,23 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
                 for (int j = j0; j < j1; ++j) {
                     if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
                     else newton_fused_body<E, KIND, 0, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                }
+        } else if (op == NK2D_OP_NEWTON_FINAL) {
+            // the last Newton iteration of a frozen step, which also ends the step (y_new, the next attempt's predicted stage
+            // values), and the next attempt's planes -- into the second sets of plane buffers: this command's own stage and sweep
+            // parts still read the current ones
+            const StreamFinal& S = cmd.u.fn;
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) {
+                    if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
+                    else newton_fused_body<E, KIND, 0, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
+                }
+            for (int ti = tw; ti < 3; ti += nw)
+                for (int j = j0; j < j1; ++j) {
+                    double kv[E];
+                    vmix_body_kv<E, 1>(P, S.V, ti * P.ny + j, lane, kv);
+                    if (ti == S.J.stage)
+                        jac_core<E, 1>(P, kv, S.V.out[ti], S.J.JL, S.J.JU, S.J.JS, S.J.JN, S.J.JC, nullptr, nullptr, j, lane);
                 }
         } else if (op == NK2D_OP_ERR) {
             for (int tr = tw; tr < P.tc; tr += nw)
@@ -222,7 +251,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
         if (A.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lds_ok == 0) { status = 1; break; }
         t_exec += t2 - t1; ++n_cmd;
-        if (op >= 2 && op <= 5) { t_op[op - 2] += t2 - t1; ++n_op[op - 2]; }
+        {
+            const int bucket = (op == NK2D_OP_NEWTON_FINAL) ? 1 : ((op >= 2 && op <= 5) ? op - 2 : -1);
+            if (bucket >= 0) { t_op[bucket] += t2 - t1; ++n_op[bucket]; }
+        }
         ++seq;
     }
     if (A.prof && threadIdx.x == 0) {
@@ -294,7 +326,7 @@ unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq
 // which contexts run their years as command streams: linear sources for now (iage, forced without forcing files), host-side
 // decisions, double precision factor tables, and a grid whose workgroups are all resident at once
 int nk2d_stream_eligible(const nk2d_ctx* c) {
-    if (!c->stream_years || c->stream_lost >= 2 || c->kind != 0 || c->norm_hook || c->factor_fp32 || c->device_ctl != 0) return 0;
+    if (!c->stream_years || c->stream_lost >= 2 || c->kind != 0 || c->norm_hook || c->factor_fp32) return 0;
     if (c->xcd_map || c->prefactor) return 0;     // (the launch shape -- option "team" -- is not the stream kernel's concern)
     return 1;
 }
@@ -382,11 +414,30 @@ void nk2d_stream_free(nk2d_ctx* c) {
     c->strm = nullptr;
 }
 
+// dwords of a command with this op (the header and the member of the union it uses)
+static int cmd_dwords(int op) {
+    size_t body = 0;
+    switch (op) {
+        case NK2D_OP_SETUP: body = sizeof(StreamSetup); break;
+        case NK2D_OP_NEWTON: body = sizeof(FusedArgs); break;
+        case NK2D_OP_ERR: body = sizeof(ErrArgs); break;
+        case NK2D_OP_BOUNDARY: body = sizeof(StreamBoundary); break;
+        case NK2D_OP_SWEEP: body = sizeof(SweepArgs); break;
+        case NK2D_OP_NEWTON_FINAL: body = sizeof(StreamFinal); break;
+        case NK2D_OP_EXIT: body = 0; break;
+        default: body = sizeof(StreamColumns); break;
+    }
+    return (int)((offsetof(StreamCmd, u) + body + 3) / 4);
+}
+
+// (dword 0 carries the op in its low and the number of dwords in its high half: a reader checks the stamps of that many pairs)
 static void ring_write(nk2d_stream_state* S, unsigned seq, const StreamCmd& cmd) {
     unsigned dw[NK2D_CMD_DWORDS] = {0};
     std::memcpy(dw, &cmd, sizeof(StreamCmd));
+    const int ndw = cmd_dwords(cmd.op);
+    dw[0] = (unsigned)cmd.op | ((unsigned)ndw << 16);
     unsigned long long* slot = (S->direct ? S->d_ring : S->h_ring) + (size_t)(seq % NK2D_RING_SLOTS) * NK2D_CMD_DWORDS;
-    for (int k = 0; k < NK2D_CMD_DWORDS; ++k)
+    for (int k = 0; k < ndw; ++k)
         __atomic_store_n(slot + k, ((unsigned long long)seq << 32) | dw[k], __ATOMIC_RELAXED);
     if (S->direct) __builtin_ia32_sfence();      // (write-combined stores over the BAR: out of the CPU's buffers now)
 }

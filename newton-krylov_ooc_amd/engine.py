@@ -39,14 +39,9 @@ DEFAULT_JAC_STAGE = 1
 # The rule saves 9-13 % of a forward year but changes the step sizes, and with them the history samples by up
 # to 1.8 times the tolerance of the reference's CI comparison (tools/probe_hist_modes.py): off by default.
 DEFAULT_GROWTH_CAP = 0.0
-# Whole forward year in ONE persistent kernel (nk2d_set_option "device_ctl" 3: grid barriers between the phases,
-# SciPy's controller on the device) for grids of at most this many depth levels.  Measured against the host-controlled
-# loop of the same build (tools/probe_persistent_sizes.py, profiles/r02_persistent_sizes.log): 1.41x at 26^2, 1.26x at
-# 52^2, 1.13x at 104^2, 1.08x at 208^2, 0.97x at 416^2.  Same phase functions, same algorithm;
-# history sampling, sharded modules and the state dependent modules keep the host-controlled loop.  This concerns the
-# free-running years (F(x) itself); the perturbed years of the products are frozen years under host launches (section 3c).
-# NK2D_DEVICE_CTL in the environment overrides (0 = host control everywhere).
-PERSISTENT_MAX_NZ = 128
+# Free-running forward years run as COMMAND STREAMS by default (library option "stream_years", csrc/nk2d_stream.h): one
+# resident kernel executes the host controller's launches as commands.  NK2D_STREAM_YEARS in the environment overrides
+# (0: launch by launch; 1: free-running years; 3: frozen years too).
 
 
 class Nk2dError(RuntimeError):
@@ -180,10 +175,8 @@ class ModuleEngine:
         self._handle = ctx
         self.device_ctl = 0
         self._precond_ready = False
-        if "NK2D_DEVICE_CTL" in os.environ:
-            self.set_option("device_ctl", float(os.environ["NK2D_DEVICE_CTL"]))
-        elif module_kind == 0 and self.nz <= PERSISTENT_MAX_NZ:
-            self.set_option("device_ctl", 3)
+        if "NK2D_STREAM_YEARS" in os.environ:
+            self.set_option("stream_years", float(os.environ["NK2D_STREAM_YEARS"]))
         self.set_option("jac_fresh", float(os.environ.get("NK2D_JAC_FRESH", DEFAULT_JAC_FRESH)))
         self.set_option("growth_cap", float(os.environ.get("NK2D_GROWTH_CAP", DEFAULT_GROWTH_CAP)))
         self.set_option("jac_stage", float(os.environ.get("NK2D_JAC_STAGE", DEFAULT_JAC_STAGE)))

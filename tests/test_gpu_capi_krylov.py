@@ -317,8 +317,8 @@ def test_frozen_year_reproduces_the_recorded_year_and_checks_newton():
     xt = tight.upload(xh)
     fxt, _, _ = tight.comp_fcn(xt)
     w_ref = tight.download(tight.jvp(xt, fxt, tight.upload(v))[0])
-    for ctl, fresh in ((0, 1), (3, 1), (0, 0)):
-        eng.set_option("device_ctl", ctl)
+    for ctl, fresh in ((0, 1), (1, 1), (0, 0)):       # (base year by launches / as a command stream)
+        eng.set_option("stream_years", ctl)
         eng.set_option("jac_fresh", fresh)
         fx, st, sched = eng.comp_fcn(x, record=True)
         assert np.array_equal(eng.last_schedule(), sched) and len(sched) == st["nsteps"]
@@ -333,7 +333,7 @@ def test_frozen_year_reproduces_the_recorded_year_and_checks_newton():
     assert eng.frozen_fallbacks() == 0
     # the recorded counts of a year that converged at once (a uniform state under pure decay: no transport at all)
     # are not enough for a perturbed state with structure
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 1)
     eng.set_option("jac_fresh", 1)
     flat = eng.upload(np.zeros((2, n, n)))
     f_flat, _, s_flat = eng.comp_fcn(flat, record=True)

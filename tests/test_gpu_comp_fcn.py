@@ -76,8 +76,10 @@ def test_comp_fcn_free(golden_dir, tag, nz, ny, vv, kh):
 
 
 def test_controller_variants_take_identical_decisions():
-    """host-side Newton decisions (default), device-side decisions with one read-back per step
-    attempt, and the pipelined device-side controller must follow the same path bit for bit"""
+    """the host's controller driving launches and the same controller driving ONE resident kernel through a command stream
+    (csrc/nk2d_stream.h) follow the same path bit for bit -- here under SciPy's decisions with at least two sweeps per
+    solve (the round-1 rule); options that change what is integrated (single-launch iterations, Jacobian at every step
+    start, RADAU5's growth rule) change the step sequence, not the ODE or its tolerances"""
     import numpy as np
 
     eng = make_engine(26, 26)
@@ -88,14 +90,13 @@ def test_controller_variants_take_identical_decisions():
     results = []
     eng.set_option("jac_fresh", 0)
     eng.set_option("growth_cap", 0)
-    # the device-side controllers cannot swap stage buffers behind a launch that returns at entry, so they keep at
-    # least two sweeps per solve; the host-side controller is put under the same rule for the bitwise comparison
+    eng.set_option("jac_stage", -1)
     eng.set_option("min_sweeps", 2)
-    for mode in (0, 1, 2):
-        eng.set_option("device_ctl", mode)
+    for stream in (0, 1):
+        eng.set_option("stream_years", stream)
         fx, stats, sched = eng.comp_fcn(x, record=True)
         results.append((eng.download(fx), stats, sched))
-    eng.set_option("device_ctl", 0)
+    assert eng.counter("stream_years_run") == 1
     for res, stats, sched in results[1:]:
         assert np.array_equal(res, results[0][0])
         assert np.array_equal(sched, results[0][2])

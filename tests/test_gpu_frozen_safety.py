@@ -54,8 +54,8 @@ def test_schedule_rows_carry_error_and_fingerprint():
     assert np.all(sched[:, 6] > 0.0) and np.all(sched[:, 6] <= 1.0)          # every recorded step was accepted
     fp = eng.schedule_fingerprint()
     assert fp >= 1.0 and fp == float(int(fp)) and np.all(sched[:, 7] == fp)
-    # the persistent year stamps its steps the same way
-    eng.set_option("device_ctl", 3)
+    # a year by launches stamps its steps the same way as one that ran as a command stream
+    eng.set_option("stream_years", 0)
     _, _, sched3 = eng.comp_fcn(x, record=True)
     assert np.all(sched3[:, 7] == fp) and np.all(sched3[:, 6] <= 1.0) and np.all(sched3[:, 6] > 0.0)
     eng.close()

@@ -53,6 +53,40 @@ def test_stream_year_is_the_host_controlled_year(nz, ny, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("nz,ny", [(26, 26), (52, 52), (130, 20), (416, 8)])
+def test_frozen_year_as_a_stream(nz, ny):
+    """the frozen year of a product (a recorded schedule replayed for another state) as a command stream:
+    the launch-per-phase frozen year bit for bit, for the recorded state (= the recorded year) and for a perturbed one,
+    with the Newton check and the sampled error estimates of every frozen year; and a step replay of the same schedule"""
+    eng = _iage(nz, ny)
+    eng.set_option("frozen_persistent", 0)
+    x0 = _state(eng)
+    x = eng.upload(x0)
+    zz, yy = np.linspace(0.0, 1.0, nz), np.linspace(0.0, 1.0, ny)
+    xp = eng.upload(x0 * (1.0 + 1.0e-4 * np.outer(np.sin(3.0 * zz), np.cos(2.0 * yy))[None]))
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_l = eng.comp_fcn_frozen(xp, sched)
+    replay_l = eng.download(eng.comp_fcn(xp, replay=sched)[0])
+    eng.set_option("stream_years", 2)
+    got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
+    _, st_s = eng.comp_fcn_frozen(xp, sched)
+    assert eng.counter("stream_years_run") == 3 and eng.counter("stream_timeouts") == 0
+    assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    for key in ("nsteps", "nnewton", "nfev", "nerr_checked"):
+        assert st_s[key] == st_l[key], key
+    assert st_s["max_err"] == st_l["max_err"] and st_s["nlaunch"] < 0.2 * st_l["nlaunch"]
+    assert np.array_equal(eng.download(eng.comp_fcn(xp, replay=sched)[0]), replay_l)
+    # the product through it
+    vd = eng.upload(np.cumsum(np.random.default_rng(3).standard_normal(x0.shape), axis=1))
+    eng.set_region(np.ones((nz, ny), dtype=np.int32), np.outer(eng.grid.depth.delta, eng.grid.ypos.delta))
+    w_s, _, _ = eng.jvp(x, fx, vd, sched=sched)
+    eng.set_option("stream_years", 0)
+    w_l, _, _ = eng.jvp(x, fx, vd, sched=sched)
+    assert np.array_equal(eng.download(w_s), eng.download(w_l)) and eng.frozen_fallbacks() == 0
+    eng.close()
+
+
 def test_year_with_history_samples_as_a_stream():
     """the 61 samples of a history file have no command: each ends the kernel, runs its launches, the next command starts the
     kernel again -- same year, same samples"""
