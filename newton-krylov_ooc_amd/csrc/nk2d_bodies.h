@@ -1850,7 +1850,8 @@ static inline void fill_fused_args(nk2d_ctx* c, FusedArgs& A, bool do_stage, boo
 // (agent scope) and polls it; the others wait at the workgroup barrier behind that lane.  Arrays only ever
 // touched by their owning wave (W, right-hand sides, the line factorisation, F) stay plain.  Every spin is
 // bounded; a timeout raises a grid-wide abort flag that every wave sees at its next barrier.
-// The grid is launched cooperatively, so it is rejected -- not deadlocked -- when it is not fully resident.
+// The grid must be resident at once: the host refuses the launch when the chip cannot hold it (launch_resident), and every
+// wait is bounded by time.
 // =================================================================================================
 #define NK2D_SPIN_LIMIT 4000000
 
@@ -1981,14 +1982,6 @@ __device__ __forceinline__ double uni_d(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Cooperative launches of one process go through ONE queue of the HIP runtime, created on first use: contexts driven from
-// several host threads (the tracer modules of a ModelState run their years in a thread pool) enqueue on it one at a time --
-// two threads inside hipLaunchCooperativeKernel at once left the runtime with a queue it crashed on when the process ended
-// (rocr::AMD::AqlQueue::~AqlQueue under hsa_shut_down; tools/probe_exit2.py).  Held for the enqueue only.
-inline std::mutex& coop_launch_mutex() {
-    static std::mutex m;
-    return m;
-}
 
 
 // =================================================================================================

@@ -300,20 +300,39 @@ void nk2d_frozen_cache_free(nk2d_ctx* c) {
 //    done, its commit left to the caller);  1: not for this context / schedule (the launch-per-phase path runs);
 // 2: a grid barrier timed out (the same);  < 0: error
 // the instantiation for (levels per lane, module kind, flavour); the team flavour exists for one and two levels per lane
+// `coop`: every workgroup of the grid must be resident at once (the grid-barrier and hand-over flavours: a workgroup waits
+// for others).  Launched PLAINLY all the same: the launch is refused here (hipErrorCooperativeLaunchTooLarge) when the chip
+// cannot hold the grid -- occupancy of the kernel times the compute units --, the process runs one resident kernel at a
+// time (nk2d_turn_take), and every wait inside the kernel is bounded by time, so a grid that did not become fully
+// resident after all (a co-tenant on the chip) hands the year back instead of hanging.  hipLaunchCooperativeKernel did the
+// same check and nothing else for this kernel -- through a queue of its own that the HIP runtime crashed on when the process
+// ended under rocprofv3 (rounds 2 - 3: AqlQueue::~AqlQueue under hsa_shut_down).
+template <class K>
+static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, DevP& P, FrozenArgs& A) {
+    int per_cu = 0;
+    hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block.x, 0);
+    if (rc != hipSuccess) return rc;
+    hipDeviceProp_t prop;
+    rc = hipGetDeviceProperties(&prop, c->dev);
+    if (rc != hipSuccess) return rc;
+    if ((long long)per_cu * prop.multiProcessorCount < (long long)grid.x) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(kernel, grid, block, 0, nk2d_s(c), P, A);
+    return hipGetLastError();
+}
+
 template <int E, int KIND, int XCD, int TEAM>
 static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
     if (coop) {
-        void* args[2] = {&P, &A};
         if constexpr (!XCD) {
             if (c->frozen_nbsync) {
                 // a wave per column with the neighbour hand-over: option "frozen_wpb" waves (= columns) to a workgroup -- the
                 // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
                 const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
                 const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
-                return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), args, 0, nk2d_s(c));
+                return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A);
             }
         }
-        return hipLaunchCooperativeKernel((const void*)k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), args, 0, nk2d_s(c));
+        return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), P, A);
     }
     hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A);
     return hipGetLastError();
@@ -571,6 +590,10 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
         const dim3 grid(8 * nblk + 64);
+        struct Turn {
+            Turn() { nk2d_turn_take(); }
+            ~Turn() { nk2d_turn_give(); }
+        } turn;
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
         NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
         NK2D_CHECK(c, hipGetLastError());
@@ -592,10 +615,12 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         hipError_t rc = hipErrorInvalidValue;
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
-        {
-            std::lock_guard<std::mutex> coop(coop_launch_mutex());
-            rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
-        }
+        // one resident kernel at a time in this process (the turn is held until this one has ended)
+        struct Turn {
+            Turn() { nk2d_turn_take(); }
+            ~Turn() { nk2d_turn_give(); }
+        } turn;
+        rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));

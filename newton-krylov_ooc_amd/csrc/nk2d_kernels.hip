@@ -157,6 +157,13 @@ int nk2d_k_jac(nk2d_ctx* c, const double* kv, const double* ylin) {
     if (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0 && ylin == nullptr)
         return nk2d_fail(c, "nk2d_k_jac: a forced module with a sink threshold needs a linearisation state");
     if (c->kind == 0 || (c->kind == 2 && !(c->d.sms_nrec > 0 && c->d.sink_thres > 0.0))) ylin = nullptr;
+    if (c->stream_on) {
+        StreamCmd cmd = {};
+        cmd.op = NK2D_OP_JAC;
+        cmd.u.jac.kvp = kv; cmd.u.jac.JL = c->JL; cmd.u.jac.JU = c->JU; cmd.u.jac.JS = c->JS; cmd.u.jac.JN = c->JN;
+        cmd.u.jac.JC = c->JC; cmd.u.jac.ylin = ylin; cmd.u.jac.UPR = c->UPR;
+        return nk2d_stream_push(c, cmd, false);
+    }
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_jac<EE>, dim3(nk2d_grid(c->ny)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, kv,
                                                c->JL, c->JU, c->JS, c->JN, c->JC, ylin, c->UPR));
     NK2D_CHECK(c, hipGetLastError());

@@ -21,7 +21,9 @@ enum { NK2D_OP_EXIT = 1, NK2D_OP_SETUP = 2, NK2D_OP_NEWTON = 3, NK2D_OP_ERR = 4,
        // the several-sweep error estimate and the second estimate of a rejected step, launch for launch
        NK2D_OP_SWEEP = 6, NK2D_OP_ERR_RHS = 7, NK2D_OP_ERR_RHS2 = 8, NK2D_OP_ERR_NORM = 9, NK2D_OP_COPY = 10,
        // the launch that ends the last Newton iteration of a frozen step and the step (nk2d_r_newton_final)
-       NK2D_OP_NEWTON_FINAL = 11 };
+       NK2D_OP_NEWTON_FINAL = 11,
+       // Jacobian planes from a mixing plane in memory (nk2d_k_jac: modules whose Jacobian reads the state)
+       NK2D_OP_JAC = 12 };
 #define NK2D_CMD_NOTIFY 1   /* the host waits for this command: completion stamp of every workgroup to pinned memory */
 #define NK2D_CMD_FACTOR 2   /* OP_NEWTON: the launch that computes the line factorisation of its column (first after an "LU" event) */
 
@@ -41,6 +43,12 @@ struct StreamColumns {      // nk2d_r_err_rhs / _err_rhs2 / _err_norm, a column-
     size_t nv;
     double h;
 };
+struct StreamJac {          // nk2d_k_jac
+    const double* kvp;
+    double *JL, *JU, *JS, *JN, *JC;
+    const double* ylin;
+    double* UPR;
+};
 struct StreamFinal {        // nk2d_r_newton_final
     FusedArgs nf;
     FinalArgs fin;
@@ -51,6 +59,7 @@ struct StreamCmd {
     int op, flags;
     union {
         StreamFinal fn;
+        StreamJac jac;
         SweepArgs sw;       // nk2d_k_sweep
         StreamColumns col;
         FusedArgs nf;       // nk2d_r_newton_fused

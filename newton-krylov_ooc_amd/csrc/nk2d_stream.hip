@@ -217,6 +217,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
                     if (nre > 0) sweep_body<E, KIND, 1>(P, S, j * nvar + tr, lane);
                     if (nvar > nre) sweep_body<E, KIND, 1>(P, S, j * nvar + nre + tr, lane);
                 }
+        } else if (op == NK2D_OP_JAC) {
+            const StreamJac& S = cmd.u.jac;
+            if (tw == 0)
+                for (int j = j0; j < j1; ++j) jac_body<E, 1>(P, S.kvp, S.JL, S.JU, S.JS, S.JN, S.JC, S.ylin, S.UPR, j, lane);
         } else if (op >= NK2D_OP_ERR_RHS && op <= NK2D_OP_COPY) {
             const StreamColumns& S = cmd.u.col;
             for (int tr = tw; tr < P.tc; tr += nw)
@@ -306,27 +310,27 @@ namespace {
 std::mutex g_turn_mutex;
 std::condition_variable g_turn_cv;
 bool g_turn_taken = false;
-void turn_take() {
+}  // namespace
+void nk2d_turn_take() {
     std::unique_lock<std::mutex> lk(g_turn_mutex);
     g_turn_cv.wait(lk, [] { return !g_turn_taken; });
     g_turn_taken = true;
 }
-void turn_give() {
+void nk2d_turn_give() {
     {
         std::lock_guard<std::mutex> lk(g_turn_mutex);
         g_turn_taken = false;
     }
     g_turn_cv.notify_one();
 }
-}  // namespace
 
 bool nk2d_stream_running(const nk2d_ctx* c) { return c->strm && c->strm->running; }
 unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq : 0u; }
 
-// which contexts run their years as command streams: linear sources for now (iage, forced without forcing files), host-side
-// decisions, double precision factor tables, and a grid whose workgroups are all resident at once
+// which contexts run their years as command streams: every module kind, host-side decisions (no norm hook: a sharded module's
+// controller waits for all-reduces), double precision factor tables
 int nk2d_stream_eligible(const nk2d_ctx* c) {
-    if (!c->stream_years || c->stream_lost >= 2 || c->kind != 0 || c->norm_hook || c->factor_fp32) return 0;
+    if (!c->stream_years || c->stream_lost >= 2 || c->norm_hook || c->factor_fp32) return 0;
     if (c->xcd_map || c->prefactor) return 0;     // (the launch shape -- option "team" -- is not the stream kernel's concern)
     return 1;
 }
@@ -345,7 +349,7 @@ static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P,
 }
 static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks) {
     hipError_t rc = hipErrorInvalidValue;
-    NK2D_DISPATCH_E(c->E, rc = stream_launch_one<EE, 0>(c, grid, block, P, A, max_blocks));
+    NK2D_DISPATCH_EK(c->E, c->kind, rc = (stream_launch_one<EE, KK>(c, grid, block, P, A, max_blocks)));
     return rc;
 }
 
@@ -424,6 +428,7 @@ static int cmd_dwords(int op) {
         case NK2D_OP_BOUNDARY: body = sizeof(StreamBoundary); break;
         case NK2D_OP_SWEEP: body = sizeof(SweepArgs); break;
         case NK2D_OP_NEWTON_FINAL: body = sizeof(StreamFinal); break;
+        case NK2D_OP_JAC: body = sizeof(StreamJac); break;
         case NK2D_OP_EXIT: body = 0; break;
         default: body = sizeof(StreamColumns); break;
     }
@@ -445,7 +450,7 @@ static void ring_write(nk2d_stream_state* S, unsigned seq, const StreamCmd& cmd)
 // start the kernel (it will find the commands pushed from now on)
 static int stream_start(nk2d_ctx* c) {
     nk2d_stream_state* S = c->strm;
-    turn_take();
+    nk2d_turn_take();
     StreamArgs A = {};
     A.h_ring = S->direct ? nullptr : S->h_ring; A.d_ring = S->d_ring;
     A.abort_flag = (int*)S->d_sync;
@@ -460,7 +465,7 @@ static int stream_start(nk2d_ctx* c) {
     P.guard = nullptr;
     const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr);
     if (rc != hipSuccess) {
-        turn_give();
+        nk2d_turn_give();
         NK2D_CHECK(c, rc);
     }
     S->running = true;
@@ -603,7 +608,7 @@ int nk2d_stream_pause(nk2d_ctx* c) {
     S->running = false;
     // (the kernel's workgroups all pass the EXIT command: everything before it is complete once the kernel has ended)
     S->notifies.clear();
-    turn_give();
+    nk2d_turn_give();
     return 0;
 }
 

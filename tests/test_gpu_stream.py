@@ -14,7 +14,7 @@ def _iage(nz, ny):
     from nk_ooc_amd.grid import Grid2d
 
     eng = iage_engine(Grid2d.default(nz, ny))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (the library's default is 1: the tests switch it on where they compare)
     return eng
 
 
@@ -84,6 +84,54 @@ def test_frozen_year_as_a_stream(nz, ny):
     eng.set_option("stream_years", 0)
     w_l, _, _ = eng.jvp(x, fx, vd, sched=sched)
     assert np.array_equal(eng.download(w_s), eng.download(w_l)) and eng.frozen_fallbacks() == 0
+    eng.close()
+
+
+def _phos_state(eng, rng):
+    tc, nz, ny = eng.shape
+    prof = [np.interp(eng.grid.depth.mid, zs, vs) for zs, vs in (([1.3e2, 2.6e2], [5.5e-3, 4.1e0]), ([9.5e1, 1.4e2], [7.1e-2, 1.5e-4]),
+                                                                 ([1.7e2, 2.5e2], [1.8e-2, 7.9e-4]))]
+    return np.stack([np.broadcast_to(p[:, None], (nz, ny)) for p in prof]) * (1.0 + 0.05 * rng.random((3, nz, ny)))
+
+
+@pytest.mark.parametrize("case", ["phosphorus_30x12", "phosphorus_130x6", "phosphorus_416x4", "forced_decay_26x26", "forced_file_sink_thres_22x9",
+                                  "forced_file_restore_sms_22x9"])
+def test_other_module_kinds_as_streams(case, golden_dir, tmp_path):
+    """the modules whose Jacobian reads the state (phosphorus: three coupled tracers, a Jacobian command per attempt; forced with a
+    thresholded sink) and the file-driven forced module (its forcing fields ride with the mixing planes): free-running year and
+    frozen year as command streams against the same years by launches, bit for bit"""
+    from nk_ooc_amd.engine import forced_engine, phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    rng = np.random.default_rng(12)
+    if case.startswith("phosphorus"):
+        nz, ny = (int(v) for v in case.split("_")[1].split("x"))
+        eng = phosphorus_engine(Grid2d.default(nz, ny))
+        x0 = _phos_state(eng, rng)
+    elif case.startswith("forced_decay"):
+        eng = forced_engine(Grid2d.default(26, 26), {"forced_surf_restore_opt": "none", "forced_sms_opt": "decay", "forced_sms_decay_rate": "1.0e-8"})
+        bump = np.cumsum(np.cumsum(rng.standard_normal((1, 26, 26)), axis=1), axis=2)
+        x0 = 1.0 + 0.3 * bump / np.max(np.abs(bump))
+    else:
+        from test_gpu_forced import _file_modelinfo
+
+        g = np.load(f"{golden_dir}/{case}.npz")
+        eng = forced_engine(Grid2d.default(int(g["nz"]), int(g["ny"])), _file_modelinfo(g, tmp_path))
+        x0 = np.asarray(g["y0"]).reshape(eng.shape)
+    eng.set_option("stream_years", 0)
+    eng.set_option("frozen_persistent", 0)
+    x = eng.upload(x0)
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    xp = eng.upload(x0 * (1.0 + 1.0e-5 * np.cos(np.linspace(0.0, 3.0, x0.shape[1]))[None, :, None]))
+    fz = eng.download(eng.comp_fcn_frozen(xp, sched)[0])
+    eng.set_option("stream_years", 3)
+    fx_s, st_s, sched_s = eng.comp_fcn(x, record=True)
+    assert eng.counter("stream_years_run") == 1 and eng.counter("stream_timeouts") == 0
+    assert np.array_equal(sched_s, sched) and np.array_equal(eng.download(fx_s), eng.download(fx))
+    for key in ("nsteps", "nrejected", "nnewton", "nfev", "njev", "nlu"):
+        assert st_s[key] == st[key], key
+    assert st_s["nlaunch"] < 0.25 * st["nlaunch"]
+    assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), fz) and eng.counter("stream_years_run") == 2
     eng.close()
 
 
