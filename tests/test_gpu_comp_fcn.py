@@ -239,7 +239,7 @@ def test_year_with_history_samples_is_the_same_year():
 
     n = 52
     eng = iage_engine(Grid2d.default(n, n))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (launch counts are compared below; as a command stream: tests/test_gpu_stream.py)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
     x = eng.upload(y0)

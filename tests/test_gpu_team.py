@@ -146,7 +146,7 @@ def test_pair_frozen_year_bitwise(nz, ny):
     rng = np.random.default_rng(6)
     col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2) + 0.01 * rng.standard_normal((2, nz, ny)))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (the year by launches: its launch count is compared below)
     fx, st, sched = eng.comp_fcn(x, record=True)
     want = eng.download(fx)
     for team in (0, 1, 2):
