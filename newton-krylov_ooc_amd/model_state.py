@@ -214,6 +214,7 @@ class ModelState:
     _grid = None
     _resident = {}
     _sched_by_name = {}     # fcn file -> {module name: accepted Radau steps of the year that produced it}
+    CONCURRENT_MAX_COLUMNS = 768   # (tracer, ypos) columns of all modules together up to which their years run side by side
     RESIDENT_MAX = 256      # device snapshots kept by name; the oldest are dropped beyond this, with or
                             # without the files on disk (write_files=False: a dropped name cannot be re-opened)
     _hist_end = {}          # hist file -> {module name: end-of-year state} of state dependent preconditioners
@@ -516,10 +517,18 @@ class ModelState:
                 return tms.eng.comp_fcn(tms.vec)
             return tms.eng.comp_fcn_hist(tms.vec, t_eval)
 
-        # the modules are independent (own context, own HIP stream, own host control loop): their
-        # years run concurrently, one host thread each -- a single module leaves most of the chip
-        # idle (less than one wave per SIMD), and the ctypes calls release the GIL
-        if len(self.tracer_modules) > 1 and not os.environ.get("NK2D_SERIAL_MODULES"):
+        # the modules are independent (own context, own HIP stream, own host control loop): where their years
+        # together leave the chip room -- small grids: a year is a chain of latency-bound phases on a few dozen
+        # waves -- they run concurrently, one host thread each (the ctypes calls release the GIL).  Where every
+        # module fills the chip on its own (a wave per (tracer, ypos) column holds a SIMD: 1 024 of them), years
+        # side by side only take SIMDs from each other -- a resident one-launch year holds its SIMDs for its whole
+        # length while another module's launches queue for the rest (round 3: 0.94 s per iteration of the three-module
+        # mix at 416 x 416 against 0.70 s for its three years one after the other) -- so they run back to back.
+        # NK2D_SERIAL_MODULES=1 / 0 forces one or the other.
+        serial_env = os.environ.get("NK2D_SERIAL_MODULES")
+        columns = sum(tms.eng.tc * tms.eng.ny for tms in self.tracer_modules)
+        serial = (serial_env not in (None, "", "0")) if serial_env is not None else columns > self.CONCURRENT_MAX_COLUMNS
+        if len(self.tracer_modules) > 1 and not serial:
             with ThreadPoolExecutor(max_workers=len(self.tracer_modules)) as pool:
                 years = list(pool.map(forward_year, self.tracer_modules))
         else:
