@@ -316,6 +316,11 @@ static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, 
     rc = hipGetDeviceProperties(&prop, c->dev);
     if (rc != hipSuccess) return rc;
     if ((long long)per_cu * prop.multiProcessorCount < (long long)grid.x) return hipErrorCooperativeLaunchTooLarge;
+    if (std::getenv("NK2D_DIAG_COOPERATIVE")) {
+        // diagnostic only (profiles/r04_slowdown_ab.log): the launch as rounds 2 - 3 made it, through the runtime's cooperative queue
+        void* args[2] = {&P, &A};
+        return hipLaunchCooperativeKernel((const void*)kernel, grid, block, args, 0, nk2d_s(c));
+    }
     hipLaunchKernelGGL(kernel, grid, block, 0, nk2d_s(c), P, A);
     return hipGetLastError();
 }

@@ -30,6 +30,18 @@ def gap(tag):
 
 
 base = gap("fresh process")
+# what bench.py has done before its auxiliary legs: the 416 x 416 iage workload with its 119 GB schedule cache, closed again
+big = iage_engine(Grid2d.default(416, 416))
+colb = np.interp(big.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
+xb = big.upload(np.stack([np.broadcast_to(colb[:, None], (416, 416))] * 2).copy())
+big.set_option("frozen_alloc_async", 0)
+fb, _, schedb = big.comp_fcn(xb, record=True)
+for _ in range(3):
+    big.comp_fcn_frozen(xb, schedb)
+print(f"    (iage 416^2: {big.counter('frozen_persistent_years')} one-launch years on a cache of {big.counter('frozen_cache_bytes') / 1e9:.0f} GB)")
+gap("with a 416^2 iage engine and its schedule cache alive")
+big.close()
+gap("after closing it (119 GB given back)")
 import torch  # noqa: E402
 
 torch.cuda.set_device(0)
