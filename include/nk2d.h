@@ -205,7 +205,7 @@ int nk2d_set_frozen_schedule(nk2d_ctx* ctx, const double* sched, int64_t sched_n
 int nk2d_frozen_fallbacks(nk2d_ctx* ctx, int64_t* n);
 int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
 /* Modules whose Jacobian is a function of time alone, grids of up to 512 levels (option "frozen_persistent_max_e", levels per
-   lane, default 8; five to eight only with linear sources): a frozen year runs as ONE cooperative launch -- a wave or a
+   lane, default 8; five to eight only with linear sources): a frozen year runs as ONE launch whose workgroups are all resident -- a wave or a
    four-wave team per column, one simplified-Newton iteration per phase, workgroups handing over to their lateral neighbours
    between phases -- on a cache of everything its schedule fixes besides the state: mixing planes, Jacobian planes and line
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
@@ -334,8 +334,8 @@ int nk2d_multi_axpy(nk2d_ctx* ctx, nk2d_vec w, int32_t n, const nk2d_vec* basis,
    whole module (radau.py:118,481; common.py:63-65).  With a hook installed, every sum of squares the
    controller reads is passed through `fn` (the caller makes it an all-reduce over the shards: RCCL on
    GPUs, gloo in the CPU tests) and the RMS norms divide by global_n = the module's tc * nz * ny, so
-   that all shards take identical decisions.  fn == NULL removes the hook.  Host-side decisions only
-   (option "device_ctl" 0). */
+   that all shards take identical decisions.  fn == NULL removes the hook.  (A hooked context's years are launched: the
+   controller waits for the caller's all-reduces, which no resident kernel should sit through -- option "stream_years".) */
 typedef double (*nk2d_norm_hook_fn)(void* user, double local_sum_of_squares);
 int nk2d_set_norm_hook(nk2d_ctx* ctx, nk2d_norm_hook_fn fn, void* user, double global_n);
 /* The same with several sums per call (1 <= n <= 4; replaced in place by the module-wide sums): the controller then
@@ -351,18 +351,29 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    benchmarked path and bench.py run -- "jac_fresh" 1, "jac_stage" 1 (and desc.lin_tol = 3e-2 is what they pass);
    SciPy's decisions step for step are "jac_fresh" 0 + "jac_stage" -1 (what the counter-parity tests set).
    "lin_tol" (relative accuracy of the inner line-relaxation solves),
-   "device_ctl" (1: take the Newton convergence decisions on the device and read back once
-   per step attempt instead of once per Newton iteration), "jac_fresh" (1: re-evaluate the
+   "stream_years" (bit 1, default: free-running forward years run as COMMAND STREAMS -- one resident kernel executes the
+   launches of the host-controlled year as commands pushed into a ring in HBM, workgroups hand over to their two lateral
+   neighbours between commands, norm partials come back through pinned host memory; same controller, same device functions,
+   the same year bit for bit, csrc/nk2d_stream.h.  Bit 2: frozen / replayed years too -- measured slower than the one-launch
+   year on the schedule cache for the modules that has one, equal to launches otherwise; 0: every year by launches.
+   Counters "stream_years_run", "stream_commands", "stream_launches" (kernel starts), "stream_timeouts" (kernels that gave
+   up: the year is rerun by launches), "stream_prof_0..11" (microseconds per workgroup waiting for commands / executing /
+   waiting for neighbours, commands, and per kind of command).  NK2D_STREAM_RELAY=1 in the environment: commands through
+   pinned host memory and a relay wave instead of written over the large BAR),
+   "device_ctl" (only 0: rounds 1 - 3 had device-side controllers 1, 2, 3; they lost to the command stream and are gone),
+   "spec_bias" (default 1: what the host queues behind a Newton iteration it has not judged yet -- the next iteration, or the
+   error estimate when the predicted convergence test value is below this many tolerances; never a decision; measured flat),
+   "jac_fresh" (1: re-evaluate the
    Jacobian at every step start instead of SciPy's reuse heuristic; same ODE, same error
    control, different -- shorter -- sequence of Newton iterations), "growth_cap" (> 0: largest
    growth factor of the step size after a step whose Newton iteration failed and was repeated with
    half the step; 1.0 is the rule of Hairer & Wanner's RADAU5, 0 = SciPy, which has none),
    "min_sweeps" (1, default: a solve whose contraction bound meets lin_tol after ONE sweep runs the whole simplified
    Newton iteration as a single launch, its update written to a spare stage buffer; 2: at least two sweeps wherever
-   columns couple, the round-1 rule -- also what the device-side controllers 1 and 2 always use),
+   columns couple, the round-1 rule),
    "final_fuse" (1, default: a step of a frozen year, nk2d_comp_fcn_frozen, ends in the launch of its last Newton
    iteration; 0: in a step boundary launch of its own, for A/B runs),
-   "jac_stage" (0, 1 or 2, with "jac_fresh" 1 and host-side or persistent control: the Jacobian of a step attempt is
+   "jac_stage" (0, 1 or 2, with "jac_fresh" 1: the Jacobian of a step attempt is
    taken at the time of that stage of the attempt, t + c_i h, instead of the step start -- the simplified Newton
    iteration and the error filter use ONE Jacobian for the three stages and the vertical mixing changes over a step;
    the launch that computes the stage's mixing plane derives the Jacobian planes from it.  1 is the default; -1:
@@ -371,15 +382,13 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    "team" (launch shape of the Newton-iteration launches: 0 one wave per column; 1 one workgroup of four waves per
    column -- the three stages and the complex system on waves of their own; 2 a pair of waves per column -- stages and
    real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
-   context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto), "xcd_map" (1: workgroup -> column mapping that gives every XCD a contiguous range of columns;
-   0 default -- no measurable gain at 416 x 416), "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs),
-   "sweep_wpb",
-   "prefactor" (1: in a frozen year the next step's planes ride on the first non-factorising launch of the step and its line
-   factorisation on the step-ending launch; 0 default -- measured neutral, profiles/r03_prefactor),
+   context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto),
+   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "sweep_wpb",
+   (closed experiments removed in round 4: "xcd_map", "prefactor" -- profiles/r03_prefactor holds their measurements),
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
-   grids, see nk2d_get_counter), "frozen_team" (1, default: a four-wave team per column inside that launch, cooperative
-   flavour; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: workgroups hand over to
+   grids, see nk2d_get_counter), "frozen_team" (1, default: a four-wave team per column inside that launch, all
+   workgroups resident; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: workgroups hand over to
    their two lateral neighbours instead of meeting at a grid barrier), "frozen_wpb" (columns per workgroup of the wave-per-column
    flavour with that hand-over, 1 .. 4, default 2: the waves of a workgroup move in lock step, a neighbour in another
    workgroup is read over the fabric),

@@ -144,7 +144,6 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
-    if (key == "prefactor") { c->prefactor = value != 0.0; return 0; }
     if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
     if (key == "frozen_persistent") { c->frozen_persistent = value != 0.0; return 0; }
     if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
@@ -173,7 +172,6 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         c->jac_stage = (int)value;
         return 0;
     }
-    if (key == "xcd_map") { c->xcd_map = value != 0.0; return 0; }
     if (key == "team") {   // -1: automatic (see nk2d_team_auto), 0 / 1: never / always
         if (value != 0.0 && value != 1.0 && value != 2.0 && value != -1.0) return nk2d_fail(c, "nk2d_set_option: team must be -1, 0, 1 or 2");
         c->team = (value < 0.0) ? nk2d_team_auto(c) : (int)value;
@@ -473,7 +471,6 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->single_swap = 0;
     c->min_sweeps = 1;
     c->team = nk2d_team_auto(c);
-    c->xcd_map = 0;
     c->jac_stage = 1;     // ONE set of defaults (round 3): the mode the engines and bench.py run; -1 = SciPy's step start
     c->final_fuse = 1;
     c->jac_stage_state = 1;
@@ -493,14 +490,6 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->FR_TAB, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABR, (size_t)c->ncol * 14 * 64));
     NK2D_TRY(dev_alloc(c, &c->FC_TABI, (size_t)c->ncol * 14 * 64));
-    NK2D_TRY(dev_alloc(c, &c->FB_INV, c->nv));
-    NK2D_TRY(dev_alloc(c, &c->FCB_INVR, c->nv));
-    NK2D_TRY(dev_alloc(c, &c->FCB_INVI, c->nv));
-    NK2D_TRY(dev_alloc(c, &c->FB_TAB, (size_t)c->ncol * 14 * 64));
-    NK2D_TRY(dev_alloc(c, &c->FCB_TABR, (size_t)c->ncol * 14 * 64));
-    NK2D_TRY(dev_alloc(c, &c->FCB_TABI, (size_t)c->ncol * 14 * 64));
-    c->prefactor = 0;   // measured neutral at best (profiles/r03_prefactor): an option for A/B runs
-    c->prefactored = 0;
     NK2D_TRY(dev_alloc(c, &c->FR32_INV, c->nv));
     NK2D_TRY(dev_alloc(c, &c->FC32_INVR, c->nv));
     NK2D_TRY(dev_alloc(c, &c->FC32_INVI, c->nv));
@@ -541,7 +530,6 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     NK2D_TRY(dev_alloc(c, &c->RED, (size_t)4096));
     for (int i = 0; i < 8; ++i) NK2D_CHECK(c, hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming));
     c->snap_ready = 1;
-    c->cur_guard = nullptr;
     c->jac_fresh = 1;     // (0 = SciPy's reuse heuristic)
     c->growth_cap = 0.0;
     c->hist_n = 0;
@@ -676,7 +664,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
                       c->YOLD, c->F, c->Z, c->ZP, c->ZN, c->ZS, c->W, c->BR, c->BCR, c->BCI, c->XR[0], c->XR[1], c->XCR[0],
                       c->XCR[1], c->XCI[0], c->XCI[1], c->TMP, c->TMP2, c->PART, c->PART2, c->STEP_NORM, c->STEP_PART, c->RED, c->STAGE, c->RCOEF,
                       c->FR_INV, c->FC_INVR, c->FC_INVI, c->FR_TAB, c->FC_TABR, c->FC_TABI,
-                      c->FB_INV, c->FCB_INVR, c->FCB_INVI, c->FB_TAB, c->FCB_TABR, c->FCB_TABI, c->LIGHT, c->UPR, c->YLIN,
+                      c->LIGHT, c->UPR, c->YLIN,
                       c->SMSREC, c->RESTREC};
     for (double* b : bufs)
         if (b) (void)hipFree(b);

@@ -24,7 +24,6 @@ struct DevP {
     const double *VV, *KH, *WT, *WB, *DZR, *ZM0, *ZM1, *DM, *DMR, *DYR, *BLDMAX;
     double surf[NK2D_MAX_TRACERS], starget[NK2D_MAX_TRACERS], decay[NK2D_MAX_TRACERS], csrc;
     double atol, rtol;
-    const int* guard;  // guarded kernels return at once when *guard != 0
     // phosphorus module (kind 1): parameters, light limitation plane, d uptake / d po4 at t_jac
     double ph_hs, ph_mu, ph_sig, ph_rd, ph_rp, ph_vs;
     const double *LIGHT, *UPR;
@@ -34,7 +33,6 @@ struct DevP {
     int f_sms, f_restore;
     double f_thres_r;
     size_t np;
-    int xcd;   // 1: XCD-contiguous column ranges (TASK_PROLOGUE_XCD), 0: workgroup b takes block b (option "xcd_map")
 };
 
 static inline DevP make_devp(const nk2d_ctx* c) {
@@ -48,8 +46,6 @@ static inline DevP make_devp(const nk2d_ctx* c) {
     }
     p.csrc = c->d.const_src;
     p.atol = c->d.atol; p.rtol = c->d.rtol;
-    p.guard = c->cur_guard;
-    p.xcd = c->xcd_map;
     p.ph_hs = c->d.phos_params[0]; p.ph_mu = c->d.phos_params[1]; p.ph_sig = c->d.phos_params[2];
     p.ph_rd = c->d.phos_params[3]; p.ph_rp = c->d.phos_params[4]; p.ph_vs = c->d.phos_params[5];
     p.LIGHT = c->LIGHT; p.UPR = c->UPR;
@@ -76,23 +72,11 @@ static __constant__ double cP[3][3] = {
     {0.3333333333333333, -2.6666666666666665, 3.3333333333333335}};
 static __constant__ double cE[3] = {-10.048809399827414, 1.382142733160748, -0.3333333333333333};
 
-#define GUARD_RETURN(g) \
-    if ((g) != nullptr && *(g) != 0) return;
-
 #define TASK_PROLOGUE(ntasks)                                              \
     const int lane = threadIdx.x & 63;                                     \
     const int task = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
     if (task >= (ntasks)) return;
 
-// XCD-aware variant for the kernels that read the neighbouring columns: workgroups go to the eight XCDs round-robin
-// (blockIdx % 8), each XCD with an L2 of its own.  Workgroup b works on the virtual block (b % 8) * (gridDim / 8) + b / 8,
-// so that one XCD owns a contiguous range of columns and a column's neighbours are fetched into the same L2 (all but
-// the eight range ends) instead of into two or three of them.  The grid must be a multiple of 8 (nk2d_grid_xcd).
-#define TASK_PROLOGUE_XCD(ntasks)                                                          \
-    const int lane = threadIdx.x & 63;                                                     \
-    const int vblk_ = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x; \
-    const int task = vblk_ * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
-    if (task >= (ntasks)) return;
 
 // ---------------------------------------------------------------------------------
 // vertical mixing coefficient (vert_mix.py:44-87 with spatial_axis.py:136-187)
@@ -1104,21 +1088,6 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
     }
 }
 
-// Work of the NEXT step that depends on time alone, hidden behind the column waves of this step's launches (a frozen
-// year knows every step ahead; the launches without the factorisation hold 232 registers, so a second wave fits on
-// every SIMD beside the 832 column waves of a 416^2 launch):
-//   * its mixing planes at the three stage times and the Jacobian planes derived from one of them ride on the first
-//     launch of this step that does not factorise (k_newton_fused_pl; the exp of a mixing column is a 5 us chain);
-//   * its line factorisation -- pivots and PCR tables of both systems of every column, from those Jacobian planes -- on
-//     the launch that ends this step (PreFactor tasks of k_newton_final, the work of k_factor), into the second set of
-//     factor buffers.
-// The next step then opens with the launch that LOADS its factorisation instead of the factorising instantiation (303
-// registers, one wave per SIMD, 22.9 us instead of 16.5 us at 416^2).  Where the planes could not ride ahead (a step of
-// one launch) the final launch computes them as before and the next step factorises for itself.
-struct PreFactor {
-    int mode;        // 0: plane tasks behind the columns (the round-2 launch); 1: nothing; 2: factor tasks (planes done earlier)
-    SweepArgs sa;    // Jacobian planes of the next step, its shifts, the second set of factor buffers
-};
 
 // one (stage time, ypos column) task of the next attempt's planes; the plane the Jacobian derives from comes first
 template <int E>

@@ -31,11 +31,6 @@
 #define NK2D_OWN_REC_CAP 65536   /* rows of the context's own schedule record */
 #define NK2D_CKPT_EVERY 128      /* steps between two checkpoints of a frozen year */
 
-struct nk2d_plane_job {
-    double times[3];   // stage times of the next attempt
-    int jstage;        // stage whose plane its Jacobian derives from (-1: none due)
-    int done;
-};
 
 struct nk2d_ctx {
     nk2d_desc d;
@@ -100,7 +95,6 @@ struct nk2d_ctx {
     int jac_stage_state;   // 1: option "jac_stage" also for modules whose Jacobian reads the state (plane of the stage time, state of the step start)
     int final_fuse;    // 1: a frozen step ends in the launch of its last Newton iteration (option "final_fuse", for A/B runs)
     int jac_stage;     // >= 0: Jacobian of a step attempt from the vertical mixing plane of this stage time (option "jac_stage"); -1: step start
-    int xcd_map;       // 1: XCD-contiguous column ranges in the kernels with neighbour reads (option "xcd_map")
     int team;          // 1: Newton-iteration launches run as k_newton_team (one workgroup per column); 0: k_newton_fused (option "team")
     int single_swap;   // 1: single-launch iterations write ZN and swap (host-side decisions; see nk2d_radau.hip set_lu)
     int swap_updates;  // 1: ... and so do the update launches of several-sweep iterations (vector norm hook)
@@ -108,15 +102,6 @@ struct nk2d_ctx {
     // cached line factorisation of the current (h_lu, t_jac): pivot reciprocals and PCR tables
     double *FR_INV, *FC_INVR, *FC_INVI;   // nv each
     double *FR_TAB, *FC_TABR, *FC_TABI;   // ncol * NK2D_TAB * 64 each
-    // second set: the launch that ends a frozen step writes the NEXT step's factorisation here while its own sweep reads
-    // the current one (PreFactor in nk2d_kernels.hip; option "prefactor"); prefactored: the current set holds the
-    // tables for the shifts pre_c*, computed ahead of the integrator's "LU" event
-    double *FB_INV, *FCB_INVR, *FCB_INVI, *FB_TAB, *FCB_TABR, *FCB_TABI;
-    int prefactor, prefactored;
-    double pre_cre, pre_ccr, pre_cci;
-    // the next attempt's planes, to ride on the next Newton-iteration launch that does not factorise (set by the replay
-    // around the launches of a frozen step; k_newton_fused_pl)
-    struct nk2d_plane_job* plane_job;
     // single precision copies for the fused Newton launches: the line factorisation is an approximate
     // inverse inside an iteration that re-evaluates the exact residual, its storage precision only
     // touches the contraction rate (nk2d_set_option "factor_fp32")
@@ -124,7 +109,6 @@ struct nk2d_ctx {
     int factor_fp32;
     hipEvent_t snap_ev[8];  // "the launch that carries these partials is queued" (host-side decisions by launches)
     int snap_ready;
-    const int* cur_guard;   // flag the guarded kernels test at entry (nullptr: always run)
     int sweep_wpb;          // waves per block of the sweep kernel (1, 2 or 4)
     int jac_fresh;          // 1: re-evaluate the Jacobian at every step start (see nk2d_set_option)
     double growth_cap;      // > 0: largest step growth factor after a step whose Newton iteration failed at first
@@ -302,11 +286,6 @@ static inline int nk2d_team_auto(const nk2d_ctx* c) {
     return 0;
 }
 
-// grid of a kernel with TASK_PROLOGUE_XCD: tasks_per_block tasks per workgroup, rounded up to a multiple of the 8 XCDs
-static inline int nk2d_grid_xcd(int ntasks, int tasks_per_block) {
-    const int nblk = (ntasks + tasks_per_block - 1) / tasks_per_block;
-    return 8 * ((nblk + 7) / 8);
-}
 static inline int nk2d_grid(int ntasks) { return (ntasks + NK2D_WAVES_PER_BLOCK - 1) / NK2D_WAVES_PER_BLOCK; }
 
 // run `stmt` with a compile-time constant EE equal to the runtime levels-per-lane
@@ -622,8 +601,7 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
                          double x0, double x1, double x2, int jac_stage = -1, bool with_tend = true);
 int nk2d_r_rows_sum(nk2d_ctx* c, const double* rows, int64_t nrows, double* out);
 int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
-                        const double* times, double x0, double x1, double x2, int jac_stage, bool planes_done = false,
-                        const double* next_shifts = nullptr);
+                        const double* times, double x0, double x1, double x2, int jac_stage);
 int nk2d_r_attempt_setup(nk2d_ctx* c, const double* times, double* const* out, double x0, double x1, double x2,
                          int jac_stage = -1);
 double nk2d_fingerprint(const nk2d_ctx* c);

@@ -423,7 +423,6 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         if (c->frozen_seen_years++ < after) return 1;
     }
     DevP P = make_devp(c);
-    P.guard = nullptr;
     if (fc->key != key || fc->n != n) {
         // ---- (re)build the cache for this schedule
         if (fc->cap_rows < (size_t)n) {

@@ -221,7 +221,6 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_factor(DevP P, SweepArgs A) {
 
 template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_sweep(DevP P, SweepArgs A) {
-    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(A.ntasks)
     sweep_body<E, KIND, 0>(P, A, task, lane);
 }
@@ -246,7 +245,6 @@ int nk2d_k_factor(nk2d_ctx* c, bool do_real, bool do_cplx, double cre, double cc
     A.first = 0;
     if (A.ntasks == 0) return 0;
     DevP P = make_devp(c);
-    P.guard = nullptr;
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_factor<EE, KK>), dim3(nk2d_grid(A.ntasks)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
@@ -410,29 +408,15 @@ __global__ void k_attempt_setup(DevP P, VmixArgs V, int nblk_vmix, PredictArgs A
 
 template <int E, int KIND, int FACTOR, int STAGE>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused(DevP P, FusedArgs A) {
-    GUARD_RETURN(P.guard)
-    TASK_PROLOGUE_XCD(P.ncol)
+    TASK_PROLOGUE(P.ncol)
     newton_fused_body<E, KIND, FACTOR, STAGE, 0>(P, A, task, lane);
 }
 
-// a Newton-iteration launch without the factorisation, with the plane tasks of the next attempt behind its columns
-template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_fused_pl(DevP P, FusedArgs A, int nblk_cols, VmixArgs V, JacOut J) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    if ((int)blockIdx.x < nblk_cols) {
-        const int task = blockIdx.x * wpb + wave;
-        if (task < P.ncol) newton_fused_body<E, KIND, 0, 1, 0>(P, A, task, lane);
-        return;
-    }
-    const int ptask = (blockIdx.x - nblk_cols) * wpb + wave;
-    if (ptask < P.ny * 3) plane_task<E>(P, V, J, ptask, lane);
-}
 
 // the launch that ends a frozen step (FinalArgs): column workgroups first, then the workgroups of the next attempt's
-// planes or of its line factorisation (PreFactor)
+// planes
 template <int E, int KIND, int FACTOR, int STAGE>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J, PreFactor F) {
+__global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     if ((int)blockIdx.x < Fin.nblk_cols) {
@@ -441,20 +425,15 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_newton_final(DevP P, FusedArgs A
         return;
     }
     const int ptask = (blockIdx.x - Fin.nblk_cols) * wpb + wave;
-    if (F.mode == 0) {
-        if (ptask < P.ny * 3) plane_task<E>(P, V, J, ptask, lane);
-    } else if (F.mode == 2) {
-        if (ptask < F.sa.ntasks) factor_body<E, KIND>(P, F.sa, ptask, lane);
-    }
+    if (ptask < P.ny * 3) plane_task<E>(P, V, J, ptask, lane);
 }
 
 template <int E, int KIND, int FACTOR, int STAGE>
 __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs A) {
-    GUARD_RETURN(P.guard)
     __shared__ TeamLds<E, 3> S;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int task = P.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // see TASK_PROLOGUE_XCD
+    const int task = (int)blockIdx.x;
     if (task >= P.ncol) return;
     newton_team_body<E, KIND, FACTOR, STAGE, 4, 0>(P, A, S, task, w, lane, nullptr);
 }
@@ -463,7 +442,6 @@ __global__ void __launch_bounds__(NK2D_BLOCK, 2) k_newton_team(DevP P, FusedArgs
 // 128 threads behind the Fin.nblk_cols column workgroups)
 template <int E, int KIND, int FACTOR, int STAGE, int FIN>
 __global__ void __launch_bounds__(128, 2) k_newton_pair(DevP P, FusedArgs A, FinalArgs Fin, VmixArgs V, JacOut J) {
-    GUARD_RETURN(P.guard)
     __shared__ TeamLds<E, 0> S;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -487,15 +465,13 @@ __global__ void __launch_bounds__(128, 2) k_newton_pair(DevP P, FusedArgs A, Fin
 
 template <int E>
 __global__ void k_err_rhs(int ncol, const double* __restrict__ f, const double* __restrict__ z, size_t nv, double h,
-                          double* __restrict__ out, const int* __restrict__ guard) {
-    GUARD_RETURN(guard)
+                          double* __restrict__ out) {
     TASK_PROLOGUE(ncol)
     err_rhs_body<E, 0>(f, z, nv, h, out, task, lane);
 }
 
 template <int E, int KIND>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_err_fused(DevP P, ErrArgs A) {
-    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     err_fused_body<E, KIND, 0>(P, A, task, lane);
 }
@@ -603,7 +579,6 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
         return nk2d_stream_push(c, cmd, false);
     }
     DevP P = make_devp(c);
-    P.guard = nullptr;
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_step_boundary<EE, KK>), dim3(B.nblk_vmix + B.nblk_jac + nk2d_grid(c->ncol)),
                                                          dim3(NK2D_BLOCK), 0, nk2d_s(c), P, V, B, A));
     NK2D_CHECK(c, hipGetLastError());
@@ -614,7 +589,6 @@ int nk2d_r_step_boundary(nk2d_ctx* c, const double* kv_new, bool do_jac, const d
 template <int E>
 __global__ void k_err_norm(DevP P, const double* __restrict__ y, const double* __restrict__ z2p,
                            const double* __restrict__ err, double* __restrict__ part) {
-    GUARD_RETURN(P.guard)
     TASK_PROLOGUE(P.ncol)
     err_norm_body<E, 0>(P, y, z2p, err, part, task, lane);
 }
@@ -759,18 +733,18 @@ static int launch_fused(nk2d_ctx* c, const DevP& P, const FusedArgs& A, bool do_
         }
     } else if (c->team) {    // one workgroup of four waves per column (k_newton_team)
         if (do_factor) {
-            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 1, 1>), dim3(c->ncol), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
         } else if (do_stage) {
-            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 1>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 1>), dim3(c->ncol), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
         } else {
-            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 0>), dim3(nk2d_grid_xcd(c->ncol, 1)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+            NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_team<EE, KK, 0, 0>), dim3(c->ncol), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
         }
     } else if (do_factor) {  // always a launch with the stage part
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 1, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
     } else if (do_stage || c->kind != 1) {
-        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+        NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_newton_fused<EE, KK, 0, 1>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
     } else {          // phosphorus, sweep-only launch: the lean instantiation
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid_xcd(c->ncol, NK2D_WAVES_PER_BLOCK)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused<EE, 1, 0, 0>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A));
     }
     NK2D_CHECK(c, hipGetLastError());
     return 0;
@@ -811,29 +785,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
             c->win_bytes += 8.0 * words;
         }
     }
-    nk2d_plane_job* job = c->plane_job;
-    if (job && !job->done && !do_factor && c->team == 0 && c->kind != 1 && !c->xcd_map && P.guard == nullptr) {
-        // the next attempt's planes behind this launch's columns (k_newton_fused_pl; see PreFactor)
-        VmixArgs V;
-        for (int i = 0; i < 3; ++i) {
-            nk2d_host_interp(4, c->d.bld_tvals, c->d.bld_fvals, job->times[i], &V.frac[i]);
-            V.out[i] = c->KVN[i];
-        }
-        V.frac[3] = 0.0; V.out[3] = nullptr;
-        vmix_forcing_args(c, 3, job->times, V);
-        V.bldmin = c->d.bldepth_min; V.y0 = c->d.vmix_log_shallow; V.y1 = c->d.vmix_log_deep;
-        V.hw = c->d.vmix_half_width;
-        JacOut J = {c->JB[0], c->JB[1], c->JB[2], c->JB[3], c->JB[4], job->jstage};
-        const int nblk_cols = nk2d_grid(c->ncol);
-        const dim3 grid(nblk_cols + nk2d_grid(c->ny * 3));
-        if (c->kind == 2) {
-            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused_pl<EE, 2>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, nblk_cols, V, J));
-        } else {
-            NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_fused_pl<EE, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, nblk_cols, V, J));
-        }
-        NK2D_CHECK(c, hipGetLastError());
-        job->done = 1;
-    } else if (c->stream_on) {
+    if (c->stream_on) {
         StreamCmd cmd = {};
         cmd.op = NK2D_OP_NEWTON;
         cmd.flags = do_factor ? NK2D_CMD_FACTOR : 0;
@@ -856,8 +808,7 @@ int nk2d_r_newton_fused(nk2d_ctx* c, bool do_stage, bool first, bool do_update, 
 // are swapped into their new roles here: Y <-> YOLD, Z <-> ZN (when this launch also evaluated the stages), the stage
 // planes and -- when derived -- the Jacobian planes with their second sets.
 int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, double mcr, double mci, int src, bool delta,
-                        const double* times, double x0, double x1, double x2, int jac_stage, bool planes_done,
-                        const double* next_shifts) {
+                        const double* times, double x0, double x1, double x2, int jac_stage) {
     if (c->kind == 1) return nk2d_fail(c, "nk2d_r_newton_final: not for modules whose Jacobian reads the state");
     FusedArgs A;
     fill_fused_args(c, A, do_stage, first, true, mreal, mcr, mci, src, delta);
@@ -884,7 +835,6 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     V.hw = c->d.vmix_half_width;
     JacOut J = {c->JB[0], c->JB[1], c->JB[2], c->JB[3], c->JB[4], jac_stage};
     DevP P = make_devp(c);
-    P.guard = nullptr;
     {
         const double words = fused_words(c, do_stage, first, true, delta, do_factor);
         // counted with the path's launches and bytes (end-to-end figures); not in the shape tallies of
@@ -892,25 +842,7 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
         c->sweep_launches++;
         c->fused_bytes_all += 8.0 * words;
     }
-    // planes_done: an earlier launch of this step already computed the next attempt's planes (k_newton_fused_pl); this
-    // launch then carries that attempt's line factorisation instead, when its shifts are known and its Jacobian is new
-    PreFactor F = {};
-    F.mode = planes_done ? 1 : 0;
-    const bool prefactor = planes_done && next_shifts != nullptr && jac_stage >= 0;
-    if (prefactor) {
-        F.mode = 2;
-        F.sa.JL = c->JB[0]; F.sa.JU = c->JB[1]; F.sa.JS = c->JB[2]; F.sa.JN = c->JB[3]; F.sa.JC = c->JB[4];
-        F.sa.cre = next_shifts[0]; F.sa.ccr = next_shifts[1]; F.sa.cci = next_shifts[2];
-        F.sa.fr_inv = c->FB_INV; F.sa.fc_invr = c->FCB_INVR; F.sa.fc_invi = c->FCB_INVI;
-        F.sa.fr_tab = c->FB_TAB; F.sa.fc_tabr = c->FCB_TABR; F.sa.fc_tabi = c->FCB_TABI;
-        F.sa.f32 = 0;
-        F.sa.nreal = c->ncol;
-        F.sa.ntasks = 2 * c->ncol;
-        const double Pc = (double)c->nz * c->ny, N = Pc * c->tc;
-        c->fused_bytes_all += 8.0 * (3.0 * Pc + 3.0 * N + 3.0 * 14.0 / c->E * N);     // planes read, tables written
-    }
     if (c->stream_on) {
-        if (F.mode != 0) return nk2d_fail(c, "nk2d_r_newton_final: option \"prefactor\" is not for command streams");
         StreamCmd cmd = {};
         cmd.op = NK2D_OP_NEWTON_FINAL;
         cmd.flags = do_factor ? NK2D_CMD_FACTOR : 0;
@@ -918,14 +850,14 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
         NK2D_TRY(nk2d_stream_push(c, cmd, false));
         c->st.nlaunch--;
     } else {
-    const dim3 grid(Fin.nblk_cols + (F.mode == 0 ? nk2d_grid(c->ny * 3) : (F.mode == 2 ? nk2d_grid(2 * c->ncol) : 0)));
+    const dim3 grid(Fin.nblk_cols + nk2d_grid(c->ny * 3));
 #define NK2D_FINAL_LAUNCH(KK)                                                                                              \
     if (do_factor) {                                                                                                       \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 1, 1>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J, F)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 1, 1>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J)); \
     } else if (do_stage) {                                                                                                 \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 1>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J, F)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 1>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J)); \
     } else {                                                                                                               \
-        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J, F)); \
+        NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL((k_newton_final<EE, KK, 0, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A, Fin, V, J)); \
     }
     if (c->team == 2) {
         Fin.nblk_cols = c->ncol;
@@ -950,14 +882,6 @@ int nk2d_r_newton_final(nk2d_ctx* c, bool do_stage, bool first, double mreal, do
     if (jac_stage >= 0) {
         std::swap(c->JL, c->JB[0]); std::swap(c->JU, c->JB[1]); std::swap(c->JS, c->JB[2]);
         std::swap(c->JN, c->JB[3]); std::swap(c->JC, c->JB[4]);
-    }
-    c->prefactored = 0;
-    if (prefactor) {
-        // the tables of the step that begins now: the integrator's next "LU" event with these shifts finds them in place
-        std::swap(c->FR_INV, c->FB_INV); std::swap(c->FC_INVR, c->FCB_INVR); std::swap(c->FC_INVI, c->FCB_INVI);
-        std::swap(c->FR_TAB, c->FB_TAB); std::swap(c->FC_TABR, c->FCB_TABR); std::swap(c->FC_TABI, c->FCB_TABI);
-        c->prefactored = 1;
-        c->pre_cre = F.sa.cre; c->pre_ccr = F.sa.ccr; c->pre_cci = F.sa.cci;
     }
     c->st.nlaunch++;
     c->st.nsweeps++;
@@ -989,7 +913,6 @@ int nk2d_profile_replay(nk2d_ctx* c, int shape, int n, double* avg_us, double* b
     A.st.w = c->ZP;
     A.st.zout = c->ZN;
     DevP P = make_devp(c);
-    P.guard = nullptr;
     for (int i = 0; i < 3; ++i) NK2D_TRY(launch_fused(c, P, A, false, do_stage));   // warm-up
     NK2D_CHECK(c, hipEventRecord(c->timer_ev[0], nk2d_s(c)));
     for (int i = 0; i < n; ++i) NK2D_TRY(launch_fused(c, P, A, false, do_stage));
@@ -1032,14 +955,14 @@ int nk2d_prof_window_end(nk2d_ctx* c) {
 }
 
 int nk2d_r_err_rhs(nk2d_ctx* c, double h) {
-    if (c->stream_on && c->cur_guard == nullptr) {
+    if (c->stream_on) {
         StreamCmd cmd = {};
         cmd.op = NK2D_OP_ERR_RHS;
         cmd.u.col.a = c->F; cmd.u.col.b = c->Z; cmd.u.col.nv = c->nv; cmd.u.col.h = h; cmd.u.col.out = c->BR;
         return nk2d_stream_push(c, cmd, false);
     }
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_err_rhs<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
-                                               c->ncol, c->F, c->Z, c->nv, h, c->BR, c->cur_guard));
+                                               c->ncol, c->F, c->Z, c->nv, h, c->BR));
     NK2D_CHECK(c, hipGetLastError());
     c->st.nlaunch++;
     return 0;
@@ -1099,7 +1022,6 @@ int nk2d_r_err_rhs2(nk2d_ctx* c, const double* err, double h) {
 // y_new = Y + Z[2] -> YOLD (the spare buffer), F = fun(., y_new) with the plane kv
 int nk2d_r_commit_tend(nk2d_ctx* c, const double* kv) {
     DevP P = make_devp(c);
-    P.guard = nullptr;
     NK2D_DISPATCH_EK(c->E, c->kind, hipLaunchKernelGGL((k_commit_tend<EE, KK>), dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c), P,
                                                c->Y, c->Z + 2 * c->nv, kv, c->YOLD, c->F));
     NK2D_CHECK(c, hipGetLastError());

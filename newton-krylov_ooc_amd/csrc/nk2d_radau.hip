@@ -94,11 +94,7 @@ int set_lu(Ctl& s, double h) {
     s.c->st.nlu += 2;
     // the factorisation itself happens inside the first fused Newton launch that needs it
     s.c->lu_cre = MU_REAL / h; s.c->lu_ccr = MU_CR / h; s.c->lu_cci = MU_CI / h;
-    // ... unless the launch that ended the step before already computed it for exactly these shifts and the Jacobian
-    // planes it derived itself (a frozen year, nk2d_r_newton_final with next_shifts)
-    const bool ready = s.c->prefactored && s.c->pre_cre == s.c->lu_cre && s.c->pre_ccr == s.c->lu_ccr && s.c->pre_cci == s.c->lu_cci;
-    s.c->prefactored = 0;
-    s.c->factor_pending = ready ? 0 : 1;
+    s.c->factor_pending = 1;
     return 0;
 }
 
@@ -789,14 +785,6 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
         const bool final_fused = chained && !needs_state && !jac_at_tnew && n_iter >= 1 && c->final_fuse && !ckpt_next &&
                                  !want_err && !next_err;
         if (final_fused) {
-            // the next row's planes ride on the first launch of this step that does not factorise, its line
-            // factorisation on the launch that ends the step (PreFactor in nk2d_kernels.hip)
-            nk2d_plane_job job = {{times[0], times[1], times[2]}, jstage2, 0};
-            struct JobGuard {
-                nk2d_ctx* c;
-                ~JobGuard() { c->plane_job = nullptr; }
-            } job_guard{c};
-            c->plane_job = (c->prefactor && !c->factor_fp32) ? &job : nullptr;
             NK2D_TRY(newton_fixed(s, h, 0, n_iter - 1, n_iter, row_last, row_prev));
             const double mreal = MU_REAL / h, mcr = MU_CR / h, mci = MU_CI / h;
             const int m = std::max(s.m_real, s.m_cplx);
@@ -807,13 +795,7 @@ int replay_rows(Ctl& s, const double* sched, int64_t n, int64_t i0, bool check, 
                 src = 1 - src;
             }
             c->part_cur = row_last;
-            // the next row's line factorisation rides along when this launch derives that row's Jacobian planes
-            const double h_lu2 = r2[5];
-            const double shifts2[3] = {MU_REAL / h_lu2, MU_CR / h_lu2, MU_CI / h_lu2};
-            const bool pre = jstage2 >= 0 && h_lu2 > 0.0 && std::isfinite(h_lu2);
-            c->plane_job = nullptr;
-            NK2D_TRY(nk2d_r_newton_final(c, m == 1, m == 1, mreal, mcr, mci, (m - 1) & 1, m == 2, times, x[0], x[1], x[2], jstage2,
-                                         job.done != 0, pre ? shifts2 : nullptr));
+            NK2D_TRY(nk2d_r_newton_final(c, m == 1, m == 1, mreal, mcr, mci, (m - 1) & 1, m == 2, times, x[0], x[1], x[2], jstage2));
             c->part_cur = nullptr;
             c->st.nsolve += 2;
             c->st.nfev += 3;
@@ -1060,7 +1042,6 @@ int nk2d_radau_year(nk2d_ctx* c, nk2d_vec x, nk2d_vec fx, nk2d_stats* stats, con
     const auto wall0 = std::chrono::steady_clock::now();
     c->st = nk2d_stats();
     if (c->strm) nk2d_stream_part_forget(c, nullptr);     // (every partial buffer stands for itself until a command takes its name)
-    c->prefactored = 0;
     // every free-running year leaves its accepted steps behind (nk2d_last_schedule): recorded into the caller's
     // buffer, or into the context's own
     int64_t own_n = 0;

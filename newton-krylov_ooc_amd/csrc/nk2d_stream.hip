@@ -331,7 +331,6 @@ unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq
 // controller waits for all-reduces), double precision factor tables
 int nk2d_stream_eligible(const nk2d_ctx* c) {
     if (!c->stream_years || c->stream_lost >= 2 || c->norm_hook || c->factor_fp32) return 0;
-    if (c->xcd_map || c->prefactor) return 0;     // (the launch shape -- option "team" -- is not the stream kernel's concern)
     return 1;
 }
 
@@ -462,7 +461,6 @@ static int stream_start(nk2d_ctx* c) {
     A.fences = c->year_fences;
     A.prof = S->d_prof;
     DevP P = make_devp(c);
-    P.guard = nullptr;
     const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr);
     if (rc != hipSuccess) {
         nk2d_turn_give();

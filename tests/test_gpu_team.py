@@ -1,5 +1,5 @@
-"""Column teams (`k_newton_team`, option "team") and the XCD-contiguous column mapping (option "xcd_map") are
-launch-shape choices of the Newton-iteration kernel: every value is computed by the same operations in the same order
+"""Column teams and pairs (`k_newton_team`, `k_newton_pair`, option "team") are launch-shape choices of the
+Newton-iteration kernel of the launch-per-phase path: every value is computed by the same operations in the same order
 as with one wave per column, so a forward year must come out BIT-IDENTICAL -- results, step schedule and counters --
 for every module kind (iage; phosphorus, whose waves read the other tracers of their column; a forced module with
 forcing files) and for grids that do not fill the last workgroup or the eight XCDs evenly."""
@@ -19,11 +19,10 @@ def make_engine(nz, ny, vv=0.1, kh=1000.0, **kw):
 
 
 def _year_variants(eng, x, counters=("nfev", "njev", "nlu", "nsteps", "nrejected", "nnewton", "nsweeps")):
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (the launch shapes are those of the years that are launched)
     ref = None
-    for team, xcd in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 0)):       # 2: a pair of waves per column
+    for team, xcd in ((0, 0), (1, 0), (2, 0)):       # 2: a pair of waves per column
         eng.set_option("team", team)
-        eng.set_option("xcd_map", xcd)
         fx, stats, sched = eng.comp_fcn(x, record=True)
         got = (eng.download(fx), sched, {k: stats[k] for k in counters})
         if ref is None:
@@ -33,7 +32,6 @@ def _year_variants(eng, x, counters=("nfev", "njev", "nlu", "nsteps", "nrejected
         assert np.array_equal(got[1], ref[1]), (team, xcd)
         assert got[2] == ref[2], (team, xcd)
     eng.set_option("team", -1)
-    eng.set_option("xcd_map", 0)
     return ref
 
 
@@ -55,7 +53,7 @@ def test_team_min_sweeps_two_and_replay():
     model, _ = oracle_iage(26, 26)
     col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2).copy())
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     eng.set_option("min_sweeps", 2)
     out = []
     for team in (0, 1):
@@ -118,7 +116,7 @@ def test_profile_replay_and_shapes():
     model, _ = oracle_iage(26, 26)
     col = np.interp(model.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (26, 26))] * 2).copy())
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     with pytest.raises(Exception, match="forward year"):
         eng.profile_replay(0, 4)
     eng.profile_reset(0)

@@ -8,12 +8,10 @@ from nk_ooc_amd.grid import Grid2d
 
 import os
 sizes = [int(a) for a in sys.argv[1:]] or [26, 104, 416]
-DEVCTL = float(os.environ.get("NK2D_DEVICE_CTL", "0"))
 FRESH = float(os.environ.get("NK2D_JAC_FRESH", "0"))
 for n in sizes:
     grid = Grid2d.default(n, n)
     eng = iage_engine(grid)
-    eng.set_option("device_ctl", DEVCTL)
     eng.set_option("jac_fresh", FRESH)
     eng.set_option("factor_fp32", float(os.environ.get("NK2D_F32", "0")))
     col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])

@@ -13,7 +13,7 @@ from nk_ooc_amd.grid import Grid2d  # noqa: E402
 for n in [int(v) for v in (sys.argv[1:] or ["52", "416"])]:
     grid = Grid2d.default(n, n)
     eng = iage_engine(grid)
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
     x = eng.axpby(1.0, x, 1.0, eng.comp_fcn(x)[0])

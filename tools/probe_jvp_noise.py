@@ -21,9 +21,9 @@ MODES = [("SciPy decisions (jac_fresh 0)", 0, -1), ("J at step start", 1, -1), (
 for n in [int(v) for v in (sys.argv[1:] or ["26", "52", "104"])]:
     grid = Grid2d.default(n, n)
     eng = iage_engine(grid)
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     tight = iage_engine(grid, rtol=1.0e-10, atol=1.0e-10, lin_tol=1.0e-10)
-    tight.set_option("device_ctl", 0)
+    tight.set_option("stream_years", 0)       # (by launches)
     tight.set_option("jac_fresh", 0)
     rng = np.random.default_rng(n)
     col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])

@@ -5,7 +5,7 @@ from nk_ooc_amd.engine import iage_engine
 from nk_ooc_amd.grid import Grid2d
 for nz, ny in ((320, 48), (384, 48), (512, 48), (250, 48)):
     eng = iage_engine(Grid2d.default(nz, ny))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     eng.set_option("frozen_alloc_async", 0)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x0 = np.stack([np.broadcast_to(col[:, None], (nz, ny))] * 2).copy()

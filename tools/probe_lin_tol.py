@@ -16,7 +16,7 @@ grid = Grid2d.default(n, n)
 col = np.interp(grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
 y0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
 tight = iage_engine(grid, rtol=1.0e-9, atol=1.0e-9, lin_tol=1.0e-10)
-tight.set_option("device_ctl", 0)
+tight.set_option("stream_years", 0)       # (by launches)
 tight.set_option("jac_fresh", 0)
 x0 = tight.upload(y0)
 x0 = tight.axpby(1.0, x0, 1.0, tight.comp_fcn(x0)[0])
@@ -24,7 +24,7 @@ xh = tight.download(x0)
 ref = tight.download(tight.comp_fcn(x0)[0])
 tight.close()
 eng = iage_engine(grid)
-eng.set_option("device_ctl", 0)
+eng.set_option("stream_years", 0)       # (by launches)
 x = eng.upload(xh)
 for min_sweeps, tol in ((2, 3e-2), (1, 1e-2), (1, 3e-2), (1, 6e-2), (1, 1e-1), (1, 2e-1), (1, 3e-1)):
     eng.set_option("min_sweeps", min_sweeps)

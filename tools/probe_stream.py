@@ -11,7 +11,7 @@ from nk_ooc_amd.grid import Grid2d  # noqa: E402
 sizes = [int(a) for a in sys.argv[1:]] or [416]
 for n in sizes:
     eng = iage_engine(Grid2d.default(n, n))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x = eng.upload(np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy())
     res = {}
@@ -40,9 +40,4 @@ for n in sizes:
                                                                                "err_estimates_queued", "err_estimates_dropped")), flush=True)
     same = np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     print(f"{n}^2 bit-identical: {same}; speed-up {res[0][0][0] / res[1][0][0]:.2f}x", flush=True)
-    if n <= 128:
-        eng.set_option("stream_years", 0)
-        eng.set_option("device_ctl", 3)
-        best = min(eng.comp_fcn(x)[1]["seconds"] for _ in range(3))
-        print(f"{n}^2 the one-launch year with the controller on the device (device_ctl 3): {best:.4f} s", flush=True)
     eng.close()

@@ -11,7 +11,7 @@ from nk_ooc_amd.grid import Grid2d  # noqa: E402
 sizes = [int(a) for a in sys.argv[1:]] or [416]
 for n in sizes:
     eng = iage_engine(Grid2d.default(n, n))
-    eng.set_option("device_ctl", 0)
+    eng.set_option("stream_years", 0)       # (by launches)
     eng.set_option("frozen_alloc_async", 0)
     col = np.interp(eng.grid.depth.mid, [55.0, 200.0], [0.0, 2.0])
     x0 = np.stack([np.broadcast_to(col[:, None], (n, n))] * 2).copy()
