@@ -221,6 +221,31 @@ __device__ __forceinline__ void load_coef(const DevP& P, int j, int lane, ColCoe
     cf.dyr = P.DYR[j];
 }
 
+// The same from LDS: a wave of a resident kernel owns its column for a whole year and the coefficients are static -- 7 E + 1
+// values per lane, 25 KB per wave at seven levels per lane, fetched from L2 again in every phase otherwise (an eighth of a
+// phase's bytes, a fifth of its load instructions, all of them ahead of the first tendency)
+#define NK2D_COEF_LDS_DOUBLES(E) ((7 * (E) + 1) * 64)
+template <int E>
+__device__ __forceinline__ void store_coef_lds(double* s, int lane, const ColCoef<E>& cf) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        s[(0 * E + e) * 64 + lane] = cf.vS[e]; s[(1 * E + e) * 64 + lane] = cf.vN[e]; s[(2 * E + e) * 64 + lane] = cf.khS[e];
+        s[(3 * E + e) * 64 + lane] = cf.khN[e]; s[(4 * E + e) * 64 + lane] = cf.wT[e]; s[(5 * E + e) * 64 + lane] = cf.wB[e];
+        s[(6 * E + e) * 64 + lane] = cf.dzr[e];
+    }
+    s[7 * E * 64 + lane] = cf.dyr;
+}
+template <int E>
+__device__ __forceinline__ void load_coef_lds(const double* s, int lane, ColCoef<E>& cf) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        cf.vS[e] = s[(0 * E + e) * 64 + lane]; cf.vN[e] = s[(1 * E + e) * 64 + lane]; cf.khS[e] = s[(2 * E + e) * 64 + lane];
+        cf.khN[e] = s[(3 * E + e) * 64 + lane]; cf.wT[e] = s[(4 * E + e) * 64 + lane]; cf.wB[e] = s[(5 * E + e) * 64 + lane];
+        cf.dzr[e] = s[(6 * E + e) * 64 + lane];
+    }
+    cf.dyr = s[7 * E * 64 + lane];
+}
+
 // c: own column, cs / cn: columns j-1 / j+1 (any finite values at the walls, their
 // face coefficients are zero), kv: vertical mixing coeff between level k and k+1
 template <int E, int KIND = 0>
@@ -827,15 +852,16 @@ struct FusedArgs {
 // STAGE = 0: instantiation for launches without the stage part.  For the phosphorus module the
 // full kernel needs more registers than two waves per SIMD leave while its 3 ny columns are more
 // waves than the chip has SIMDs; the stage-less instantiation fits and runs in one round.
-template <int E, int KIND, int FACTOR, int STAGE, int MP = 0, int FINAL = 0>
+template <int E, int KIND, int FACTOR, int STAGE, int MP = 0, int FINAL = 0, int CL = 0>
 __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane,
-                                                  const FinalArgs* fin = nullptr) {
+                                                  const FinalArgs* fin = nullptr, const double* coef_lds = nullptr) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
     if (STAGE && A.do_stage) {
         ColCoef<E> cf;
-        load_coef<E>(P, j, lane, cf);
+        if constexpr (CL) load_coef_lds<E>(coef_lds, lane, cf);       // (the wave's own column: stored there at kernel entry)
+        else load_coef<E>(P, j, lane, cf);
         double y0[E], ys[E], yn[E];
         load_col<E, MP>(A.st.y, task, lane, y0);
         load_col<E, MP>(A.st.y, cs_col, lane, ys);
@@ -2142,6 +2168,7 @@ struct FrozenArgs {
     double* out;                 // [32]: status, rows done, parities
     long long spin_ticks;
     int fences;
+    int coef_lds;                // 1: the static coefficients of a wave's column live in LDS for the year (option "frozen_coef_lds")
     unsigned* tickets;           // XCD flavour: the workgroups that find themselves on XCD 0 take a number here
     int nwg;                     // ... until this many have one
 };

@@ -104,6 +104,18 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
 #define FZ_ZN (swapZ ? A.Z : A.ZN)
 #define FZ_SYNC() \
     if (!(NB ? nbs.sync() : bar.sync())) { status = 1; goto finish; }
+    // a wave per column, three and more levels per lane (option "frozen_coef_lds"): the static coefficients of the wave's column
+    // in LDS for the whole year (dynamic shared memory of the launch: NK2D_COEF_LDS_DOUBLES(E) doubles per wave)
+    constexpr bool COEF_LDS = NB != 0 && !TEAM && !XCD && E >= 3;
+    extern __shared__ double dyn_lds[];
+    double* my_coef = dyn_lds + (size_t)(threadIdx.x >> 6) * NK2D_COEF_LDS_DOUBLES(E);
+    if constexpr (COEF_LDS) {
+        if (A.coef_lds && col_wave) {
+            ColCoef<E> cf;
+            load_coef<E>(P, wave % P.ny, lane, cf);
+            store_coef_lds<E>(my_coef, lane, cf);
+        }
+    }
     // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
     if (col_wave && (!TEAM || tw == 0)) {
         double zero[E];
@@ -171,6 +183,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                         if constexpr (KIND == 0 && E <= 2) {
                             if (m == 1) { newton_single_body<E, MPX, 1>(P, FA, wave, lane, &Fin); taken = true; }
                         }
+                        if constexpr (COEF_LDS) {
+                            if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 1>(P, FA, wave, lane, &Fin, my_coef); taken = true; }
+                        }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 1>(P, FA, wave, lane, &Fin);
                     }
                     swapY ^= 1;
@@ -183,6 +198,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                         bool taken = false;
                         if constexpr (KIND == 0 && E <= 2) {
                             if (m == 1) { newton_single_body<E, MPX, 0>(P, FA, wave, lane); taken = true; }
+                        }
+                        if constexpr (COEF_LDS) {
+                            if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 1>(P, FA, wave, lane, nullptr, my_coef); taken = true; }
                         }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 0>(P, FA, wave, lane);
                     }
@@ -308,9 +326,9 @@ void nk2d_frozen_cache_free(nk2d_ctx* c) {
 // same check and nothing else for this kernel -- through a queue of its own that the HIP runtime crashed on when the process
 // ended under rocprofv3 (rounds 2 - 3: AqlQueue::~AqlQueue under hsa_shut_down).
 template <class K>
-static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, DevP& P, FrozenArgs& A) {
+static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, DevP& P, FrozenArgs& A, size_t lds_bytes = 0) {
     int per_cu = 0;
-    hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block.x, 0);
+    hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block.x, lds_bytes);
     if (rc != hipSuccess) return rc;
     hipDeviceProp_t prop;
     rc = hipGetDeviceProperties(&prop, c->dev);
@@ -319,9 +337,9 @@ static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, 
     if (std::getenv("NK2D_DIAG_COOPERATIVE")) {
         // diagnostic only (profiles/r04_slowdown_ab.log): the launch as rounds 2 - 3 made it, through the runtime's cooperative queue
         void* args[2] = {&P, &A};
-        return hipLaunchCooperativeKernel((const void*)kernel, grid, block, args, 0, nk2d_s(c));
+        return hipLaunchCooperativeKernel((const void*)kernel, grid, block, args, (unsigned)lds_bytes, nk2d_s(c));
     }
-    hipLaunchKernelGGL(kernel, grid, block, 0, nk2d_s(c), P, A);
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, nk2d_s(c), P, A);
     return hipGetLastError();
 }
 
@@ -334,7 +352,9 @@ static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, 
                 // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
                 const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
                 const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
-                return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A);
+                // (a wave per column, three and more levels per lane: room for the static coefficients of its column in LDS)
+                const size_t lds = (!TEAM && E >= 3 && A.coef_lds) ? sizeof(double) * NK2D_COEF_LDS_DOUBLES(E) * wpb : 0;
+                return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A, lds);
             }
         }
         return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), P, A);
@@ -574,6 +594,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     A.out = c->YR_OUT;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
+    A.coef_lds = c->frozen_coef_lds;
     // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column.  Measured
     // (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want a CU each -- on one XCD, two to four
     // workgroups to a CU, they lose more than they gain (26^2: 13.3 ms, 16.1 ms when LDS padding forces exactly two per CU) --

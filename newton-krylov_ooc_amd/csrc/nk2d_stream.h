@@ -88,6 +88,7 @@ struct StreamArgs {
     int nwg, cpw;                       // workgroups, ypos columns per workgroup
     long long spin_ticks;               // longest wait (ticks of s_memrealtime, 100 MHz)
     int fences;
+    int coef_lds;                       // 1: the static coefficients of the workgroup's ypos columns live in LDS (dynamic shared memory)
     unsigned long long* prof;           // [nwg][12]: ticks waiting for a command, executing, waiting for neighbours; commands; per op
 };
 

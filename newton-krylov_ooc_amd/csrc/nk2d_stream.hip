@@ -78,6 +78,17 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
     const int nw = (int)(blockDim.x >> 6);
     const int j0 = wg * A.cpw, j1 = min(j0 + A.cpw, P.ny);   // this workgroup's ypos columns, every tracer of them
     const int left = (wg > 0) ? wg - 1 : -1, right = (wg < A.nwg - 1) ? wg + 1 : -1;
+    // the static coefficients of this workgroup's ypos columns (the same for every tracer of a column) in LDS for as long as the
+    // kernel runs: otherwise fetched from L2 by every Newton command (see load_coef_lds)
+    extern __shared__ double dyn_lds[];
+    if (A.coef_lds) {
+        for (int j = j0 + tw; j < j1; j += nw) {
+            ColCoef<E> cf;
+            load_coef<E>(P, j, lane, cf);
+            store_coef_lds<E>(dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E), lane, cf);
+        }
+        __syncthreads();
+    }
     unsigned seq = A.seq0;
     int status = 0;
     long long t_cmd = 0, t_exec = 0, t_nb = 0, n_cmd = 0;     // where the time of this workgroup goes (wave 0's clock)
@@ -145,8 +156,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
         if (op == NK2D_OP_NEWTON) {
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
-                    if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
-                    else newton_fused_body<E, KIND, 0, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                    const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
+                    if (A.coef_lds) {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
+                    } else {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                        else newton_fused_body<E, KIND, 0, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
+                    }
                 }
         } else if (op == NK2D_OP_NEWTON_FINAL) {
             // the last Newton iteration of a frozen step, which also ends the step (y_new, the next attempt's predicted stage
@@ -155,8 +172,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
             const StreamFinal& S = cmd.u.fn;
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
-                    if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
-                    else newton_fused_body<E, KIND, 0, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
+                    const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
+                    if (A.coef_lds) {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
+                    } else {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
+                    }
                 }
             for (int ti = tw; ti < 3; ti += nw)
                 for (int j = j0; j < j1; ++j) {
@@ -290,6 +313,7 @@ struct nk2d_stream_state {
     unsigned done_upto = 0;                 // every workgroup is known to have completed this command
     std::deque<unsigned> notifies;          // commands flagged NOTIFY that have not been waited for yet
     bool running = false, lost = false;
+    bool coef_lds = true;                   // the static coefficients of a workgroup's columns in LDS (NK2D_STREAM_COEF_LDS=0: not)
     bool direct = false;                    // the host writes its commands straight into d_ring (large BAR): no relay hop
     int nwg = 0, cpw = 1, nw = 1;
     int64_t launches = 0;
@@ -335,21 +359,25 @@ int nk2d_stream_eligible(const nk2d_ctx* c) {
 }
 
 template <int E, int KIND>
-static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks) {
+static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes) {
     if (max_blocks) {
         int nb = 0;
-        hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<E, KIND>, (int)block.x, 0);
+        hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<E, KIND>, (int)block.x, lds_bytes);
         if (rc != hipSuccess) return rc;
         *max_blocks = nb;
         return hipSuccess;
     }
-    hipLaunchKernelGGL((k_stream<E, KIND>), grid, block, 0, c->stream_, P, A);
+    hipLaunchKernelGGL((k_stream<E, KIND>), grid, block, lds_bytes, c->stream_, P, A);
     return hipGetLastError();
 }
-static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks) {
+static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes) {
     hipError_t rc = hipErrorInvalidValue;
-    NK2D_DISPATCH_EK(c->E, c->kind, rc = (stream_launch_one<EE, KK>(c, grid, block, P, A, max_blocks)));
+    NK2D_DISPATCH_EK(c->E, c->kind, rc = (stream_launch_one<EE, KK>(c, grid, block, P, A, max_blocks, lds_bytes)));
     return rc;
+}
+// dynamic shared memory of a launch whose workgroups own cpw ypos columns each
+static size_t stream_lds_bytes(const nk2d_ctx* c, int cpw, bool coef_lds) {
+    return coef_lds ? sizeof(double) * (size_t)cpw * NK2D_COEF_LDS_DOUBLES(c->E) : 0;
 }
 
 static int stream_alloc(nk2d_ctx* c) {
@@ -358,16 +386,23 @@ static int stream_alloc(nk2d_ctx* c) {
     c->strm = S;
     S->nw = std::min(c->tc, NK2D_WAVES_PER_BLOCK);
     // ypos columns per workgroup: one where the chip holds a workgroup per column, more where it does not
-    int per_cu = 0;
     DevP P = make_devp(c);
     StreamArgs A = {};
-    NK2D_CHECK(c, stream_launch(c, dim3(1), dim3(64 * S->nw), P, A, &per_cu));
     hipDeviceProp_t prop;
     NK2D_CHECK(c, hipGetDeviceProperties(&prop, c->dev));
-    const int capacity = per_cu * prop.multiProcessorCount - 1;     // (one workgroup is the relay's)
-    if (capacity < 1) return nk2d_fail(c, "command stream: the kernel does not fit a compute unit");
-    S->cpw = (c->ny + capacity - 1) / capacity;
-    S->nwg = (c->ny + S->cpw - 1) / S->cpw;
+    S->coef_lds = std::getenv("NK2D_STREAM_COEF_LDS") == nullptr || std::atoi(std::getenv("NK2D_STREAM_COEF_LDS")) != 0;
+    // (the columns per workgroup and the LDS they need depend on each other: one column first, more until the grid fits)
+    for (S->cpw = 1;; ++S->cpw) {
+        int per_cu = 0;
+        NK2D_CHECK(c, stream_launch(c, dim3(1), dim3(64 * S->nw), P, A, &per_cu, stream_lds_bytes(c, S->cpw, S->coef_lds)));
+        const int capacity = per_cu * prop.multiProcessorCount - 1;     // (one workgroup is the relay's)
+        S->nwg = (c->ny + S->cpw - 1) / S->cpw;
+        if (capacity >= S->nwg) break;
+        if (S->cpw >= c->ny) {
+            if (S->coef_lds) { S->coef_lds = false; S->cpw = 0; continue; }     // (without the LDS copy, then)
+            return nk2d_fail(c, "command stream: the kernel does not fit a compute unit");
+        }
+    }
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_done, sizeof(unsigned) * S->nwg));
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_status, sizeof(unsigned) * 16));
@@ -460,8 +495,9 @@ static int stream_start(nk2d_ctx* c) {
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
     A.prof = S->d_prof;
+    A.coef_lds = S->coef_lds ? 1 : 0;
     DevP P = make_devp(c);
-    const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr);
+    const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr, stream_lds_bytes(c, S->cpw, S->coef_lds));
     if (rc != hipSuccess) {
         nk2d_turn_give();
         NK2D_CHECK(c, rc);
