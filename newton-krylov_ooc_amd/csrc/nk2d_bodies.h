@@ -852,15 +852,31 @@ struct FusedArgs {
 // STAGE = 0: instantiation for launches without the stage part.  For the phosphorus module the
 // full kernel needs more registers than two waves per SIMD leave while its 3 ny columns are more
 // waves than the chip has SIMDs; the stage-less instantiation fits and runs in one round.
+// W of a column in LDS ([3][E][64] doubles behind the coefficients): W is the wave's own, read and rewritten by every Newton
+// iteration and by nothing else -- a fifth of an iteration's bytes that need not leave the compute unit while a resident kernel runs
+template <int E>
+__device__ __forceinline__ void w_lds_get(const double* s, int r, int lane, double (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s[(r * E + e) * 64 + lane];
+}
+template <int E>
+__device__ __forceinline__ void w_lds_put(double* s, int r, int lane, const double (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[(r * E + e) * 64 + lane] = v[e];
+}
+
+// CL: bit 0 -- the static coefficients of the column come from LDS (load_coef_lds), bit 1 -- W lives in LDS (w_lds_get / _put);
+// at `coef_lds` / `w_lds`
 template <int E, int KIND, int FACTOR, int STAGE, int MP = 0, int FINAL = 0, int CL = 0>
 __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane,
-                                                  const FinalArgs* fin = nullptr, const double* coef_lds = nullptr) {
+                                                  const FinalArgs* fin = nullptr, const double* coef_lds = nullptr,
+                                                  double* w_lds = nullptr) {
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
     if (STAGE && A.do_stage) {
         ColCoef<E> cf;
-        if constexpr (CL) load_coef_lds<E>(coef_lds, lane, cf);       // (the wave's own column: stored there at kernel entry)
+        if constexpr (CL & 1) load_coef_lds<E>(coef_lds, lane, cf);       // (the wave's own column: stored there at kernel entry)
         else load_coef<E>(P, j, lane, cf);
         double y0[E], ys[E], yn[E];
         load_col<E, MP>(A.st.y, task, lane, y0);
@@ -894,9 +910,13 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
             }
         }
         double w0[E], w1[E], w2[E];
-        load_col<E>(A.st.w, task, lane, w0);
-        load_col<E>(A.st.w + A.st.nv, task, lane, w1);
-        load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+        if constexpr (CL & 2) {
+            w_lds_get<E>(w_lds, 0, lane, w0); w_lds_get<E>(w_lds, 1, lane, w1); w_lds_get<E>(w_lds, 2, lane, w2);
+        } else {
+            load_col<E>(A.st.w, task, lane, w0);
+            load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+            load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             fr[e] = fr[e] - A.st.mreal * w0[e];
@@ -1048,9 +1068,13 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
     // dW = (fr, fcr, fci): norm partial, W += dW, Z = T W
     double yy[E], w0[E], w1[E], w2[E];
     load_col<E, MP>(A.st.y, task, lane, yy);
-    load_col<E>(A.st.w, task, lane, w0);
-    load_col<E>(A.st.w + A.st.nv, task, lane, w1);
-    load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+    if constexpr (CL & 2) {
+        w_lds_get<E>(w_lds, 0, lane, w0); w_lds_get<E>(w_lds, 1, lane, w1); w_lds_get<E>(w_lds, 2, lane, w2);
+    } else {
+        load_col<E>(A.st.w, task, lane, w0);
+        load_col<E>(A.st.w + A.st.nv, task, lane, w1);
+        load_col<E>(A.st.w + 2 * A.st.nv, task, lane, w2);
+    }
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1097,14 +1121,19 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
             for (int e = 0; e < E; ++e) wv[e] = (cTI[r][0] * o[0][e] + cTI[r][1] * o[1][e]) + cTI[r][2] * o[2][e];
-            store_col<E>(wout + r * A.st.nv, task, lane, wv);
+            if constexpr (CL & 2) w_lds_put<E>(w_lds, r, lane, wv);
+            else store_col<E>(wout + r * A.st.nv, task, lane, wv);
         }
         return;
     }
     double* zout = A.st.zout;
-    store_col<E>(wout, task, lane, w0);
-    store_col<E>(wout + A.st.nv, task, lane, w1);
-    store_col<E>(wout + 2 * A.st.nv, task, lane, w2);
+    if constexpr (CL & 2) {
+        w_lds_put<E>(w_lds, 0, lane, w0); w_lds_put<E>(w_lds, 1, lane, w1); w_lds_put<E>(w_lds, 2, lane, w2);
+    } else {
+        store_col<E>(wout, task, lane, w0);
+        store_col<E>(wout + A.st.nv, task, lane, w1);
+        store_col<E>(wout + 2 * A.st.nv, task, lane, w2);
+    }
     double zz[E];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -2168,7 +2197,7 @@ struct FrozenArgs {
     double* out;                 // [32]: status, rows done, parities
     long long spin_ticks;
     int fences;
-    int coef_lds;                // 1: the static coefficients of a wave's column live in LDS for the year (option "frozen_coef_lds")
+    int coef_lds;                // option "frozen_coef_lds": bit 0 -- the static coefficients of a wave's column live in LDS for the year, bit 1 -- W too
     unsigned* tickets;           // XCD flavour: the workgroups that find themselves on XCD 0 take a number here
     int nwg;                     // ... until this many have one
 };

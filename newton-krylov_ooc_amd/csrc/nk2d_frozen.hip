@@ -108,7 +108,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
     // in LDS for the whole year (dynamic shared memory of the launch: NK2D_COEF_LDS_DOUBLES(E) doubles per wave)
     constexpr bool COEF_LDS = NB != 0 && !TEAM && !XCD && E >= 3;
     extern __shared__ double dyn_lds[];
-    double* my_coef = dyn_lds + (size_t)(threadIdx.x >> 6) * NK2D_COEF_LDS_DOUBLES(E);
+    const bool w_in_lds = COEF_LDS && (A.coef_lds & 2) != 0;
+    double* my_coef = dyn_lds + (size_t)(threadIdx.x >> 6) * (NK2D_COEF_LDS_DOUBLES(E) + (w_in_lds ? 3 * E * 64 : 0));
+    double* my_w = my_coef + NK2D_COEF_LDS_DOUBLES(E);
+    (void)my_w;
     if constexpr (COEF_LDS) {
         if (A.coef_lds && col_wave) {
             ColCoef<E> cf;
@@ -125,6 +128,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         for (int i = 0; i < 3; ++i) {
             store_col<E, MPX>(FZ_Z + i * nv, wave, lane, zero);
             store_col<E, (TEAM ? MPX : 0)>(A.W + i * nv, wave, lane, zero);
+            if constexpr (COEF_LDS) {
+                if (w_in_lds) w_lds_put<E>(my_w, i, lane, zero);
+            }
         }
     }
     FZ_SYNC()
@@ -184,7 +190,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                             if (m == 1) { newton_single_body<E, MPX, 1>(P, FA, wave, lane, &Fin); taken = true; }
                         }
                         if constexpr (COEF_LDS) {
-                            if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 1>(P, FA, wave, lane, &Fin, my_coef); taken = true; }
+                            if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 3>(P, FA, wave, lane, &Fin, my_coef, my_w); taken = true; }
+                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 1>(P, FA, wave, lane, &Fin, my_coef); taken = true; }
                         }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 1>(P, FA, wave, lane, &Fin);
                     }
@@ -200,7 +207,8 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                             if (m == 1) { newton_single_body<E, MPX, 0>(P, FA, wave, lane); taken = true; }
                         }
                         if constexpr (COEF_LDS) {
-                            if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 1>(P, FA, wave, lane, nullptr, my_coef); taken = true; }
+                            if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 3>(P, FA, wave, lane, nullptr, my_coef, my_w); taken = true; }
+                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 1>(P, FA, wave, lane, nullptr, my_coef); taken = true; }
                         }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 0>(P, FA, wave, lane);
                     }
@@ -230,6 +238,17 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                 Fin.x0 = R.x0; Fin.x1 = R.x1; Fin.x2 = R.x2;
                 Fin.nblk_cols = 0;
                 step_tail_body<E, MPX>(FZ_Y, FZ_Z, nv, Fin, A.W, wave, lane);
+                if constexpr (COEF_LDS) {
+                    if (w_in_lds) {     // (this rare phase writes W to memory: into the column's LDS copy from there)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            double wv[E];
+                            load_col<E, (TEAM ? MPX : 0)>(A.W + r * nv, wave, lane, wv);
+                            w_lds_put<E>(my_w, r, lane, wv);
+                        }
+                    }
+                }
             }
             swapY ^= 1;
             swapZ ^= 1;
@@ -238,6 +257,16 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         done = i + 1;
     }
 finish:
+    if constexpr (COEF_LDS) {
+        if (w_in_lds && col_wave) {      // W of the last phase back where the launch-per-phase path keeps it
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double wv[E];
+                w_lds_get<E>(my_w, r, lane, wv);
+                store_col<E>(A.W + r * nv, wave, lane, wv);
+            }
+        }
+    }
     if constexpr (NB != 0) {
         // no barrier behind the last phase: every workgroup reports a failure of its own (the host cleared `out`), the first
         // the rest -- a workgroup that gave up raised the abort flag, its neighbours give up on it in turn
@@ -353,7 +382,8 @@ static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, 
                 const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
                 const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
                 // (a wave per column, three and more levels per lane: room for the static coefficients of its column in LDS)
-                const size_t lds = (!TEAM && E >= 3 && A.coef_lds) ? sizeof(double) * NK2D_COEF_LDS_DOUBLES(E) * wpb : 0;
+                const size_t lds = (!TEAM && E >= 3 && A.coef_lds)
+                                       ? sizeof(double) * (NK2D_COEF_LDS_DOUBLES(E) + ((A.coef_lds & 2) ? 3 * E * 64 : 0)) * wpb : 0;
                 return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A, lds);
             }
         }
@@ -594,7 +624,9 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     A.out = c->YR_OUT;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
+    // (W beside the coefficients where four waves' blocks fit a compute unit's 160 KB: up to seven levels per lane)
     A.coef_lds = c->frozen_coef_lds;
+    if ((A.coef_lds & 2) && 4 * sizeof(double) * (NK2D_COEF_LDS_DOUBLES(c->E) + 3 * c->E * 64) > 160 * 1024) A.coef_lds &= 1;
     // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column.  Measured
     // (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want a CU each -- on one XCD, two to four
     // workgroups to a CU, they lose more than they gain (26^2: 13.3 ms, 16.1 ms when LDS padding forces exactly two per CU) --

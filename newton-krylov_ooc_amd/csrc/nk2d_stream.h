@@ -88,7 +88,9 @@ struct StreamArgs {
     int nwg, cpw;                       // workgroups, ypos columns per workgroup
     long long spin_ticks;               // longest wait (ticks of s_memrealtime, 100 MHz)
     int fences;
-    int coef_lds;                       // 1: the static coefficients of the workgroup's ypos columns live in LDS (dynamic shared memory)
+    int coef_lds;                       // bit 0: the static coefficients of the workgroup's ypos columns live in LDS (dynamic shared
+                                        // memory), bit 1: so does W of its columns
+    double* W;                          // the context's W (3 nv): loaded into LDS when the kernel starts, stored back when it ends
     unsigned long long* prof;           // [nwg][12]: ticks waiting for a command, executing, waiting for neighbours; commands; per op
 };
 

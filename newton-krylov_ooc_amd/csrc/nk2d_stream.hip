@@ -80,13 +80,31 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
     const int left = (wg > 0) ? wg - 1 : -1, right = (wg < A.nwg - 1) ? wg + 1 : -1;
     // the static coefficients of this workgroup's ypos columns (the same for every tracer of a column) in LDS for as long as the
     // kernel runs: otherwise fetched from L2 by every Newton command (see load_coef_lds)
+    // ... and W of its columns (every tracer): the wave's own, read and rewritten by every Newton command and by nothing else of
+    // this kernel but the predictions of SETUP / BOUNDARY -- loaded when the kernel starts, stored back when it ends (what runs
+    // between two kernels of a year finds it in memory)
     extern __shared__ double dyn_lds[];
+    const bool w_in_lds = (A.coef_lds & 2) != 0;
+    double* const w_base = dyn_lds + (size_t)A.cpw * NK2D_COEF_LDS_DOUBLES(E);
+    const size_t nvw = (size_t)P.ncol * (E * 64);
+#define ST_WLDS(tr, j) (w_base + ((size_t)((j) - j0) * P.tc + (tr)) * (3 * E * 64))
+    auto w_from_memory = [&](int tr, int j) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double wv[E];
+            load_col<E>(A.W + r * nvw, tr * P.ny + j, lane, wv);
+            w_lds_put<E>(ST_WLDS(tr, j), r, lane, wv);
+        }
+    };
     if (A.coef_lds) {
         for (int j = j0 + tw; j < j1; j += nw) {
             ColCoef<E> cf;
             load_coef<E>(P, j, lane, cf);
             store_coef_lds<E>(dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E), lane, cf);
         }
+        if (w_in_lds)
+            for (int tr = tw; tr < P.tc; tr += nw)
+                for (int j = j0; j < j1; ++j) w_from_memory(tr, j);
         __syncthreads();
     }
     unsigned seq = A.seq0;
@@ -157,7 +175,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
                     const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
-                    if (A.coef_lds) {
+                    if (w_in_lds) {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl, ST_WLDS(tr, j));
+                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl, ST_WLDS(tr, j));
+                    } else if (A.coef_lds) {
                         if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
                         else newton_fused_body<E, KIND, 0, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
                     } else {
@@ -173,7 +194,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
                     const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
-                    if (A.coef_lds) {
+                    if (w_in_lds) {
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl, ST_WLDS(tr, j));
+                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl, ST_WLDS(tr, j));
+                    } else if (A.coef_lds) {
                         if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
                         else newton_fused_body<E, KIND, 0, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
                     } else {
@@ -203,7 +227,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
                         jac_core<E, 1>(P, kv, S.V.out[ti], S.J.JL, S.J.JU, S.J.JS, S.J.JN, S.J.JC, nullptr, nullptr, j, lane);
                 }
             for (int tr = tw; tr < P.tc; tr += nw)
-                for (int j = j0; j < j1; ++j) predict_body<E, 1>(S.A, tr * P.ny + j, lane);
+                for (int j = j0; j < j1; ++j) {
+                    predict_body<E, 1>(S.A, tr * P.ny + j, lane);
+                    if (w_in_lds) {      // (the prediction wrote W to memory: into the column's LDS copy from there)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        w_from_memory(tr, j);
+                    }
+                }
         } else if (op == NK2D_OP_BOUNDARY) {
             const StreamBoundary& S = cmd.u.bd;
             for (int ti = tw; ti < 3; ti += nw)
@@ -230,6 +260,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's y_new is in memory before it reads it back
                     predict_body<E, 1>(S.A, task, lane);
+                    if (w_in_lds) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        w_from_memory(tr, j);
+                    }
                 }
         }
         else if (op == NK2D_OP_SWEEP) {
@@ -284,6 +318,18 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
         }
         ++seq;
     }
+    if (w_in_lds) {      // W back to memory: whatever runs behind this kernel (launches, the next kernel of the year) finds it there
+        for (int tr = tw; tr < P.tc; tr += nw)
+            for (int j = j0; j < j1; ++j) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double wv[E];
+                    w_lds_get<E>(ST_WLDS(tr, j), r, lane, wv);
+                    store_col<E>(A.W + r * nvw, tr * P.ny + j, lane, wv);
+                }
+            }
+    }
+#undef ST_WLDS
     if (A.prof && threadIdx.x == 0) {
         unsigned long long* pr = A.prof + (size_t)wg * 12;
         pr[0] += (unsigned long long)t_cmd; pr[1] += (unsigned long long)t_exec; pr[2] += (unsigned long long)t_nb;
@@ -377,7 +423,7 @@ static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, Str
 }
 // dynamic shared memory of a launch whose workgroups own cpw ypos columns each
 static size_t stream_lds_bytes(const nk2d_ctx* c, int cpw, bool coef_lds) {
-    return coef_lds ? sizeof(double) * (size_t)cpw * NK2D_COEF_LDS_DOUBLES(c->E) : 0;
+    return coef_lds ? sizeof(double) * (size_t)cpw * (NK2D_COEF_LDS_DOUBLES(c->E) + (size_t)c->tc * 3 * c->E * 64) : 0;
 }
 
 static int stream_alloc(nk2d_ctx* c) {
@@ -495,7 +541,8 @@ static int stream_start(nk2d_ctx* c) {
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
     A.prof = S->d_prof;
-    A.coef_lds = S->coef_lds ? 1 : 0;
+    A.coef_lds = S->coef_lds ? 3 : 0;
+    A.W = c->W;
     DevP P = make_devp(c);
     const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr, stream_lds_bytes(c, S->cpw, S->coef_lds));
     if (rc != hipSuccess) {

@@ -18,7 +18,7 @@ for n in [int(a) for a in sys.argv[2:]] or [416]:
     xp = eng.upload(x0 * (1.0 + 1.0e-4 * np.outer(np.sin(3.0 * zz), np.cos(2.0 * zz))[None]))
     fx, st, sched = eng.comp_fcn(x, record=True)
     ref = None
-    for opt in (1, 0, 1, 0):
+    for opt in ((3, 1, 0, 3, 1, 0) if option == "frozen_coef_lds" else (1, 0, 1, 0)):
         eng.set_option(option, opt)
         best = min(eng.comp_fcn_frozen(xp, sched)[1]["seconds"] for _ in range(5))
         got = eng.download(eng.comp_fcn_frozen(xp, sched)[0])
