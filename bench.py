@@ -513,7 +513,7 @@ def roofline_of(eng, n):
         levels = (eng.nz + 63) // 64
         flavour = ("a four-wave team per column" if eng.counter("frozen_team_years") else "a wave per column") + (
             ", all workgroups on one XCD" if eng.counter("frozen_xcd_years") else
-            ", cooperative launch, workgroups hand over to their lateral neighbours")
+            ", all workgroups resident, workgroups hand over to their lateral neighbours; static coefficients and W of a column in LDS")
         out = {"bound": "hbm", "kernel": f"k_frozen_persistent<{levels}, 0, ...> (a whole frozen year in ONE launch on the schedule "
                                          f"cache: one simplified-Newton iteration per phase; {flavour})",
                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -525,7 +525,8 @@ def roofline_of(eng, n):
                "year_seconds_host_clock": ModelState.last_stats[0]["seconds"],
                "one_launch_years": eng.counter("frozen_persistent_years"), "team_years": eng.counter("frozen_team_years"),
                "xcd_local_years": eng.counter("frozen_xcd_years"), "schedule_cache_builds": eng.counter("frozen_cache_builds")}
-        pmc_fname = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_one_launch_{n}.json")
+        pmc_fname = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02}_pmc_traffic_one_launch_{n}.json") for r in (4, 3))
+                          if os.path.exists(f)), "")
         if os.path.exists(pmc_fname):
             pmc = json.load(open(pmc_fname))
             # the counters were collected on a year of another schedule (tools/probe_traffic.py: 9 751 phases, here
@@ -536,7 +537,8 @@ def roofline_of(eng, n):
                                      "FETCH_SIZE / WRITE_SIZE passes over the same kernel on another year: "
                                      f"{pmc['traffic_bytes_per_launch_upper']:.4g} B of fabric traffic for "
                                      f"{pmc['algorithmic_bytes_per_launch']:.4g} algorithmic; not collected in this run)")
-        stats_fname = os.path.join(ROOT, "profiles", f"r03_rocprof_one_launch_{n}", "kernel_stats.csv")
+        stats_fname = next((f for f in (os.path.join(ROOT, "profiles", d, "kernel_stats.csv")
+                                        for d in (f"r04_rocprof_one_launch_{n}", f"r03_rocprof_one_launch_{n}")) if os.path.exists(f)), "")
         if os.path.exists(stats_fname):
             for line in open(stats_fname):
                 if line.startswith('"void k_frozen_persistent<' + str(levels)):
