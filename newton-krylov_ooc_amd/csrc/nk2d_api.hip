@@ -149,7 +149,8 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
     if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
     if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
-    if (key == "frozen_coef_lds") { c->frozen_coef_lds = (int)value & 3; return 0; }
+    if (key == "frozen_coef_lds") { c->frozen_coef_lds = (int)value & 15; return 0; }
+    if (key == "frozen_by_column") { c->frozen_by_column = (int)value; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
     if (key == "spec_bias") { c->spec_bias = value > 0.0 ? value : 1.0; return 0; }
     if (key == "stream_years") { c->stream_years = (int)value; c->stream_lost = 0; return 0; }
@@ -514,7 +515,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_team = 1;
     c->frozen_nbsync = 1;
     c->frozen_cache_after = 0;
-    c->frozen_coef_lds = 3;
+    c->frozen_coef_lds = 15;
+    c->frozen_by_column = 1;
     c->strm = nullptr;
     c->spec_bias = 1.0;
     c->stream_years = 1;      // free-running years as command streams where eligible (bit 2: frozen years too)

@@ -865,12 +865,29 @@ __device__ __forceinline__ void w_lds_put(double* s, int r, int lane, const doub
     for (int e = 0; e < E; ++e) s[(r * E + e) * 64 + lane] = v[e];
 }
 
-// CL: bit 0 -- the static coefficients of the column come from LDS (load_coef_lds), bit 1 -- W lives in LDS (w_lds_get / _put);
-// at `coef_lds` / `w_lds`
+// What a column's wave finds in LDS inside a resident kernel (CL, a bit mask):
+//   bit 0  coef: the static coefficients of the column (load_coef_lds)
+//   bit 1  w   : W of the column lives there (w_lds_get / _put)
+//   bit 2  step: what is constant over the Newton iterations of a STEP and the same for every tracer of the ypos column -- the
+//                three mixing columns of the stage times, then the vertical Jacobian diagonals JL, JU ([5][E][64] doubles)
+//   bit 3  piv : the pivot reciprocals of the column's real system ([E][64])
+struct LdsSrc {
+    const double* coef;
+    double* w;
+    const double* step;
+    const double* piv;
+};
+template <int E>
+__device__ __forceinline__ void col_lds_get(const double* s, int r, int lane, double (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s[(r * E + e) * 64 + lane];
+}
 template <int E, int KIND, int FACTOR, int STAGE, int MP = 0, int FINAL = 0, int CL = 0>
 __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs& A, int task, int lane,
-                                                  const FinalArgs* fin = nullptr, const double* coef_lds = nullptr,
-                                                  double* w_lds = nullptr) {
+                                                  const FinalArgs* fin = nullptr, const LdsSrc* lds = nullptr) {
+    const double* coef_lds = (CL & 1) ? lds->coef : nullptr;
+    double* w_lds = (CL & 2) ? lds->w : nullptr;
+    (void)coef_lds; (void)w_lds;
     const int tr = task / P.ny, j = task - tr * P.ny;
     const int cs_col = (j > 0) ? task - 1 : task, cn_col = (j < P.ny - 1) ? task + 1 : task;
     double fr[E], fcr[E], fci[E];
@@ -890,7 +907,8 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
             load_col<E, MP>(A.st.z + i * A.st.nv, task, lane, c);
             load_col<E, MP>(A.st.z + i * A.st.nv, cs_col, lane, cs);
             load_col<E, MP>(A.st.z + i * A.st.nv, cn_col, lane, cn);
-            load_col<E, MP>(A.st.kv[i], j, lane, kv);
+            if constexpr (CL & 4) col_lds_get<E>(lds->step, i, lane, kv);
+            else load_col<E, MP>(A.st.kv[i], j, lane, kv);
 #pragma unroll
             for (int e = 0; e < E; ++e) { c[e] = y0[e] + c[e]; cs[e] = ys[e] + cs[e]; cn[e] = yn[e] + cn[e]; }
             tend_col<E, KIND>(P, cf, c, cs, cn, kv, tr, lane, f);
@@ -939,8 +957,13 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
     double a[E], cc[E];
     {
         double jl[E], ju[E];
-        load_col<E, MP>(A.sw.JL, j, lane, jl);
-        load_col<E, MP>(A.sw.JU, j, lane, ju);
+        if constexpr (CL & 4) {
+            col_lds_get<E>(lds->step, 3, lane, jl);
+            col_lds_get<E>(lds->step, 4, lane, ju);
+        } else {
+            load_col<E, MP>(A.sw.JL, j, lane, jl);
+            load_col<E, MP>(A.sw.JU, j, lane, ju);
+        }
         line_offdiag<E, KIND>(P, tr, lane, jl, ju, a, cc);
     }
     if (!A.sw.first) {
@@ -987,7 +1010,8 @@ __device__ __forceinline__ void newton_fused_body(const DevP& P, const FusedArgs
             load_col32<E>(A.sw.fr_inv32, task, lane, inv);
             load_tab32(A.sw.fr_tab32, task, lane, tab);
         } else {
-            load_col<E>(A.sw.fr_inv, task, lane, inv);
+            if constexpr (CL & 8) col_lds_get<E>(lds->piv, 0, lane, inv);
+            else load_col<E>(A.sw.fr_inv, task, lane, inv);
             load_tab<E>(A.sw.fr_tab, task, lane, tab);
         }
 #pragma unroll
@@ -2197,7 +2221,8 @@ struct FrozenArgs {
     double* out;                 // [32]: status, rows done, parities
     long long spin_ticks;
     int fences;
-    int coef_lds;                // option "frozen_coef_lds": bit 0 -- the static coefficients of a wave's column live in LDS for the year, bit 1 -- W too
+    int coef_lds;                // option "frozen_coef_lds" (bits of LdsSrc): what a wave finds in LDS; bits 2, 3 need `by_column`
+    int by_column;               // 1: a workgroup is ONE ypos column with all its tracers (a wave each) instead of adjacent columns of one tracer
     unsigned* tickets;           // XCD flavour: the workgroups that find themselves on XCD 0 take a number here
     int nwg;                     // ... until this many have one
 };

@@ -131,6 +131,7 @@ struct nk2d_ctx {
     int frozen_nbsync;    // option "frozen_nbsync": team columns hand over to their lateral neighbours instead of meeting at a grid barrier
     int frozen_wpb;       // option "frozen_wpb": columns (waves) per workgroup of the wave-per-column one-launch year with neighbour hand-over
     int frozen_coef_lds;  // option "frozen_coef_lds": the one-launch year keeps the static coefficients of a wave's column in LDS
+    int frozen_by_column; // option "frozen_by_column": a workgroup of the one-launch year is one ypos column with all its tracers
     int frozen_alloc_async;   // option "frozen_alloc_async": a schedule cache above 8 GB is allocated by a thread of its own
     int frozen_cache_after;   // option "frozen_cache_after": frozen years of a schedule that run launch by launch before its cache is built (default 0; -1: 0 for a cache below 8 GB, 3 above)
     uint64_t frozen_seen_key; int frozen_seen_years;   // the schedule last seen by nk2d_frozen_persistent and its years so far

@@ -78,8 +78,12 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         if (wg < 0) return;
     }
     const int tw = uni_i((int)(threadIdx.x >> 6));                      // TEAM: the wave's place in its team
-    const int wave = TEAM ? uni_i(wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));   // the column
-    const bool col_wave = wave < P.ncol;
+    // the column of this wave.  A team: the workgroup's.  A wave per column: adjacent columns of one tracer to a workgroup, or
+    // -- `by_column` -- the workgroup is ONE ypos column and its waves that column's tracers (what is the same for every tracer
+    // of a ypos column is then shared through LDS)
+    const bool by_col = !TEAM && !XCD && NB != 0 && A.by_column != 0;
+    const int wave = TEAM ? uni_i(wg) : (by_col ? uni_i(tw * P.ny + wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)));
+    const bool col_wave = wave < P.ncol && (!by_col || (tw < P.tc && wg < P.ny));
     GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
     // NB: neighbour-to-neighbour hand-over instead of the grid barrier.  The unit is the workgroup: one column (teams), or
     // the columns of its waves -- then the workgroup to the left matters if its first column has a left neighbour, the one to
@@ -89,6 +93,9 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
         const int nb_j = wave % P.ny;
         nb_left = (nb_j > 0) ? wg - 1 : -1;
         nb_right = (nb_j < P.ny - 1) ? wg + 1 : -1;
+    } else if (by_col) {
+        nb_left = (wg > 0) ? wg - 1 : -1;
+        nb_right = (wg < P.ny - 1) ? wg + 1 : -1;
     } else {
         const int wpb = (int)(blockDim.x >> 6);
         const int c0 = wg * wpb, cl = min(c0 + wpb - 1, P.ncol - 1);
@@ -107,18 +114,40 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
     // a wave per column, three and more levels per lane (option "frozen_coef_lds"): the static coefficients of the wave's column
     // in LDS for the whole year (dynamic shared memory of the launch: NK2D_COEF_LDS_DOUBLES(E) doubles per wave)
     constexpr bool COEF_LDS = NB != 0 && !TEAM && !XCD && E >= 3;
+    // Layout of the dynamic shared memory.  Adjacent columns: per wave [coefficients][W].  By column: [coefficients of the ypos
+    // column][step block: 3 mixing columns, JL, JU][per wave: W][per wave: pivots of the real system] (each part present where
+    // its bit of A.coef_lds is set; frozen_lds_doubles() on the host computes the same)
     extern __shared__ double dyn_lds[];
     const bool w_in_lds = COEF_LDS && (A.coef_lds & 2) != 0;
-    double* my_coef = dyn_lds + (size_t)(threadIdx.x >> 6) * (NK2D_COEF_LDS_DOUBLES(E) + (w_in_lds ? 3 * E * 64 : 0));
-    double* my_w = my_coef + NK2D_COEF_LDS_DOUBLES(E);
-    (void)my_w;
+    const bool step_in_lds = COEF_LDS && by_col && (A.coef_lds & 4) != 0;
+    const bool piv_in_lds = COEF_LDS && by_col && (A.coef_lds & 8) != 0;
+    const int nwv = (int)(blockDim.x >> 6);
+    double* my_coef;
+    double* my_w;
+    double* step_lds = nullptr;
+    double* my_piv = nullptr;
+    if (by_col) {
+        double* p = dyn_lds;
+        my_coef = p; p += NK2D_COEF_LDS_DOUBLES(E);
+        step_lds = p; p += step_in_lds ? 5 * E * 64 : 0;
+        my_w = p + (size_t)tw * (3 * E * 64); p += w_in_lds ? (size_t)nwv * 3 * E * 64 : 0;
+        my_piv = p + (size_t)tw * (E * 64);
+    } else {
+        my_coef = dyn_lds + (size_t)(threadIdx.x >> 6) * (NK2D_COEF_LDS_DOUBLES(E) + (w_in_lds ? 3 * E * 64 : 0));
+        my_w = my_coef + NK2D_COEF_LDS_DOUBLES(E);
+    }
+    const LdsSrc L = {my_coef, my_w, step_lds, my_piv};
+    (void)L;
     if constexpr (COEF_LDS) {
-        if (A.coef_lds && col_wave) {
+        if (A.coef_lds && col_wave && (!by_col || tw == 0)) {
             ColCoef<E> cf;
             load_coef<E>(P, wave % P.ny, lane, cf);
             store_coef_lds<E>(my_coef, lane, cf);
         }
+        if (by_col && A.coef_lds) __syncthreads();      // (the other tracers' waves read what wave 0 stored)
     }
+    int lds_step = -1;      // the step whose constants the step block / the pivots hold
+    (void)lds_step;
     // first attempt of the year: Z0 = 0, W0 = 0 (radau.py:445-446)
     if (col_wave && (!TEAM || tw == 0)) {
         double zero[E];
@@ -175,6 +204,27 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                 FA.part = (k == n_iter - 1) ? A.STEP_PART + (size_t)(3 * i) * P.ncol
                                             : ((k == n_iter - 2) ? A.STEP_PART + (size_t)(3 * i + 1) * P.ncol : A.PART);
                 FA.do_stage = do_stage ? 1 : 0; FA.do_update = do_update ? 1 : 0; FA.delta = delta ? 1 : 0;
+                if constexpr (COEF_LDS) {
+                    if (step_in_lds && lds_step != i) {
+                        // first phase of a step: what is constant over the step's iterations goes to LDS once -- the three mixing
+                        // columns and JL, JU of the ypos column shared out over the workgroup's waves, each wave's own pivots
+                        for (int r = tw; r < 5; r += nwv) {
+                            double v[E];
+                            // (selects, not an index: a struct indexed at run time would live in scratch memory)
+                            const double* src = (r == 0) ? FA.st.kv[0] : ((r == 1) ? FA.st.kv[1] : ((r == 2) ? FA.st.kv[2]
+                                                : ((r == 3) ? FA.sw.JL : FA.sw.JU)));
+                            load_col<E, MPX>(src, wave % P.ny, lane, v);
+                            w_lds_put<E>(step_lds, r, lane, v);
+                        }
+                        if (piv_in_lds && col_wave) {
+                            double v[E];
+                            load_col<E>(FA.sw.fr_inv, wave, lane, v);
+                            w_lds_put<E>(my_piv, 0, lane, v);
+                        }
+                        lds_step = i;
+                        __syncthreads();
+                    }
+                }
                 if (is_final) {
                     FinalArgs Fin;
                     Fin.ynew = FZ_YOLD;
@@ -190,8 +240,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                             if (m == 1) { newton_single_body<E, MPX, 1>(P, FA, wave, lane, &Fin); taken = true; }
                         }
                         if constexpr (COEF_LDS) {
-                            if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 3>(P, FA, wave, lane, &Fin, my_coef, my_w); taken = true; }
-                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 1>(P, FA, wave, lane, &Fin, my_coef); taken = true; }
+                            if (step_in_lds && piv_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 15>(P, FA, wave, lane, &Fin, &L); taken = true; }
+                            else if (step_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 7>(P, FA, wave, lane, &Fin, &L); taken = true; }
+                            else if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 3>(P, FA, wave, lane, &Fin, &L); taken = true; }
+                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 1, 1>(P, FA, wave, lane, &Fin, &L); taken = true; }
                         }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 1>(P, FA, wave, lane, &Fin);
                     }
@@ -207,8 +259,10 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
                             if (m == 1) { newton_single_body<E, MPX, 0>(P, FA, wave, lane); taken = true; }
                         }
                         if constexpr (COEF_LDS) {
-                            if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 3>(P, FA, wave, lane, nullptr, my_coef, my_w); taken = true; }
-                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 1>(P, FA, wave, lane, nullptr, my_coef); taken = true; }
+                            if (step_in_lds && piv_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 15>(P, FA, wave, lane, nullptr, &L); taken = true; }
+                            else if (step_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 7>(P, FA, wave, lane, nullptr, &L); taken = true; }
+                            else if (w_in_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 3>(P, FA, wave, lane, nullptr, &L); taken = true; }
+                            else if (A.coef_lds) { newton_fused_body<E, KIND, 0, 1, MPX, 0, 1>(P, FA, wave, lane, nullptr, &L); taken = true; }
                         }
                         if (!taken) newton_fused_body<E, KIND, 0, 1, MPX, 0>(P, FA, wave, lane);
                     }
@@ -354,6 +408,13 @@ void nk2d_frozen_cache_free(nk2d_ctx* c) {
 // resident after all (a co-tenant on the chip) hands the year back instead of hanging.  hipLaunchCooperativeKernel did the
 // same check and nothing else for this kernel -- through a queue of its own that the HIP runtime crashed on when the process
 // ended under rocprofv3 (rounds 2 - 3: AqlQueue::~AqlQueue under hsa_shut_down).
+// doubles of dynamic shared memory of a wave-per-column workgroup of `nwaves` waves (the kernel's layout; bits: LdsSrc)
+static size_t frozen_lds_doubles(int E, int bits, bool by_column, int nwaves) {
+    if (!bits) return 0;
+    if (!by_column) return (size_t)nwaves * (NK2D_COEF_LDS_DOUBLES(E) + ((bits & 2) ? 3 * E * 64 : 0));
+    return NK2D_COEF_LDS_DOUBLES(E) + ((bits & 4) ? 5 * E * 64 : 0) + (size_t)nwaves * (((bits & 2) ? 3 * E * 64 : 0) + ((bits & 8) ? E * 64 : 0));
+}
+
 template <class K>
 static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, DevP& P, FrozenArgs& A, size_t lds_bytes = 0) {
     int per_cu = 0;
@@ -381,9 +442,11 @@ static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, 
                 // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
                 const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
                 const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
-                // (a wave per column, three and more levels per lane: room for the static coefficients of its column in LDS)
-                const size_t lds = (!TEAM && E >= 3 && A.coef_lds)
-                                       ? sizeof(double) * (NK2D_COEF_LDS_DOUBLES(E) + ((A.coef_lds & 2) ? 3 * E * 64 : 0)) * wpb : 0;
+                // (a wave per column, three and more levels per lane: a wave's own data of the year in LDS -- frozen_lds_doubles)
+                if (!TEAM && E >= 3 && A.by_column)
+                    return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, dim3((unsigned)c->ny), dim3(64 * c->tc), P, A,
+                                           sizeof(double) * frozen_lds_doubles(E, A.coef_lds, true, c->tc));
+                const size_t lds = (!TEAM && E >= 3 && A.coef_lds) ? sizeof(double) * frozen_lds_doubles(E, A.coef_lds, false, wpb) : 0;
                 return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A, lds);
             }
         }
@@ -624,9 +687,26 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     A.out = c->YR_OUT;
     A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
     A.fences = c->year_fences;
-    // (W beside the coefficients where four waves' blocks fit a compute unit's 160 KB: up to seven levels per lane)
-    A.coef_lds = c->frozen_coef_lds;
-    if ((A.coef_lds & 2) && 4 * sizeof(double) * (NK2D_COEF_LDS_DOUBLES(c->E) + 3 * c->E * 64) > 160 * 1024) A.coef_lds &= 1;
+    // what lives in LDS (option "frozen_coef_lds", bits of LdsSrc) and which columns share a workgroup (option "frozen_by_column"):
+    // as much as lets a compute unit hold what the grid needs of it -- ceil(waves / compute units) waves: pivots, then the step
+    // block, then W are given up until it fits the 160 KB (E = 8 keeps everything but the pivots)
+    A.coef_lds = (c->E >= 3) ? c->frozen_coef_lds : 0;
+    // (by column -- and with it the step block and the pivots -- from five levels per lane: 416^2 125.2 -> 120.3 ms; at four the shared
+    // block does not pay for the wider hand-over, 208^2 65.2 -> 68.1 ms: profiles/r04_frozen_lds_by_column.log; option value 2 forces it)
+    A.by_column = (c->frozen_by_column && c->tc <= NK2D_WAVES_PER_BLOCK && A.coef_lds &&
+                   (c->E >= 5 || (c->frozen_by_column >= 2 && c->E >= 3))) ? 1 : 0;
+    if (!A.by_column) A.coef_lds &= 3;
+    {
+        hipDeviceProp_t prop;
+        NK2D_CHECK(c, hipGetDeviceProperties(&prop, c->dev));
+        const int nw = A.by_column ? c->tc : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
+        const int wgs = A.by_column ? c->ny : (c->ncol + nw - 1) / nw;
+        const int per_cu = (wgs + prop.multiProcessorCount - 1) / prop.multiProcessorCount;
+        for (const int drop : {8, 4, 2}) {
+            if (8 * frozen_lds_doubles(c->E, A.coef_lds, A.by_column != 0, nw) * (size_t)per_cu <= 160u * 1024u) break;
+            A.coef_lds &= ~drop;
+        }
+    }
     // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column.  Measured
     // (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want a CU each -- on one XCD, two to four
     // workgroups to a CU, they lose more than they gain (26^2: 13.3 ms, 16.1 ms when LDS padding forces exactly two per CU) --

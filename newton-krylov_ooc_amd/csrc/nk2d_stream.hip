@@ -174,13 +174,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
         if (op == NK2D_OP_NEWTON) {
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
-                    const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
+                    const LdsSrc L = {dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E), w_in_lds ? ST_WLDS(tr, j) : nullptr, nullptr, nullptr};
                     if (w_in_lds) {
-                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl, ST_WLDS(tr, j));
-                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl, ST_WLDS(tr, j));
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, &L);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 3>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, &L);
                     } else if (A.coef_lds) {
-                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
-                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, cl);
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, &L);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 0, 1>(P, cmd.u.nf, tr * P.ny + j, lane, nullptr, &L);
                     } else {
                         if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
                         else newton_fused_body<E, KIND, 0, 1, 1>(P, cmd.u.nf, tr * P.ny + j, lane);
@@ -193,13 +193,13 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
             const StreamFinal& S = cmd.u.fn;
             for (int tr = tw; tr < P.tc; tr += nw)
                 for (int j = j0; j < j1; ++j) {
-                    const double* cl = dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E);
+                    const LdsSrc L = {dyn_lds + (size_t)(j - j0) * NK2D_COEF_LDS_DOUBLES(E), w_in_lds ? ST_WLDS(tr, j) : nullptr, nullptr, nullptr};
                     if (w_in_lds) {
-                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl, ST_WLDS(tr, j));
-                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl, ST_WLDS(tr, j));
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, &L);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 3>(P, S.nf, tr * P.ny + j, lane, &S.fin, &L);
                     } else if (A.coef_lds) {
-                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
-                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, cl);
+                        if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, &L);
+                        else newton_fused_body<E, KIND, 0, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin, &L);
                     } else {
                         if (flags & NK2D_CMD_FACTOR) newton_fused_body<E, KIND, 1, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);
                         else newton_fused_body<E, KIND, 0, 1, 1, 1>(P, S.nf, tr * P.ny + j, lane, &S.fin);

@@ -181,6 +181,10 @@ def test_every_levels_per_lane_instantiation_of_the_one_launch_year(nz):
     assert eng.counter("frozen_persistent_years") == 3 and eng.counter("frozen_xcd_years") == 0
     assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert st_p["nerr_checked"] > 0 and st_p["seconds"] < st_l["seconds"]
+    # adjacent columns of one tracer to a workgroup, or one ypos column with all its tracers (and the step's constants shared in LDS)
+    for by_col in (0, 2):
+        eng.set_option("frozen_by_column", by_col)
+        assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), want[1]), by_col
     eng.close()
 
 
@@ -216,6 +220,15 @@ def test_full_size_year_in_one_launch():
     eng.set_option("frozen_wpb", 1)
     eng.set_option("frozen_nbsync", 1)
     assert eng.counter("frozen_persistent_years") == 5
+    # what lives in LDS for the year (bits: coefficients, W, the step's mixing columns and Jacobian diagonals, pivots) and which
+    # columns share a workgroup: the same bits whatever the choice
+    for by_col, lds in ((0, 0), (0, 1), (0, 3), (2, 3), (2, 7), (2, 15)):
+        eng.set_option("frozen_by_column", by_col)
+        eng.set_option("frozen_coef_lds", lds)
+        assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), want[1]), (by_col, lds)
+    eng.set_option("frozen_by_column", 1)
+    eng.set_option("frozen_coef_lds", 15)
+    assert eng.counter("frozen_persistent_years") == 11
     fx2, _, sched2 = eng.comp_fcn(xp, record=True)
     fx2_p, _ = eng.comp_fcn_frozen(xp, sched2)
     assert np.array_equal(eng.download(fx2_p), eng.download(fx2)) and eng.counter("frozen_cache_builds") == 2
