@@ -262,7 +262,7 @@ class MixWorkload:
         self.iterate = ModelState("gen_init_iterate")
         for tms in self.iterate.tracer_modules:
             if tms.name == "forced_dye":
-                # the initial iterate of the module is exactly uniform; give it structure
+                # the initial iterate of the module is exactly uniform; give it structure (docs/DESIGN_history_r1-r3.md section 5)
                 rng = np.random.default_rng(3)
                 bump = np.cumsum(np.cumsum(rng.standard_normal((1, n, n)), axis=1), axis=2)
                 tms.eng.upload(1.0 + 0.3 * bump / np.max(np.abs(bump)), out=tms.vec)

@@ -391,7 +391,11 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    workgroups resident; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: workgroups hand over to
    their two lateral neighbours instead of meeting at a grid barrier), "frozen_wpb" (columns per workgroup of the wave-per-column
    flavour with that hand-over, 1 .. 4, default 2: the waves of a workgroup move in lock step, a neighbour in another
-   workgroup is read over the fabric),
+   workgroup is read over the fabric), "frozen_coef_lds" (bits, default 15: what a wave of that flavour keeps in LDS for the
+   year at three and more levels per lane -- 1 the static coefficients of its column, 2 W, 4 the step's mixing columns and
+   vertical Jacobian diagonals, 8 the real system's pivots; bits 4 and 8 need "frozen_by_column"), "frozen_by_column" (1,
+   default: from five levels per lane a workgroup is ONE ypos column with all its tracers, so that what is the same for every
+   tracer of a column is shared through LDS; 2: from three levels per lane; 0: adjacent columns of one tracer),
    "hook_spec_depth" (1 or 2, default 2: whole Newton iterations a controller with a vector norm hook queues ahead of a verdict), "barrier_timeout_ms" (longest wait at a grid barrier of the one-launch years, default 2000:
    then the year is rerun launch by launch), "year_fences" (1: release / acquire fences around those barriers, validation),
    "pc_fp32" (1: the preconditioner's Schur inverses stored in single precision -- half the HBM -- and every apply refined

@@ -2033,7 +2033,7 @@ __device__ __forceinline__ double uni_d(double v) {
 
 
 // =================================================================================================
-// The frozen year of a small grid in ONE launch, on a schedule cache (DESIGN.md section 3d).
+// The frozen year of a small grid in ONE launch, on a schedule cache (DESIGN.md section 3.6).
 //
 // A frozen year (nk2d_comp_fcn_frozen: the perturbed year of a finite-difference product) decides nothing, and for
 // the modules whose Jacobian is a function of time alone everything but the state is known from the schedule:

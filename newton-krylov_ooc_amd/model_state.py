@@ -745,7 +745,7 @@ class ModelState:
         # Internal numerical differentiation: the perturbed year repeats the accepted steps of the year that produced
         # `fcn` (carried by it when it was computed in this process), so that the quotient below differentiates ONE
         # discrete map.  Two free-running years take different controller decisions here and there, and the
-        # difference of their discretisation errors over sigma is 5 ... 90 % of the product (DESIGN.md section 3c,
+        # difference of their discretisation errors over sigma is 5 ... 90 % of the product (DESIGN.md section 3.5,
         # tools/probe_jvp_noise.py).  NK2D_JVP_FROZEN=0, or an `fcn` read back from a file, gives free-running years.
         frozen = getattr(fcn, "_sched", None) if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else None
         mode = ("frozen controller: the perturbed year repeats the accepted steps of the year behind F(x)" if frozen

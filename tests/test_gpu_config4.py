@@ -34,7 +34,7 @@ def _setup(workdir, nz, ny, names=NAMES, **solverinfo):
 
 def _structured_dye(ModelState, iterate, nz, ny, seed=3):
     """the forced module's initial iterate is exactly uniform, where the reference's own map amplifies roundoff
-    (DESIGN.md section 5): give the tracer a smooth positive structure, as the parity tests of `forced` do"""
+    (docs/DESIGN_history_r1-r3.md section 5): give the tracer a smooth positive structure, as the parity tests of `forced` do"""
     rng = np.random.default_rng(seed)
     bump = np.cumsum(np.cumsum(rng.standard_normal((1, nz, ny)), axis=1), axis=2)
     dye = 1.0 + 0.3 * bump / np.max(np.abs(bump))

@@ -60,7 +60,7 @@ def test_two_module_krylov(tmp_path, monkeypatch):
     """tracer_module_names = iage,forced_{suff}:dye with the decay options: two engines
     (two HIP streams), Hessenberg / beta of shape [2, ...]; compared with the oracle"""
     # The forced module starts from an exactly uniform state, where the reference's own map amplifies
-    # roundoff to 1e-3 (stale-Jacobian Newton iterations, DESIGN.md section 5): its Hessenberg entries are
+    # roundoff to 1e-3 (stale-Jacobian Newton iterations, docs/DESIGN_history_r1-r3.md section 5): its Hessenberg entries are
     # comparable with the oracle's only when the engines reuse the Jacobian as SciPy does.
     monkeypatch.setenv("NK2D_JAC_FRESH", "0")
     monkeypatch.setenv("NK2D_GROWTH_CAP", "0")

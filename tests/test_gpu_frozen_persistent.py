@@ -1,4 +1,4 @@
-"""The frozen year of a small grid as ONE launch on a schedule cache (k_frozen_persistent, DESIGN.md section 3d): the same
+"""The frozen year of a small grid as ONE launch on a schedule cache (k_frozen_persistent, DESIGN.md section 3.6): the same
 device functions as the launch-per-phase path, so the same bits -- for the recorded state (the recorded year again) and for
 a perturbed one; the cache is built once per schedule; modules it is not made for, larger grids and years that do not pass
 their check take the launch-per-phase path."""

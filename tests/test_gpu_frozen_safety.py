@@ -1,4 +1,4 @@
-"""The safety net of the products on frozen years (DESIGN.md section 3c; round-2 ADVICE items 1, 3, 5; VERDICT item 7):
+"""The safety net of the products on frozen years (DESIGN.md section 3.5; round-2 ADVICE items 1, 3, 5; VERDICT item 7):
 
 * a frozen year whose recorded Newton iteration count is not enough at some step is RESUMED from the checkpoint before
   that step with one more iteration there (at most twice), instead of being thrown away for a free-running year;

@@ -55,7 +55,7 @@ def test_stream_year_is_the_host_controlled_year(nz, ny, mode):
 
 @pytest.mark.parametrize("nz,ny", [(26, 26), (52, 52), (130, 20), (416, 8)])
 def test_frozen_year_as_a_stream(nz, ny):
-    """the frozen year of a product (a recorded schedule replayed for another state; DESIGN.md section 3c) as a command stream:
+    """the frozen year of a product (a recorded schedule replayed for another state; DESIGN.md section 3.5) as a command stream:
     the launch-per-phase frozen year bit for bit, for the recorded state (= the recorded year) and for a perturbed one,
     with the Newton check and the sampled error estimates of every frozen year; and a step replay of the same schedule"""
     eng = _iage(nz, ny)
