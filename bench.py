@@ -662,6 +662,16 @@ def run_ladder(device_ordinal, device, args):
                    "base_year_free_running_s": wl.fwd_stats["seconds"],
                    "roofline_frac": roof["frac"], "avg_launch_us": roof["avg_launch_us"],
                    "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"]}
+            # the same iterations as ONE C call with every vector in HBM and no file trail (nk2d_gmres_solve): what the Python
+            # solver and the checkpoint files cost at this size
+            x_vec, f_vec = wl.iterate.tracer_modules[0].vec, wl.fcn.tracer_modules[0].vec
+            sched = (wl.fcn._sched or {}).get("iage") if os.environ.get("NK2D_JVP_FROZEN", "1") != "0" else None
+            wl.eng.gmres_solve(x_vec, f_vec, 0.0, 0, 1, sched=sched)
+            wl.eng.sync()
+            t_g = time.perf_counter()
+            wl.eng.gmres_solve(x_vec, f_vec, 0.0, 0, args.ladder_steps, sched=sched)
+            wl.eng.sync()
+            row["jvps_per_s_gmres_solve_in_hbm"] = args.ladder_steps / (time.perf_counter() - t_g)
             if args.cpu_baseline_seconds > 0:
                 wl.eng.set_option("jac_fresh", 0)       # attempts of a year under SciPy's decisions, as the oracle takes them
                 _, st_f, _ = wl.eng.comp_fcn(wl.iterate.tracer_modules[0].vec)

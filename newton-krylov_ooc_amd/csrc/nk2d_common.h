@@ -247,8 +247,8 @@ struct nk2d_ctx {
     } while (0)
 
 // nk2d_stream.hip (the year as a command stream, nk2d_stream.h)
-void nk2d_turn_take();   // ONE resident kernel (a one-launch year, a command-stream kernel) at a time in a process
-void nk2d_turn_give();
+void nk2d_turn_take(int waves);   // resident kernels of a process: one at a time, or side by side where their waves leave room
+void nk2d_turn_give(int waves);
 #define NK2D_RC_STREAM_LOST 17   /* the command-stream kernel gave up (a wait timed out): the caller reruns the year by launches */
 int nk2d_stream_pause(nk2d_ctx* c);
 bool nk2d_stream_running(const nk2d_ctx* c);

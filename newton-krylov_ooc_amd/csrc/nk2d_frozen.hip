@@ -728,9 +728,10 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
         const dim3 grid(8 * nblk + 64);
         struct Turn {
-            Turn() { nk2d_turn_take(); }
-            ~Turn() { nk2d_turn_give(); }
-        } turn;
+            int waves;
+            explicit Turn(int w) : waves(w) { nk2d_turn_take(waves); }
+            ~Turn() { nk2d_turn_give(waves); }
+        } turn(4 * nblk);
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
         NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
         NK2D_CHECK(c, hipGetLastError());
@@ -754,9 +755,10 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
         // one resident kernel at a time in this process (the turn is held until this one has ended)
         struct Turn {
-            Turn() { nk2d_turn_take(); }
-            ~Turn() { nk2d_turn_give(); }
-        } turn;
+            int waves;
+            explicit Turn(int w) : waves(w) { nk2d_turn_take(waves); }
+            ~Turn() { nk2d_turn_give(waves); }
+        } turn(team ? 4 * c->ncol : c->ncol);
         rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);

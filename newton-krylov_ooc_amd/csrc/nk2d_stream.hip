@@ -362,6 +362,7 @@ struct nk2d_stream_state {
     bool coef_lds = true;                   // the static coefficients of a workgroup's columns in LDS (NK2D_STREAM_COEF_LDS=0: not)
     bool direct = false;                    // the host writes its commands straight into d_ring (large BAR): no relay hop
     int nwg = 0, cpw = 1, nw = 1;
+    int turn_waves = 0;                     // what the running kernel holds of the process-wide turn
     int64_t launches = 0;
     // pinned buffers for the norm partials, handed out in turn: the controller names its buffers (hPART, hPARTB, ...) and
     // reuses a name as soon as IT is done with it -- also when a command writing there was dropped unread (an iteration
@@ -379,19 +380,27 @@ struct nk2d_stream_state {
 namespace {
 std::mutex g_turn_mutex;
 std::condition_variable g_turn_cv;
-bool g_turn_taken = false;
+int g_turn_waves = 0;          // waves of the resident kernels running now
+int g_turn_kernels = 0;
+const int kTurnCapacity = 640; // waves that may be resident together (of 1 024 SIMDs, a wave each at the registers these kernels hold)
 }  // namespace
-void nk2d_turn_take() {
+// Resident kernels (a one-launch year, a command-stream kernel) wait inside for workgroups that must all be on the chip: a
+// process runs them one at a time -- or side by side where their waves together leave the chip room (small grids: a few dozen
+// waves each; the years of several tracer modules then overlap as their launches used to).  `waves`: what the kernel holds;
+// given back with the same number.  Contexts driven by other host threads wait their turn.
+void nk2d_turn_take(int waves) {
     std::unique_lock<std::mutex> lk(g_turn_mutex);
-    g_turn_cv.wait(lk, [] { return !g_turn_taken; });
-    g_turn_taken = true;
+    g_turn_cv.wait(lk, [waves] { return g_turn_kernels == 0 || g_turn_waves + waves <= kTurnCapacity; });
+    g_turn_waves += waves;
+    g_turn_kernels += 1;
 }
-void nk2d_turn_give() {
+void nk2d_turn_give(int waves) {
     {
         std::lock_guard<std::mutex> lk(g_turn_mutex);
-        g_turn_taken = false;
+        g_turn_waves -= waves;
+        g_turn_kernels -= 1;
     }
-    g_turn_cv.notify_one();
+    g_turn_cv.notify_all();
 }
 
 bool nk2d_stream_running(const nk2d_ctx* c) { return c->strm && c->strm->running; }
@@ -530,7 +539,8 @@ static void ring_write(nk2d_stream_state* S, unsigned seq, const StreamCmd& cmd)
 // start the kernel (it will find the commands pushed from now on)
 static int stream_start(nk2d_ctx* c) {
     nk2d_stream_state* S = c->strm;
-    nk2d_turn_take();
+    S->turn_waves = (S->nwg + 1) * S->nw;
+    nk2d_turn_take(S->turn_waves);
     StreamArgs A = {};
     A.h_ring = S->direct ? nullptr : S->h_ring; A.d_ring = S->d_ring;
     A.abort_flag = (int*)S->d_sync;
@@ -546,7 +556,7 @@ static int stream_start(nk2d_ctx* c) {
     DevP P = make_devp(c);
     const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr, stream_lds_bytes(c, S->cpw, S->coef_lds));
     if (rc != hipSuccess) {
-        nk2d_turn_give();
+        nk2d_turn_give(S->turn_waves);
         NK2D_CHECK(c, rc);
     }
     S->running = true;
@@ -689,7 +699,7 @@ int nk2d_stream_pause(nk2d_ctx* c) {
     S->running = false;
     // (the kernel's workgroups all pass the EXIT command: everything before it is complete once the kernel has ended)
     S->notifies.clear();
-    nk2d_turn_give();
+    nk2d_turn_give(S->turn_waves);
     return 0;
 }
 
