@@ -511,9 +511,9 @@ def roofline_of(eng, n):
             eng.counter("frozen_persistent_years") - getattr(eng, "_launch_years_base", 0), 1)
         achieved = nbytes / (launch_us * 1e-6) / 1e9
         levels = (eng.nz + 63) // 64
-        flavour = ("a four-wave team per column" if eng.counter("frozen_team_years") else "a wave per column") + (
-            ", all workgroups on one XCD" if eng.counter("frozen_xcd_years") else
-            ", all workgroups resident, workgroups hand over to their lateral neighbours; static coefficients and W of a column in LDS")
+        flavour = ("a four-wave team per column" if eng.counter("frozen_team_years") else
+                   "a wave per column, a wave's own data of the year in LDS") + (
+            ", all workgroups resident, workgroups hand over to their lateral neighbours")
         out = {"bound": "hbm", "kernel": f"k_frozen_persistent<{levels}, 0, ...> (a whole frozen year in ONE launch on the schedule "
                                          f"cache: one simplified-Newton iteration per phase; {flavour})",
                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -524,7 +524,7 @@ def roofline_of(eng, n):
                "phases_per_launch": ModelState.last_stats[0]["nsweeps"],
                "year_seconds_host_clock": ModelState.last_stats[0]["seconds"],
                "one_launch_years": eng.counter("frozen_persistent_years"), "team_years": eng.counter("frozen_team_years"),
-               "xcd_local_years": eng.counter("frozen_xcd_years"), "schedule_cache_builds": eng.counter("frozen_cache_builds")}
+               "schedule_cache_builds": eng.counter("frozen_cache_builds")}
         pmc_fname = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02}_pmc_traffic_one_launch_{n}.json") for r in (4, 3))
                           if os.path.exists(f)), "")
         if os.path.exists(pmc_fname):

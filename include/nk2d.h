@@ -210,18 +210,19 @@ int nk2d_frozen_resumes(nk2d_ctx* ctx, int64_t* n);
    between phases -- on a cache of everything its schedule fixes besides the state: mixing planes, Jacobian planes and line
    factorisation of every step, built by two batched launches when a new schedule arrives (options "frozen_persistent" 0/1,
    "frozen_cache_gb": at most that much HBM, default 128, and never more than 85 % of what the device has free; 102 GB and 26 ms
-   per schedule at 416 x 416, where the year takes 145 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
+   per schedule at 416 x 416, where the year takes 115 - 120 ms instead of 190 ms; "frozen_cache_after": frozen years of a schedule
    that run launch by launch before its cache is built, default 0; "frozen_alloc_async" 1, default: a cache above 8 GB is
    allocated by a thread of the library's own -- hipMalloc of 120 GB takes 0.03 to 3 s -- and the years of the meantime run
    launch by launch).  Same device functions, bit-identical results; a year that does not pass the Newton check, or a
    barrier that times out, is handed to the launch-per-phase path.  Counters by name: "frozen_persistent_years",
-   "frozen_xcd_years" (of them: all workgroups on one XCD), "frozen_team_years" (of them: a four-wave team per column),
+   "frozen_team_years" (of them: a four-wave team per column), "frozen_cache_bytes",
    "frozen_launch_us" (device time of those launches), "frozen_cache_pending" (1 while a thread allocates a large cache),
    "frozen_cache_builds", "frozen_fallbacks", "frozen_resumes"; of the host-side controller: "spec_launches_dropped",
    "spec_front_launches_dropped", "err_estimates_queued", "err_estimates_dropped" (work queued ahead of a verdict). */
 int nk2d_get_counter(nk2d_ctx* ctx, const char* name, int64_t* out);
 /* hash of everything a recorded schedule depends on besides the state: grid, module description, tolerances, the
-   controller options (jac_fresh, jac_stage, lin_tol, min_sweeps, growth_cap, factor storage) and the library version;
+   controller options (jac_fresh, jac_stage, lin_tol, min_sweeps, growth_cap, factor storage), the library version and a
+   checksum of its sources (another build's schedules are refused);
    an integer below 2^52, never 0 */
 int nk2d_schedule_fingerprint(nk2d_ctx* ctx, double* out);
 /* accepted steps of the most recent free-running year of this context (whichever entry point ran it: nk2d_comp_fcn,
@@ -386,10 +387,9 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "sweep_wpb",
    (closed experiments removed in round 4: "xcd_map", "prefactor" -- profiles/r03_prefactor holds their measurements),
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
-   "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" / "frozen_xcd" (the one-launch frozen year of small
-   grids, see nk2d_get_counter), "frozen_team" (1, default: a four-wave team per column inside that launch, all
-   workgroups resident; 0: a wave per column, on one XCD where the workgroups fit), "frozen_nbsync" (1, default: workgroups hand over to
-   their two lateral neighbours instead of meeting at a grid barrier), "frozen_wpb" (columns per workgroup of the wave-per-column
+   "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" (the one-launch frozen year, see nk2d_get_counter),
+   "frozen_team" (1, default: a four-wave team per column inside that launch up to two levels per lane; 0: a wave per
+   column), "frozen_wpb" (columns per workgroup of the wave-per-column
    flavour with that hand-over, 1 .. 4, default 2: the waves of a workgroup move in lock step, a neighbour in another
    workgroup is read over the fabric), "frozen_coef_lds" (bits, default 15: what a wave of that flavour keeps in LDS for the
    year at three and more levels per lane -- 1 the static coefficients of its column, 2 W, 4 the step's mixing columns and

@@ -146,9 +146,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "final_fuse") { c->final_fuse = value != 0.0; return 0; }
     if (key == "year_fences") { c->year_fences = value != 0.0; return 0; }
     if (key == "frozen_persistent") { c->frozen_persistent = value != 0.0; return 0; }
-    if (key == "frozen_xcd") { c->frozen_xcd = value != 0.0; c->frozen_xcd_failed = 0; return 0; }
     if (key == "frozen_team") { c->frozen_team = value != 0.0; return 0; }
-    if (key == "frozen_nbsync") { c->frozen_nbsync = value != 0.0; return 0; }
     if (key == "frozen_coef_lds") { c->frozen_coef_lds = (int)value & 15; return 0; }
     if (key == "frozen_by_column") { c->frozen_by_column = (int)value; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
@@ -510,10 +508,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_persistent = 1;
     c->frozen_persistent_max_e = 8;
     c->frozen_cache_max_gb = 128.0;
-    c->frozen_cache_builds = c->frozen_persistent_years = c->frozen_xcd_years = 0;
-    c->frozen_xcd = 1;
+    c->frozen_cache_builds = c->frozen_persistent_years = 0;
     c->frozen_team = 1;
-    c->frozen_nbsync = 1;
     c->frozen_cache_after = 0;
     c->frozen_coef_lds = 15;
     c->frozen_by_column = 1;
@@ -525,7 +521,6 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->stream_cmds = c->stream_launches = c->stream_timeouts = c->stream_years_run = 0;
     c->frozen_wpb = 2;
     c->frozen_alloc_async = 1;
-    c->frozen_xcd_failed = 0;
     c->barrier_timeout_ms = 2000.0;
     c->year_fences = 0;
     c->frozen_err_check = NK2D_CKPT_EVERY;   // the rows that start a checkpoint interval: the step before ends in a launch of its own anyway
@@ -953,7 +948,6 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     int64_t v = 0;
     if (key == "frozen_persistent_years") v = c->frozen_persistent_years;
     else if (key == "frozen_cache_builds") v = c->frozen_cache_builds;
-    else if (key == "frozen_xcd_years") v = c->frozen_xcd_years;
     else if (key == "frozen_team_years") v = c->frozen_team_years;
     else if (key == "stream_years_run") v = c->stream_years_run;
     else if (key == "stream_commands") v = c->stream_cmds;

@@ -1881,94 +1881,20 @@ static inline void fill_fused_args(nk2d_ctx* c, FusedArgs& A, bool do_stage, boo
 }
 
 // =================================================================================================
-// The whole forward year in ONE launch (nk2d_set_option "device_ctl" 3).
+// Resident kernels (the one-launch frozen year, nk2d_frozen.hip; the command stream, nk2d_stream.hip): a wave owns its
+// (tracer, ypos) column for as long as the kernel runs, the phases are the device functions the per-phase kernels call.
 //
-// The host-controlled integrator (nk2d_radau.hip) reads one scalar per simplified-Newton iteration and
-// launches 60 000 small kernels per 416 x 416 year; at 26 x 26 ... 208 x 208 the year is nothing but
-// launch gaps and host round trips.  Here every wave owns its (tracer, ypos) column for the WHOLE year:
-// the phases of the Radau step (the same device functions the per-phase kernels call, in the same order)
-// are separated by grid-wide barriers, and SciPy's controller (radau.py:399-539) runs redundantly in every
-// wave -- all waves read the same norm partials, reduce them in the association of nk2d_part_sum and
-// take identical decisions, so no decision is ever broadcast and the host is not involved until y(T).
-//
-// Visibility between workgroups follows the hand-off the guides validate for gfx950 (MI355X_MICROARCH.md,
-// inter-workgroup visibility, table row 1): every array another workgroup may read is stored write-through
-// and loaded L1-bypassing (MP = 1 accessors: relaxed agent-scope atomics = sc1); before a barrier every
-// wave drains its stores (s_waitcnt vmcnt(0)), the workgroup joins, ONE lane adds to the arrival counter
-// (agent scope) and polls it; the others wait at the workgroup barrier behind that lane.  Arrays only ever
-// touched by their owning wave (W, right-hand sides, the line factorisation, F) stay plain.  Every spin is
-// bounded; a timeout raises a grid-wide abort flag that every wave sees at its next barrier.
-// The grid must be resident at once: the host refuses the launch when the chip cannot hold it (launch_resident), and every
-// wait is bounded by time.
+// Visibility between workgroups follows the hand-off the guides validate for gfx950 (MI355X_MICROARCH.md, inter-workgroup
+// visibility, table row 1): every array another workgroup may read is stored write-through and loaded L1-bypassing (MP = 1
+// accessors: relaxed agent-scope atomics = sc1); before a hand-over every wave drains its stores (s_waitcnt vmcnt(0)), the
+// workgroup joins, ONE lane publishes and polls; the others wait at the workgroup barrier behind that lane.  Arrays only ever
+// touched by their owning wave (right-hand sides, the line factorisation, F) stay plain -- or live in LDS.  Every spin is
+// bounded by time; a timeout raises an abort flag every workgroup sees at its next hand-over.
 // =================================================================================================
 #define NK2D_SPIN_LIMIT 4000000
 
-// Arrival counter in NK2D_BAR_SHARDS shards, each on a 128-byte line of its own: an agent-scope atomic executes at
-// the memory side and adds to ONE address serialise (MI355X_MICROARCH.md, global atomics: ~50 ns each) -- with 200
-// workgroups on one counter the arrivals alone cost 10 us.  A workgroup adds to shard (blockIdx & 31); the polling
-// wave reads all shards with one load instruction (lane i reads shard i) and sums them.
-#define NK2D_BAR_SHARDS 32
-#define NK2D_BAR_STRIDE 32   /* unsigned ints between shards = 128 bytes */
-
-struct GridBarrier {
-    unsigned* arrive;
-    int* abort_flag;
-    unsigned nwg, epoch;
-    int* lds_ok;
-    long long spin_ticks;
-    int fences;
-    int xcd = 0;     // 1: every workgroup of the barrier sits on one XCD -- ONE counter, adds executed in that XCD's L2
-    int wg_id = 0;   // this workgroup's number among them (xcd = 0: blockIdx.x)
-    __device__ __forceinline__ bool sync() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left
-        // validation mode: the textbook hand-off as well (every wave releases before the barrier and acquires after it), which
-        // also covers an array the write-through / L1-bypassing accessors might have missed -- results must not change
-        if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x < 64) {     // the first wave arrives for the workgroup and polls
-            const int lane = threadIdx.x;
-            const unsigned target = (epoch + 1u) * nwg;
-            if (lane == 0) {
-                if (xcd) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else __hip_atomic_fetch_add(arrive + (size_t)(blockIdx.x % NK2D_BAR_SHARDS) * NK2D_BAR_STRIDE, 1u,
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            int good = 1;
-            long long spins = 0;
-            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                unsigned v = 0u;
-                if (lane < (xcd ? 1 : NK2D_BAR_SHARDS))
-                    v = __hip_atomic_load(arrive + (size_t)lane * NK2D_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-                const unsigned total = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-                if (total >= target) break;
-                const int ab = __builtin_amdgcn_readfirstlane(
-                    (lane == 0) ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
-                // bounded by TIME (a slow co-tenant must not fail a year that is merely waiting), and by a spin count as a
-                // last resort should the clock not advance
-                // (the clock is read every 64th poll; a limit of zero -- tests -- gives up at the first poll that has to wait)
-                const bool late = ((++spins & 63) == 0 || spin_ticks == 0) &&
-                                  (long long)__builtin_amdgcn_s_memrealtime() - t_begin > spin_ticks;
-                if (late || spins > 4000LL * NK2D_SPIN_LIMIT || ab != 0) {
-                    if (lane == 0) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    good = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (lane == 0) *lds_ok = good;
-        }
-        __syncthreads();
-        if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ++epoch;
-        return *lds_ok != 0;
-    }
-};
-
-// Synchronisation block of the one-launch years: arrival counters (32 shards on lines of their own), abort flag at 4096,
-// tickets of the XCD flavour at 6144, and from 8192 one 128-byte line per column for NeighbourSync.
+// Synchronisation block of the one-launch frozen year: abort flag at 4096, from 8192 one 128-byte line per workgroup
+// for NeighbourSync.
 static inline size_t yr_sync_bytes(const nk2d_ctx* c) { return 8192 + (size_t)c->ncol * 128; }
 
 // Where a workgroup is ONE column (the team flavour of k_frozen_persistent) the grid barrier asks for more than the data
@@ -2223,8 +2149,6 @@ struct FrozenArgs {
     int fences;
     int coef_lds;                // option "frozen_coef_lds" (bits of LdsSrc): what a wave finds in LDS; bits 2, 3 need `by_column`
     int by_column;               // 1: a workgroup is ONE ypos column with all its tracers (a wave each) instead of adjacent columns of one tracer
-    unsigned* tickets;           // XCD flavour: the workgroups that find themselves on XCD 0 take a number here
-    int nwg;                     // ... until this many have one
 };
 
 // XCD = 1: launched plainly with eight times the workgroups it needs (and some); a workgroup reads the XCD it landed on

@@ -125,10 +125,8 @@ struct nk2d_ctx {
     int frozen_persistent;          // option "frozen_persistent": 1 = where eligible (default), 0 = never
     int frozen_persistent_max_e;    // ... for grids of at most this many levels per lane (option "frozen_persistent_max_e")
     double frozen_cache_max_gb;     // ... whose schedule cache stays below this size (option "frozen_cache_gb")
-    int64_t frozen_cache_builds, frozen_persistent_years, frozen_xcd_years;
-    int frozen_xcd, frozen_xcd_failed;   // option "frozen_xcd": the year's workgroups on one XCD; set once the placement failed
+    int64_t frozen_cache_builds, frozen_persistent_years;
     int frozen_team;      // option "frozen_team": a four-wave team per column inside the one-launch frozen year (grids of at most two levels per lane)
-    int frozen_nbsync;    // option "frozen_nbsync": team columns hand over to their lateral neighbours instead of meeting at a grid barrier
     int frozen_wpb;       // option "frozen_wpb": columns (waves) per workgroup of the wave-per-column one-launch year with neighbour hand-over
     int frozen_coef_lds;  // option "frozen_coef_lds": the one-launch year keeps the static coefficients of a wave's column in LDS
     int frozen_by_column; // option "frozen_by_column": a workgroup of the one-launch year is one ypos column with all its tracers

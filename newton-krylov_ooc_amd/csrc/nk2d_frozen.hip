@@ -54,29 +54,14 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_cache_factor(DevP P, const Cache
 // the complex system on the fourth, exchanges through LDS): the phase of a small grid is the dependent arithmetic of one
 // column's Newton iteration, and the team cuts that chain (three tendencies one after the other, then the real and the
 // complex solve one after the other -> one tendency, then both solves side by side).  Same arithmetic, same bits.
-template <int E, int KIND, int XCD, int TEAM = 0, int NB = 0>
+template <int E, int KIND, int TEAM = 0>
 __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, FrozenArgs A) {
+    constexpr int XCD = 0, NB = 1;      // (rounds 2 - 3 also had all workgroups on one XCD and a grid barrier between the phases)
     __shared__ int lds_ok;
-    __shared__ int lds_id;
     __shared__ double team_lds[TEAM ? sizeof(TeamLds<E, 3>) / sizeof(double) : 1];
     constexpr int MPX = XCD ? 2 : 1;
     const int lane = threadIdx.x & 63;
     int wg = (int)blockIdx.x;
-    if constexpr (XCD) {
-        if (threadIdx.x == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            int id = -1;
-            if ((xcc & 7u) == 0u) {
-                const unsigned t = __hip_atomic_fetch_add(A.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t < (unsigned)A.nwg) id = (int)t;
-            }
-            lds_id = id;
-        }
-        __syncthreads();
-        wg = lds_id;
-        if (wg < 0) return;
-    }
     const int tw = uni_i((int)(threadIdx.x >> 6));                      // TEAM: the wave's place in its team
     // the column of this wave.  A team: the workgroup's.  A wave per column: adjacent columns of one tracer to a workgroup, or
     // -- `by_column` -- the workgroup is ONE ypos column and its waves that column's tracers (what is the same for every tracer
@@ -84,7 +69,6 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
     const bool by_col = !TEAM && !XCD && NB != 0 && A.by_column != 0;
     const int wave = TEAM ? uni_i(wg) : (by_col ? uni_i(tw * P.ny + wg) : uni_i(wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)));
     const bool col_wave = wave < P.ncol && (!by_col || (tw < P.tc && wg < P.ny));
-    GridBarrier bar{A.arrive, A.abort_flag, XCD ? (unsigned)A.nwg : gridDim.x, 0u, &lds_ok, A.spin_ticks, A.fences, XCD, wg};
     // NB: neighbour-to-neighbour hand-over instead of the grid barrier.  The unit is the workgroup: one column (teams), or
     // the columns of its waves -- then the workgroup to the left matters if its first column has a left neighbour, the one to
     // the right if its last column has a right neighbour (a tracer boundary inside the workgroup needs nothing)
@@ -110,7 +94,7 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_frozen_persistent(DevP P, Frozen
 #define FZ_Z (swapZ ? A.ZN : A.Z)
 #define FZ_ZN (swapZ ? A.Z : A.ZN)
 #define FZ_SYNC() \
-    if (!(NB ? nbs.sync() : bar.sync())) { status = 1; goto finish; }
+    if (!nbs.sync()) { status = 1; goto finish; }
     // a wave per column, three and more levels per lane (option "frozen_coef_lds"): the static coefficients of the wave's column
     // in LDS for the whole year (dynamic shared memory of the launch: NK2D_COEF_LDS_DOUBLES(E) doubles per wave)
     constexpr bool COEF_LDS = NB != 0 && !TEAM && !XCD && E >= 3;
@@ -321,16 +305,11 @@ finish:
             }
         }
     }
-    if constexpr (NB != 0) {
-        // no barrier behind the last phase: every workgroup reports a failure of its own (the host cleared `out`), the first
-        // the rest -- a workgroup that gave up raised the abort flag, its neighbours give up on it in turn
-        if (status != 0 && threadIdx.x == 0) A.out[0] = (double)status;
-        if (wg == 0 && threadIdx.x == 0) {
-            A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ; A.out[4] = (double)nbs.phase;
-        }
-    } else if (wave == 0 && lane == 0 && (!TEAM || tw == 0)) {
-        A.out[0] = (double)status; A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ;
-        A.out[4] = (double)bar.epoch;
+    // no barrier behind the last phase: every workgroup reports a failure of its own (the host cleared `out`), the first the
+    // rest -- a workgroup that gave up raised the abort flag, its neighbours give up on it in turn
+    if (status != 0 && threadIdx.x == 0) A.out[0] = (double)status;
+    if (wg == 0 && threadIdx.x == 0) {
+        A.out[1] = (double)done; A.out[2] = (double)swapY; A.out[3] = (double)swapZ; A.out[4] = (double)nbs.phase;
     }
 #undef FZ_SYNC
 #undef FZ_Y
@@ -433,53 +412,40 @@ static hipError_t launch_resident(nk2d_ctx* c, K kernel, dim3 grid, dim3 block, 
     return hipGetLastError();
 }
 
-template <int E, int KIND, int XCD, int TEAM>
-static hipError_t launch_frozen_one(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
-    if (coop) {
-        if constexpr (!XCD) {
-            if (c->frozen_nbsync) {
-                // a wave per column with the neighbour hand-over: option "frozen_wpb" waves (= columns) to a workgroup -- the
-                // waves of a workgroup move in lock step, its neighbours are the workgroups to the left and right
-                const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
-                const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
-                // (a wave per column, three and more levels per lane: a wave's own data of the year in LDS -- frozen_lds_doubles)
-                if (!TEAM && E >= 3 && A.by_column)
-                    return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, dim3((unsigned)c->ny), dim3(64 * c->tc), P, A,
-                                           sizeof(double) * frozen_lds_doubles(E, A.coef_lds, true, c->tc));
-                const size_t lds = (!TEAM && E >= 3 && A.coef_lds) ? sizeof(double) * frozen_lds_doubles(E, A.coef_lds, false, wpb) : 0;
-                return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 1>, g, dim3(64 * wpb), P, A, lds);
-            }
-        }
-        return launch_resident(c, k_frozen_persistent<E, KIND, XCD, TEAM, 0>, grid, dim3(NK2D_BLOCK), P, A);
-    }
-    hipLaunchKernelGGL((k_frozen_persistent<E, KIND, XCD, TEAM, 0>), grid, dim3(NK2D_BLOCK), 0, nk2d_s(c), P, A);
-    return hipGetLastError();
+template <int E, int KIND, int TEAM>
+static hipError_t launch_frozen_one(nk2d_ctx* c, dim3 grid, DevP& P, FrozenArgs& A) {
+    // a team per column: the workgroup IS the column.  A wave per column: option "frozen_wpb" adjacent columns of one tracer to
+    // a workgroup (its waves move in lock step, its neighbours are the workgroups to the left and right), or -- by_column --
+    // one ypos column with all its tracers.  Three and more levels per lane: a wave's own data of the year in LDS
+    const int wpb = TEAM ? NK2D_WAVES_PER_BLOCK : std::max(1, std::min(NK2D_WAVES_PER_BLOCK, c->frozen_wpb));
+    const dim3 g = TEAM ? grid : dim3((unsigned)((c->ncol + wpb - 1) / wpb));
+    if (!TEAM && E >= 3 && A.by_column)
+        return launch_resident(c, k_frozen_persistent<E, KIND, TEAM>, dim3((unsigned)c->ny), dim3(64 * c->tc), P, A,
+                               sizeof(double) * frozen_lds_doubles(E, A.coef_lds, true, c->tc));
+    const size_t lds = (!TEAM && E >= 3 && A.coef_lds) ? sizeof(double) * frozen_lds_doubles(E, A.coef_lds, false, wpb) : 0;
+    return launch_resident(c, k_frozen_persistent<E, KIND, TEAM>, g, dim3(64 * wpb), P, A, lds);
 }
-template <int KIND, int XCD, int TEAM>
-static hipError_t launch_frozen_e(nk2d_ctx* c, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
+template <int KIND, int TEAM>
+static hipError_t launch_frozen_e(nk2d_ctx* c, dim3 grid, DevP& P, FrozenArgs& A) {
     switch (c->E) {
-        case 1: return launch_frozen_one<1, KIND, XCD, TEAM>(c, coop, grid, P, A);
-        case 2: return launch_frozen_one<2, KIND, XCD, TEAM>(c, coop, grid, P, A);
-        // three and four levels per lane: a wave per column, cooperative flavour (all module kinds)
-        case 3: if constexpr (!TEAM && !XCD) return launch_frozen_one<3, KIND, 0, 0>(c, coop, grid, P, A); else break;
-        case 4: if constexpr (!TEAM && !XCD) return launch_frozen_one<4, KIND, 0, 0>(c, coop, grid, P, A); else break;
-        // five to eight levels per lane (up to 512 levels): a wave per column, cooperative flavour, linear sources
-        case 5: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<5, 0, 0, 0>(c, coop, grid, P, A); else break;
-        case 6: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<6, 0, 0, 0>(c, coop, grid, P, A); else break;
-        case 7: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<7, 0, 0, 0>(c, coop, grid, P, A); else break;
-        case 8: if constexpr (!TEAM && !XCD && KIND == 0) return launch_frozen_one<8, 0, 0, 0>(c, coop, grid, P, A); else break;
+        case 1: return launch_frozen_one<1, KIND, TEAM>(c, grid, P, A);
+        case 2: return launch_frozen_one<2, KIND, TEAM>(c, grid, P, A);
+        // three and four levels per lane: a wave per column (all module kinds)
+        case 3: if constexpr (!TEAM) return launch_frozen_one<3, KIND, 0>(c, grid, P, A); else break;
+        case 4: if constexpr (!TEAM) return launch_frozen_one<4, KIND, 0>(c, grid, P, A); else break;
+        // five to eight levels per lane (up to 512 levels): a wave per column, linear sources
+        case 5: if constexpr (!TEAM && KIND == 0) return launch_frozen_one<5, 0, 0>(c, grid, P, A); else break;
+        case 6: if constexpr (!TEAM && KIND == 0) return launch_frozen_one<6, 0, 0>(c, grid, P, A); else break;
+        case 7: if constexpr (!TEAM && KIND == 0) return launch_frozen_one<7, 0, 0>(c, grid, P, A); else break;
+        case 8: if constexpr (!TEAM && KIND == 0) return launch_frozen_one<8, 0, 0>(c, grid, P, A); else break;
         default: break;
     }
     return hipErrorInvalidValue;
 }
-static hipError_t launch_frozen(nk2d_ctx* c, bool xcd, bool team, bool coop, dim3 grid, DevP& P, FrozenArgs& A) {
+static hipError_t launch_frozen(nk2d_ctx* c, bool team, dim3 grid, DevP& P, FrozenArgs& A) {
     const bool forced = c->kind == 2;
-    if (xcd) {
-        if (team) return forced ? launch_frozen_e<2, 1, 1>(c, coop, grid, P, A) : launch_frozen_e<0, 1, 1>(c, coop, grid, P, A);
-        return forced ? launch_frozen_e<2, 1, 0>(c, coop, grid, P, A) : launch_frozen_e<0, 1, 0>(c, coop, grid, P, A);
-    }
-    if (team) return forced ? launch_frozen_e<2, 0, 1>(c, coop, grid, P, A) : launch_frozen_e<0, 0, 1>(c, coop, grid, P, A);
-    return forced ? launch_frozen_e<2, 0, 0>(c, coop, grid, P, A) : launch_frozen_e<0, 0, 0>(c, coop, grid, P, A);
+    if (team) return forced ? launch_frozen_e<2, 1>(c, grid, P, A) : launch_frozen_e<0, 1>(c, grid, P, A);
+    return forced ? launch_frozen_e<2, 0>(c, grid, P, A) : launch_frozen_e<0, 0>(c, grid, P, A);
 }
 
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows) {
@@ -714,41 +680,8 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
     // against 11.8 - 12.6 ms, 30^2 12.6 / 14.2, 40^2 15.5 / 16.1, 52^2 18.5 / 20.1, 104^2 36.5 / 40.9.
     const bool team = c->frozen_team && c->E <= 2;
     const int nblk = team ? c->ncol : nk2d_grid(c->ncol);
-    A.tickets = (unsigned*)((char*)c->YR_SYNC + 6144);
-    A.nwg = nblk;
     const double* o = c->hYR_OUT;
-    bool ran = false, timed = false;
-    // ---- all of the year's workgroups on ONE XCD (option "frozen_xcd"; at most what an XCD's 32 CUs hold at once)
-    // (one workgroup per CU is what the kernel's registers admit at two levels per lane: an XCD holds 32 of them at once)
-    // (up to two levels per lane: beyond, the cooperative flavour with the neighbour hand-over is the faster one -- 250 x 48: 91.5 ms
-    // on one XCD against 76 ms launch by launch)
-    if (c->frozen_xcd && !c->frozen_xcd_failed && !team && nblk <= 28 && c->E <= 2) {
-        // a workgroup that does not get its partners gives up after 20 ms (the year itself takes less than that per phase)
-        A.spin_ticks = std::min<long long>(A.spin_ticks, 2000000LL);
-        NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
-        const dim3 grid(8 * nblk + 64);
-        struct Turn {
-            int waves;
-            explicit Turn(int w) : waves(w) { nk2d_turn_take(waves); }
-            ~Turn() { nk2d_turn_give(waves); }
-        } turn(4 * nblk);
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[0], nk2d_s(c)));
-        NK2D_CHECK(c, launch_frozen(c, /*xcd*/ true, team, /*coop*/ false, grid, P, A));
-        NK2D_CHECK(c, hipGetLastError());
-        NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));
-        NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, nk2d_s(c)));
-        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
-        ran = (int)o[0] == 0 && (int64_t)o[1] == n;
-        timed = true;
-        if (!ran) {
-            // XCD 0 did not get its workgroups (placement is not promised): not again on this context; the state is
-            // where the year started only if nothing ran -- hand the year back to the caller, who restarts it
-            c->frozen_xcd_failed = 1;
-            return 2;
-        }
-        c->frozen_xcd_years++;
-    }
-    if (!ran) {
+    {
         A.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
         hipError_t rc = hipErrorInvalidValue;
         NK2D_CHECK(c, hipMemsetAsync(c->YR_OUT, 0, sizeof(double) * 32, nk2d_s(c)));
@@ -759,17 +692,16 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
             explicit Turn(int w) : waves(w) { nk2d_turn_take(waves); }
             ~Turn() { nk2d_turn_give(waves); }
         } turn(team ? 4 * c->ncol : c->ncol);
-        rc = launch_frozen(c, /*xcd*/ false, team, /*coop*/ true, dim3(nblk), P, A);
+        rc = launch_frozen(c, team, dim3(nblk), P, A);
         if (rc == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return 1; }
         NK2D_CHECK(c, rc);
         NK2D_CHECK(c, hipEventRecord(c->yr_ev[1], nk2d_s(c)));
-        timed = true;
         NK2D_CHECK(c, hipMemcpyAsync(c->hYR_OUT, c->YR_OUT, sizeof(double) * 32, hipMemcpyDeviceToHost, nk2d_s(c)));
         NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
         if ((int)o[0] != 0 || (int64_t)o[1] != n) return 2;
     }
     if (team) c->frozen_team_years++;
-    if (timed) {   // the launch itself, between two events on the context's stream (bench.py's roofline of the one-launch year)
+    {   // the launch itself, between two events on the context's stream (bench.py's roofline of the one-launch year)
         float ms = 0.f;
         NK2D_CHECK(c, hipEventElapsedTime(&ms, c->yr_ev[0], c->yr_ev[1]));
         c->frozen_launch_us += (int64_t)(1000.0 * (double)ms);

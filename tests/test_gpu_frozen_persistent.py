@@ -50,7 +50,7 @@ def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
     assert np.array_equal(eng.download(fxp_p), eng.download(fxp_l))          # and the launch-per-phase year of another state
     assert eng.counter("frozen_persistent_years") == 2 and eng.counter("frozen_cache_builds") == 1   # one cache per schedule
     # which flavour ran: a four-wave team per column, cooperative launch (option "frozen_team", the default)
-    assert eng.counter("frozen_team_years") == 2 and eng.counter("frozen_xcd_years") == 0
+    assert eng.counter("frozen_team_years") == 2
     for key in ("nsteps", "nnewton"):
         assert st_p[key] == st_l[key], key
     # (both evaluate the error estimate of every 128th step -- a tendency and a solve each; the one-launch year leaves out
@@ -120,10 +120,9 @@ def test_forced_modules_and_column_grids():
 
 @pytest.mark.parametrize("case", ["iage_26", "iage_52_two_sweeps", "forced_decay_22x9"])
 def test_team_and_wave_per_column_flavours_agree(case):
-    """(also: columns that hand over to their lateral neighbours instead of meeting at a grid barrier, with and without the
-    validation fences)  the four-wave team inside the one-launch year (option "frozen_team" 1, the default) against the wave per column
-    (0: on one XCD where the workgroups fit), each against the launch-per-phase year: the recorded and a perturbed state, bit for bit -- also with two-sweep solves
-    (inner tolerance 1e-3), whose second launch of an iteration has no stage part"""
+    """the four-wave team inside the one-launch year (option "frozen_team" 1, the default up to two levels per lane) against the wave
+    per column, with and without the validation fences, each against the launch-per-phase year: the recorded and a perturbed state,
+    bit for bit -- also with two-sweep solves (inner tolerance 1e-3), whose second launch of an iteration has no stage part"""
     from nk_ooc_amd.engine import forced_engine
     from nk_ooc_amd.grid import Grid2d
 
@@ -148,16 +147,15 @@ def test_team_and_wave_per_column_flavours_agree(case):
     want = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
     assert np.array_equal(want[0], eng.download(fx))
     eng.set_option("frozen_persistent", 1)
-    # (team, neighbour hand-over instead of the grid barrier -- option "frozen_nbsync", default with teams --, fences)
-    for team, nbsync, fences, years in ((1, 1, 0, 2), (0, 0, 0, 2), (1, 0, 0, 4), (1, 1, 1, 6)):
+    # (team or a wave per column, columns per workgroup of the latter, release / acquire fences around every hand-over)
+    for team, wpb, fences, years in ((1, 2, 0, 2), (0, 4, 0, 2), (0, 1, 0, 2), (1, 2, 1, 4), (0, 2, 1, 4)):
         eng.set_option("frozen_team", team)
-        eng.set_option("frozen_nbsync", nbsync)
+        eng.set_option("frozen_wpb", wpb)
         eng.set_option("year_fences", fences)
         got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team, nbsync, fences)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, team, wpb, fences)
         assert eng.counter("frozen_team_years") == years
-    assert eng.counter("frozen_xcd_years") == 2         # the two years of the wave-per-column flavour
-    assert eng.counter("frozen_persistent_years") == 8 and eng.frozen_fallbacks() == 0
+    assert eng.counter("frozen_persistent_years") == 10 and eng.frozen_fallbacks() == 0
     eng.close()
 
 
@@ -178,7 +176,7 @@ def test_every_levels_per_lane_instantiation_of_the_one_launch_year(nz):
     eng.set_option("frozen_persistent", 1)
     got = [eng.download(eng.comp_fcn_frozen(v, sched)[0]) for v in (x, xp)]
     _, st_p = eng.comp_fcn_frozen(xp, sched)
-    assert eng.counter("frozen_persistent_years") == 3 and eng.counter("frozen_xcd_years") == 0
+    assert eng.counter("frozen_persistent_years") == 3
     assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert st_p["nerr_checked"] > 0 and st_p["seconds"] < st_l["seconds"]
     # adjacent columns of one tracer to a workgroup, or one ypos column with all its tracers (and the step's constants shared in LDS)
@@ -212,13 +210,13 @@ def test_full_size_year_in_one_launch():
     assert np.array_equal(want[0], eng.download(fx)) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert st_p["nlaunch"] < 20 < st_l["nlaunch"] and st_p["seconds"] < 0.9 * st_l["seconds"]
     print(f"416^2 frozen year: {1e3 * st_l['seconds']:.1f} ms launch by launch, {1e3 * st_p['seconds']:.1f} ms in one launch")
-    # four columns to a workgroup instead of one (option "frozen_wpb"), and the grid barrier instead of the hand-over: the same bits
-    for wpb, nbsync in ((4, 1), (1, 0)):
+    # adjacent columns of one tracer to a workgroup, four or one of them (option "frozen_wpb"): the same bits
+    eng.set_option("frozen_by_column", 0)
+    for wpb in (4, 1):
         eng.set_option("frozen_wpb", wpb)
-        eng.set_option("frozen_nbsync", nbsync)
-        assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), want[1]), (wpb, nbsync)
-    eng.set_option("frozen_wpb", 1)
-    eng.set_option("frozen_nbsync", 1)
+        assert np.array_equal(eng.download(eng.comp_fcn_frozen(xp, sched)[0]), want[1]), wpb
+    eng.set_option("frozen_wpb", 2)
+    eng.set_option("frozen_by_column", 1)
     assert eng.counter("frozen_persistent_years") == 5
     # what lives in LDS for the year (bits: coefficients, W, the step's mixing columns and Jacobian diagonals, pivots) and which
     # columns share a workgroup: the same bits whatever the choice
