@@ -166,6 +166,46 @@ def test_a_kernel_that_gives_up_hands_the_year_back():
     eng.close()
 
 
+def test_commands_through_the_relay_wave(monkeypatch):
+    """NK2D_STREAM_RELAY=1: the host writes its commands into pinned memory and a relay wave of the kernel copies them into HBM (what a
+    device without a large BAR gets): the same year"""
+    eng = _iage(52, 52)
+    x = eng.upload(_state(eng))
+    fx, st, sched = eng.comp_fcn(x, record=True)
+    eng.close()
+    monkeypatch.setenv("NK2D_STREAM_RELAY", "1")
+    eng = _iage(52, 52)
+    x = eng.upload(_state(eng))
+    eng.set_option("stream_years", 1)
+    fx_s, st_s, sched_s = eng.comp_fcn(x, record=True)
+    assert eng.counter("stream_years_run") == 1 and eng.counter("stream_timeouts") == 0
+    assert np.array_equal(sched_s, sched) and st_s["nlaunch"] < 0.2 * st["nlaunch"]
+    eng.close()
+
+
+def test_two_engines_driven_from_two_threads():
+    """two contexts, a host thread each (as ModelState drives its tracer modules): their resident kernels take turns -- or run side by
+    side where their waves leave the chip room -- and each year is the year of its engine alone"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    engs = [_iage(52, 52), _iage(130, 20)]
+    xs = [e.upload(_state(e, seed=9 + i)) for i, e in enumerate(engs)]
+    want = [e.download(e.comp_fcn(x)[0]) for e, x in zip(engs, xs)]
+    for e in engs:
+        e.set_option("stream_years", 1)
+
+    def years(k):
+        return [engs[k].download(engs[k].comp_fcn(xs[k])[0]) for _ in range(3)]
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        got = list(pool.map(years, range(2)))
+    for k in range(2):
+        for g in got[k]:
+            assert np.array_equal(g, want[k])
+        assert engs[k].counter("stream_years_run") == 3 and engs[k].counter("stream_timeouts") == 0
+        engs[k].close()
+
+
 def test_full_size_stream_year():
     """416 x 416: the year that produces F(x), bit for bit, and faster than by launches"""
     n = 416
