@@ -1965,11 +1965,11 @@ __device__ __forceinline__ double uni_d(double v) {
 // the modules whose Jacobian is a function of time alone everything but the state is known from the schedule:
 // the mixing planes of every step's stage times, its Jacobian planes, its line factorisation.  Up to 208 x 208 that is
 // at most a few GB per schedule, computed ONCE per schedule (= once per Newton iteration) by two batched launches over
-// (step, column) -- k_cache_planes, k_cache_factor -- and read by every year of the Krylov solve.  What is left of a
-// year are its simplified-Newton iterations, one phase each: k_frozen_persistent runs them all in one cooperative
-// launch, a wave per column, the phases separated by the grid barrier of k_year_persistent, with the launch-per-phase
-// path's own device functions (newton_fused_body; the last iteration of a step ends it: FINAL) -- bit-identical to it.
-// At 26 x 26 a launch-per-phase year is 2 200 launches of 7.6 us; a phase here costs its barrier plus a microsecond.
+// (step, column) -- k_cache_planes, k_cache_factor -- and read by every year of the Krylov solve (at 416 x 416: 102 GB, the
+// cache is what the 288 GB are for).  What is left of a year are its simplified-Newton iterations, one phase each:
+// k_frozen_persistent runs them all in one launch whose workgroups are all resident, a wave or a four-wave team per
+// column, workgroups handing over to their lateral neighbours between phases, with the launch-per-phase path's own device
+// functions (newton_fused_body; the last iteration of a step ends it: FINAL) -- bit-identical to it.
 // =================================================================================================
 struct CacheRow {
     VmixArgs v;          // slots 0..2: the stage times of the row (out: its planes in the cache); slot 3: its Jacobian time
@@ -2151,12 +2151,6 @@ struct FrozenArgs {
     int by_column;               // 1: a workgroup is ONE ypos column with all its tracers (a wave each) instead of adjacent columns of one tracer
 };
 
-// XCD = 1: launched plainly with eight times the workgroups it needs (and some); a workgroup reads the XCD it landed on
-// (HW_REG_XCC_ID), those on XCD 0 take a ticket, the first nwg of them are the year's workgroups, everybody else exits.
-// All exchanges then stay in ONE L2: plain stores + L1-bypassing loads (MP = 2), ONE arrival counter with L2-executed adds
-// -- a barrier costs 1.0-1.5 us instead of 2.1 us and a neighbour's column comes from L2 instead of the fabric
-// (tools/proto_xcd_barrier.hip, profiles/r03_xcd_barrier.log).  HIP promises no placement: if XCD 0 does not get its nwg
-// workgroups the barrier times out, the abort flag is raised and the caller runs the cooperative flavour (XCD = 0).
 // f = fun(t, y) of the column (the plane kvp is the mixing plane at t): the tendency at a step start, for the error estimate
 template <int E, int KIND, int MP>
 __device__ __forceinline__ void tend_at_body(const DevP& P, const double* __restrict__ y, const double* __restrict__ kvp,

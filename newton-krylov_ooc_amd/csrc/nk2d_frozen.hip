@@ -673,11 +673,9 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
             A.coef_lds &= ~drop;
         }
     }
-    // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column.  Measured
-    // (tools/probe_frozen_persistent.py, profiles/r03_frozen_team.log): teams want a CU each -- on one XCD, two to four
-    // workgroups to a CU, they lose more than they gain (26^2: 13.3 ms, 16.1 ms when LDS padding forces exactly two per CU) --
-    // so they run in the cooperative flavour, where they beat the wave-per-column year on one XCD at every size: 26^2 11.4
-    // against 11.8 - 12.6 ms, 30^2 12.6 / 14.2, 40^2 15.5 / 16.1, 52^2 18.5 / 20.1, 104^2 36.5 / 40.9.
+    // option "frozen_team": a workgroup per column (four waves: newton_team_body) instead of a wave per column, up to two levels per
+    // lane.  Measured in round 3 (profiles/r03_frozen_team.log, r03_frozen_nbsync.log): teams want a CU each and beat the
+    // wave-per-column year at every such size -- 26^2 9.4 ms, 52^2 14.9, 104^2 27.0 with the neighbour hand-over.
     const bool team = c->frozen_team && c->E <= 2;
     const int nblk = team ? c->ncol : nk2d_grid(c->ncol);
     const double* o = c->hYR_OUT;

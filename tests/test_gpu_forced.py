@@ -122,9 +122,8 @@ def test_two_module_krylov(tmp_path, monkeypatch):
 
 def test_two_module_process_ends_cleanly():
     """two modules whose years run from two host threads, Krylov solve, engines closed -- and, second run, left open: the
-    process must END with status 0.  (Two threads inside hipLaunchCooperativeKernel at once used to leave the HIP runtime
-    with a queue its tear-down crashed on, after every result was written: exit status 139.  The library now enqueues
-    cooperative launches one at a time.)"""
+    process must END with status 0.  (Rounds 2 - 3: cooperative launches left the HIP runtime with a queue its tear-down crashed
+    on, after every result was written: exit status 139.  Nothing is launched cooperatively any more.)"""
     import subprocess
     import sys
 

@@ -49,7 +49,7 @@ def test_one_launch_year_is_the_launch_per_phase_year(n, mode):
     fxp_p, st_pp = eng.comp_fcn_frozen(xp, sched)
     assert np.array_equal(eng.download(fxp_p), eng.download(fxp_l))          # and the launch-per-phase year of another state
     assert eng.counter("frozen_persistent_years") == 2 and eng.counter("frozen_cache_builds") == 1   # one cache per schedule
-    # which flavour ran: a four-wave team per column, cooperative launch (option "frozen_team", the default)
+    # which flavour ran: a four-wave team per column (option "frozen_team", the default up to two levels per lane)
     assert eng.counter("frozen_team_years") == 2
     for key in ("nsteps", "nnewton"):
         assert st_p[key] == st_l[key], key
@@ -161,7 +161,7 @@ def test_team_and_wave_per_column_flavours_agree(case):
 
 @pytest.mark.parametrize("nz", [250, 320, 384, 512])
 def test_every_levels_per_lane_instantiation_of_the_one_launch_year(nz):
-    """four, five, six and eight levels per lane (a wave per column, cooperative launch, neighbour hand-over) on a narrow grid:
+    """four, five, six and eight levels per lane (a wave per column, neighbour hand-over) on a narrow grid:
     the one-launch year against the launch-per-phase year, recorded and perturbed state, bit for bit -- and faster"""
     ny = 48
     eng = _iage(nz, ny)
