@@ -151,7 +151,6 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_by_column") { c->frozen_by_column = (int)value; return 0; }
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
     if (key == "spec_bias") { c->spec_bias = value > 0.0 ? value : 1.0; return 0; }
-    if (key == "pc_one_launch") { c->pc_one_launch = (int)value; return 0; }
     if (key == "stream_years") { c->stream_years = (int)value; c->stream_lost = 0; return 0; }
     if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
     if (key == "frozen_alloc_async") { c->frozen_alloc_async = value != 0.0; return 0; }
@@ -516,8 +515,6 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_by_column = 1;
     c->strm = nullptr;
     c->spec_bias = 1.0;
-    c->pc_one_launch = 1;
-    c->pc_one_launch_applies = 0;
     c->stream_years = 1;      // free-running years as command streams where eligible (bit 2: frozen years too)
     c->stream_on = 0;
     c->stream_lost = 0;
@@ -952,7 +949,6 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     if (key == "frozen_persistent_years") v = c->frozen_persistent_years;
     else if (key == "frozen_cache_builds") v = c->frozen_cache_builds;
     else if (key == "frozen_team_years") v = c->frozen_team_years;
-    else if (key == "pc_one_launch_applies") v = c->pc_one_launch_applies;
     else if (key == "stream_years_run") v = c->stream_years_run;
     else if (key == "stream_commands") v = c->stream_cmds;
     else if (key == "stream_launches") v = c->stream_launches;

@@ -177,8 +177,6 @@ struct nk2d_ctx {
     double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
-    int pc_one_launch;   // option "pc_one_launch": the block substitution of an apply as ONE launch (k_pc_subst)
-    int64_t pc_one_launch_applies;
     int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
     int pc_fp32;   // 1: Schur inverses of the linear modules' preconditioner stored in single precision (option "pc_fp32")
     int pc_refine; // ... with this many refinement steps per apply against the exact operator (option "pc_refine", default 1)

@@ -48,10 +48,8 @@ struct Precond {
     int fp32;
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
     double* ROWS;  // scaled pivot rows    [tc][NB][m]
-    double* YV;    // forward-sweep vectors [tc][nb][m]; behind them [cap_sys][nb][m] for k_pc_subst's updated vectors
+    double* YV;    // forward-sweep vectors [tc][nb][m]
     double* XV;    // solution vectors      [tc][nb][m]
-    void* SUBST_SYNC = nullptr;   // arrival counters, abort flag, status of the one-launch substitution (k_pc_subst)
-    void* hSUBST = nullptr;       // pinned: its status
     double dt;
 };
 
@@ -437,168 +435,6 @@ __global__ void __launch_bounds__(256) k_pc_gemv2(PcDev P, int mode, int j, cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The whole block substitution in ONE launch (round 4; option "pc_one_launch", default).  The chain of 2 nb - 1 dependent
-// mat-vecs was 2 nb - 1 launches: ~3 us of streaming a step at 416 x 416, ~4 us of launch boundary behind each.  Here a wave
-// owns one row of a system for the whole substitution, and what a step needs from the others -- the WHOLE vector of the step
-// before -- it takes from them without a barrier: the vectors are pre-set to a NaN that no computation produces
-// (PC_POISON), the producers store their element write-through, the consumers poll the vector itself until no element is
-// the poison (bounded by time).  No arrival counters, no wait for a store to complete.
-//   The bytes of the kernel are the matrix rows (cold HBM, read once).  They are requested TWO steps ahead into three
-// register sets: vmcnt retires in order, so a poll issued behind a row request returns behind it -- with one request always
-// in flight, the poll of step s returns when the rows of step s+1 have landed, the rows of step s+2 are requested at once,
-// and the chain (dot product, store, visibility at the other workgroups: ~2 us) hides behind the ~3 us the stream needs.
-//   Same arithmetic in the same order as k_pc_gemv2: bit-identical.  The backward sweep's updated vectors y_j - U_j x_{j+1}
-// go to a buffer of their own (ZV) so that "not the poison" means "updated".
-// ---------------------------------------------------------------------------------------------------------------------
-#define PC_POISON_WORD 0x7FF8DEADu                   // both halves: hipMemsetD32Async fills the vectors
-#define PC_POISON 0x7FF8DEAD7FF8DEADull
-#define PC_XS_PER_THREAD(NT) ((64 * PC_GEMV_CHUNK + (NT)-1) / (NT))
-struct PcSubstArgs {
-    const double* sinv;      // [nsys][nb][m][m]
-    double* yv;              // [nsys][nb][m]  forward vectors           (poisoned by the host; y_0 = r_0 copied in)
-    double* zv;              // [nsys][nb][m]  y_j - U_j x_{j+1}         (poisoned by the host)
-    double* xv;              // [nsys][nb][m]  right-hand sides in, solutions out
-    size_t mstride, vstride;
-    int* abort_flag;
-    int* status;             // != 0: a wait ran over its time limit
-    long long spin_ticks;
-};
-
-// (no branch around a load: a column behind the row's end loads the row's last pair and is zeroed by a select)
-__device__ __forceinline__ void pc_load_rows(const double2* row2, int m2, int lane, double2 (&mv)[PC_GEMV_CHUNK]) {
-#pragma unroll
-    for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
-        const int c = lane + 64 * q;
-        // (scalar base + unsigned 32-bit lane offset: one address register a load, not two)
-        unsigned off = (unsigned)((c < m2) ? c : m2 - 1) * 16u;
-        asm volatile("" : "+v"(off));          // (computed where it is used: hoisted out of the step loop, the ten offsets were spilled)
-        const double2 v = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(row2) + off);
-        mv[q].x = (c < m2) ? v.x : 0.0;
-        mv[q].y = (c < m2) ? v.y : 0.0;
-    }
-}
-
-__device__ __forceinline__ bool pc_is_poison(double v) { return (unsigned long long)__double_as_longlong(v) == PC_POISON; }
-
-template <int NT, int SETS>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SETS == 3 ? 2 : 3, 4))) k_pc_subst(PcDev P, PcSubstArgs A) {
-    constexpr int XPT = PC_XS_PER_THREAD(NT);
-    __shared__ double2 xs[2][64 * PC_GEMV_CHUNK];     // m <= 128 PC_GEMV_CHUNK (checked by the host): one chunk per row
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (NT >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform: scalar bases)
-    const int sys = blockIdx.y;
-    const int m = P.m, m2 = P.m >> 1, nb = P.nb;
-    const bool live = r < m;
-    const size_t mm = (size_t)m * m;
-    const double* sinv = A.sinv + (size_t)sys * A.mstride + (size_t)(live ? r : 0) * m;
-    double* yv = A.yv + (size_t)sys * A.vstride;
-    double* zv = A.zv + (size_t)sys * A.vstride;
-    double* xv = A.xv + (size_t)sys * A.vstride;
-    const int rr = live ? r : 0;
-    const int slot = rr / P.nz, k = rr - slot * P.nz;
-    const int nsteps = 2 * nb - 1;            // forward j = 1 .. nb-1 (matrix j-1), backward j = nb-1 .. 0 (matrix j)
-    auto rows_of = [&](int s) {
-        const int jm = (s < nb - 1) ? s : (2 * nb - 2 - s);
-        return reinterpret_cast<const double2*>(sinv + (size_t)jm * mm);
-    };
-    // what the epilogue of step s needs beside the sum: (right-hand side, l) forward, (y_{j-1}, u) backward
-    auto side_of = [&](int s, double& v0, double& cf) {
-        if (s < nb - 1) {
-            const int j = s + 1;
-            v0 = xv[(size_t)j * m + rr];
-            cf = lat_l(P, slot, k, j);
-        } else {
-            const int j = 2 * nb - 2 - s;
-            v0 = (j > 0) ? ld_mp<1>(yv + (size_t)(j - 1) * m + rr) : 0.0;
-            cf = (j > 0) ? lat_u(P, slot, k, j - 1) : 0.0;
-        }
-    };
-    double2 b0[PC_GEMV_CHUNK], b1[PC_GEMV_CHUNK], b2[(SETS == 3) ? PC_GEMV_CHUNK : 1];
-    double v0, cf, v0n = 0.0, cfn = 0.0;
-    pc_load_rows(rows_of(0), m2, lane, b0);
-    pc_load_rows(rows_of(1), m2, lane, b1);      // nb >= 2: at least three steps
-    side_of(0, v0, cf);
-
-    // one step: false when a wait ran over its time limit (the whole workgroup leaves)
-    auto step = [&](int s, double2 (&cur)[PC_GEMV_CHUNK], double2 (&pre)[PC_GEMV_CHUNK]) -> bool {
-        const bool fwd = s < nb - 1;
-        const int j = fwd ? s + 1 : 2 * nb - 2 - s;
-        // the vector of this step: y_{j-1} (forward), y_{nb-1} resp. y_j - U_j x_{j+1} (backward); polled until complete
-        const double* a = fwd ? yv + (size_t)(j - 1) * m : ((j == nb - 1) ? yv + (size_t)j * m : zv + (size_t)j * m);
-        double2 (&x)[64 * PC_GEMV_CHUNK] = xs[s & 1];
-        int good = 1;
-        {
-            double2 got[XPT];
-            long long spins = 0;
-            const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                bool all = true;
-#pragma unroll
-                for (int u = 0; u < XPT; ++u) {
-                    const int i = min((int)threadIdx.x + u * NT, m2 - 1);      // (behind the end: the last pair once more)
-                    got[u] = make_double2(ld_mp<1>(a + 2 * i), ld_mp<1>(a + 2 * i + 1));
-                    all = all && !pc_is_poison(got[u].x) && !pc_is_poison(got[u].y);
-                }
-                if (all) break;
-                if ((++spins & 63) == 0) {
-                    const bool late = (long long)__builtin_amdgcn_s_memrealtime() - t_begin > A.spin_ticks;
-                    if (late || __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        good = 0;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int u = 0; u < XPT; ++u) x[min((int)threadIdx.x + u * NT, m2 - 1)] = got[u];
-        }
-        // the rows of step s+2 and the side values of step s+1: requested before anything else happens (SETS == 3; with two
-        // register sets the rows of step s+2 go where those of step s are -- behind the dot product)
-        if (SETS == 3 && s + 2 < nsteps) pc_load_rows(rows_of(s + 2), m2, lane, pre);
-        if (s + 1 < nsteps) side_of(s + 1, v0n, cfn);
-        if (__syncthreads_and(good) == 0) {
-            if (threadIdx.x == 0) *A.status = 1;
-            return false;
-        }
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < PC_GEMV_CHUNK; ++q) {
-            const int c = lane + 64 * q;
-            const double2 xv2 = (c < m2) ? x[c] : make_double2(0.0, 0.0);
-            acc[(2 * q) & 3] = __builtin_fma(cur[q].x, xv2.x, acc[(2 * q) & 3]);
-            acc[(2 * q + 1) & 3] = __builtin_fma(cur[q].y, xv2.y, acc[(2 * q + 1) & 3]);
-            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (the vector two pairs at a time: registers)
-        }
-        if (SETS == 2 && s + 2 < nsteps) pc_load_rows(rows_of(s + 2), m2, lane, pre);
-        const double sum = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        if (live && lane == 0) {
-            if (fwd) {
-                st_mp<1>(yv + (size_t)j * m + r, v0 - cf * sum);
-            } else {
-                if (j > 0) st_mp<1>(zv + (size_t)(j - 1) * m + r, v0 - cf * sum);
-                xv[(size_t)j * m + r] = sum;
-            }
-        }
-        v0 = v0n;
-        cf = cfn;
-        return true;
-    };
-    if constexpr (SETS == 3) {
-        for (int s = 0; s < nsteps; s += 3) {
-            if (!step(s, b0, b2)) return;
-            if (s + 1 < nsteps && !step(s + 1, b1, b0)) return;
-            if (s + 2 < nsteps && !step(s + 2, b2, b1)) return;
-        }
-    } else {
-        for (int s = 0; s < nsteps; s += 2) {
-            if (!step(s, b0, b0)) return;
-            if (s + 1 < nsteps && !step(s + 1, b1, b1)) return;
-        }
-    }
-}
-
 // dense mat-vec with the block-Thomas epilogues; one wave per row, eight 512-byte requests per wave in flight
 //   mode 0 (forward):  out[r] = rhs[r] - l[r] * sum_c M[r][c] a[c]
 //   mode 1 (backward): out[r] = x_j[r] = sum_c M[r][c] a[c], where a = y_j - U_j x_{j+1} was left behind by the
@@ -803,8 +639,6 @@ void nk2d_precond_free(nk2d_ctx* c) {
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (pc->SINV32) (void)hipFree(pc->SINV32);
-    if (pc->SUBST_SYNC) (void)hipFree(pc->SUBST_SYNC);
-    if (pc->hSUBST) (void)hipHostFree(pc->hSUBST);
     delete pc;
     c->precond = nullptr;
 }
@@ -855,7 +689,7 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
         }
         NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * cap * mm));
         NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * cap * PC_NB * pc->m));
-        NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * 2 * cap * pc->nb * pc->m));   // YV, then ZV (k_pc_subst)
+        NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * cap * pc->nb * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * cap * pc->nb * pc->m));
     }
     for (int tau = 0; tau < pc->nt; ++tau) {
@@ -936,61 +770,6 @@ int precond_substitute(nk2d_ctx* c, int sys0, int nsys) {
     const dim3 blk(256), grd((m + 3) / 4, nsys);
     // even m (16-byte aligned rows) and a vector that fits the LDS staging: the wide kernel
     const bool wide = !c->pc_valu && (m % 2 == 0) && m <= PC_GEMV_XMAX;
-    // ---- the whole substitution in one launch (k_pc_subst) where the systems' workgroups are resident together
-    bool one_launch = wide && !pc->fp32 && c->pc_one_launch && m <= 64 * 2 * PC_GEMV_CHUNK && nb >= 2;
-    constexpr int SUBST_NT = 256;
-    const int nwg_sys = (m + SUBST_NT / 64 - 1) / (SUBST_NT / 64);
-    int sets = 3;
-    if (one_launch) {
-        // three register sets (226 registers, two waves a SIMD) where the systems' workgroups fit the chip like that, two sets
-        // (three or more waves a SIMD) where they do not; option pc_one_launch 2 / 3 forces the sets
-        hipDeviceProp_t prop;
-        NK2D_CHECK(c, hipGetDeviceProperties(&prop, c->dev));
-        int per_cu3 = 0, per_cu2 = 0;
-        NK2D_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, k_pc_subst<SUBST_NT, 3>, SUBST_NT, 0));
-        NK2D_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k_pc_subst<SUBST_NT, 2>, SUBST_NT, 0));
-        const long long need = (long long)nwg_sys * nsys;
-        const bool fit3 = (long long)per_cu3 * prop.multiProcessorCount >= need, fit2 = (long long)per_cu2 * prop.multiProcessorCount >= need;
-        sets = (c->pc_one_launch == 2) ? 2 : ((c->pc_one_launch == 3 || fit3) ? 3 : 2);
-        one_launch = (sets == 3) ? fit3 : fit2;
-    }
-    if (one_launch) {
-        // "no element is the poison" is the consumers' signal: both vector sets start as the poison
-        double* zv = pc->YV + ((size_t)pc->cap_sys + sys0) * vstride;
-        NK2D_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)yv, (int)PC_POISON_WORD, (size_t)nsys * vstride * 2, nk2d_s(c)));
-        NK2D_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)zv, (int)PC_POISON_WORD, (size_t)nsys * vstride * 2, nk2d_s(c)));
-        for (int sys = 0; sys < nsys; ++sys)
-            NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
-                                         hipMemcpyDeviceToDevice, nk2d_s(c)));
-        if (!pc->SUBST_SYNC) {
-            NK2D_CHECK(c, hipMalloc((void**)&pc->SUBST_SYNC, 256));
-            NK2D_CHECK(c, hipHostMalloc((void**)&pc->hSUBST, 64));
-        }
-        NK2D_CHECK(c, hipMemsetAsync(pc->SUBST_SYNC, 0, 256, nk2d_s(c)));
-        PcSubstArgs SA;
-        SA.sinv = sinv; SA.yv = yv; SA.zv = zv; SA.xv = xv; SA.mstride = mstride; SA.vstride = vstride;
-        SA.abort_flag = (int*)pc->SUBST_SYNC;
-        SA.status = SA.abort_flag + 32;
-        SA.spin_ticks = (long long)(c->barrier_timeout_ms * 1.0e5);
-        struct Turn {
-            int waves;
-            explicit Turn(int w) : waves(w) { nk2d_turn_take(waves); }
-            ~Turn() { nk2d_turn_give(waves); }
-        } turn((SUBST_NT / 64) * nwg_sys * nsys);
-        if (sets == 3)
-            hipLaunchKernelGGL((k_pc_subst<SUBST_NT, 3>), dim3(nwg_sys, nsys), dim3(SUBST_NT), 0, nk2d_s(c), D, SA);
-        else
-            hipLaunchKernelGGL((k_pc_subst<SUBST_NT, 2>), dim3(nwg_sys, nsys), dim3(SUBST_NT), 0, nk2d_s(c), D, SA);
-        NK2D_CHECK(c, hipGetLastError());
-        NK2D_CHECK(c, hipMemcpyAsync(pc->hSUBST, SA.status, sizeof(int), hipMemcpyDeviceToHost, nk2d_s(c)));
-        NK2D_CHECK(c, hipStreamSynchronize(nk2d_s(c)));
-        if (*(int*)pc->hSUBST == 0) {
-            c->pc_one_launch_applies++;
-            return 0;
-        }
-        return nk2d_fail(c, "preconditioner: the one-launch block substitution ran over its time limit (a singular block -- NaN "
-                            "in the vectors -- or a co-tenant on the chip); option pc_one_launch 0 runs it as launches", -6);
-    }
     // y_0 = r_0
     for (int sys = 0; sys < nsys; ++sys)
         NK2D_CHECK(c, hipMemcpyAsync(yv + (size_t)sys * vstride, xv + (size_t)sys * vstride, sizeof(double) * m,
