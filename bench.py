@@ -823,6 +823,11 @@ def main():
     n = args.grid
     wl = None
     deadline = None
+    # the checkpoint trail as nk_driver.run keeps it: every file in program order on one writer thread, complete on disk
+    # when a solve returns -- i.e. inside every timed region (NK2D_ASYNC_TRAIL=0: written inside the call that asks for it)
+    from nk_ooc_amd import trail
+
+    trail.set_enabled(os.environ.get("NK2D_ASYNC_TRAIL", "1") != "0")
     try:
         progress(f"set-up of iage {n}x{n}")
         wl = Workload(n, local_rank, f"r{rank}", write_files=not args.no_files)
@@ -886,6 +891,9 @@ def main():
                                 "module per GPU, Krylov iterations of KrylovSolver.solve with the "
                                 "NetCDF3/JSON checkpoint trail" + (" disabled" if args.no_files else ""),
                     "grid": [n, n],
+                    "checkpoint_trail": ("disabled" if args.no_files else
+                                         ("in program order on one writer thread, on disk when the solve returns (inside the "
+                                          "timed region)" if trail.TRAIL.enabled else "written inside the call that asks for it")),
                     "tracer_modules_per_gpu": 1,
                     "krylov_iterations": args.steps,
                     "untimed_iterations_until_the_schedule_cache_was_allocated": extra_warm,

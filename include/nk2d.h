@@ -150,6 +150,13 @@ int nk2d_vec_alloc(nk2d_ctx* ctx, nk2d_vec* out);
 int nk2d_vec_free(nk2d_ctx* ctx, nk2d_vec v);
 int nk2d_vec_upload(nk2d_ctx* ctx, nk2d_vec v, const double* host);   /* [tc][nz][ny] */
 int nk2d_vec_download(nk2d_ctx* ctx, nk2d_vec v, double* host);
+/* The same in two halves, for a caller that writes vector files on a thread of its own (what the reference does inside
+ * ModelStateBase.dump, nk_ooc/model_state_base.py:93-111, here behind the next forward year): `begin` queues the copy
+ * into a pinned buffer of the download's own on the context's stream and returns at once (later work on the stream,
+ * including changes of v, is ordered behind it); `end` -- on any host thread -- waits for that copy alone and fills
+ * host [tc][nz][ny] (NULL: only releases the ticket).  Every ticket must be ended once, before nk2d_destroy. */
+int nk2d_vec_download_begin(nk2d_ctx* ctx, nk2d_vec v, void** ticket);
+int nk2d_vec_download_end(nk2d_ctx* ctx, void* ticket, double* host);
 int nk2d_vec_copy(nk2d_ctx* ctx, nk2d_vec dst, nk2d_vec src);
 int nk2d_vec_zero(nk2d_ctx* ctx, nk2d_vec v);
 
@@ -361,6 +368,10 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    up: the year is rerun by launches), "stream_prof_0..11" (microseconds per workgroup waiting for commands / executing /
    waiting for neighbours, commands, and per kind of command).  NK2D_STREAM_RELAY=1 in the environment: commands through
    pinned host memory and a relay wave instead of written over the large BAR),
+   "stream_two_waves" (default 1; before the context's first year: phosphorus from five levels per lane takes the flavour of
+   the resident kernel that fits two waves to a SIMD -- 256 registers, the rest in scratch memory -- where that lets every
+   (tracer, ypos) column be resident instead of several rounds of columns per command, 416 x 416: 1 248 columns; 2: wherever
+   that flavour exists; 0: never.  Counters "stream_two_waves_kernel", "stream_columns_per_workgroup"),
    "device_ctl" (only 0: rounds 1 - 3 had device-side controllers 1, 2, 3; they lost to the command stream and are gone),
    "spec_bias" (default 1: what the host queues behind a Newton iteration it has not judged yet -- the next iteration, or the
    error estimate when the predicted convergence test value is below this many tolerances; never a decision; measured flat),
@@ -384,7 +395,9 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    column -- the three stages and the complex system on waves of their own; 2 a pair of waves per column -- stages and
    real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
    context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto),
-   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "sweep_wpb",
+   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "pc_fused" (1, default: a panel step of the
+   preconditioner's Gauss-Jordan inversions is one launch that inverts the pivot block while its tile is on its way; 0: the
+   two launches of rounds 1 - 3, the same bits), "sweep_wpb",
    (closed experiments removed in round 4: "xcd_map", "prefactor" -- profiles/r03_prefactor holds their measurements),
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" (the one-launch frozen year, see nk2d_get_counter),

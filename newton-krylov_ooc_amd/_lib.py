@@ -102,6 +102,8 @@ SIGNATURES = {
     "nk2d_vec_free": (_ci, [_vp, _vp]),
     "nk2d_vec_upload": (_ci, [_vp, _vp, c_double_p]),
     "nk2d_vec_download": (_ci, [_vp, _vp, c_double_p]),
+    "nk2d_vec_download_begin": (_ci, [_vp, _vp, ctypes.POINTER(ctypes.c_void_p)]),
+    "nk2d_vec_download_end": (_ci, [_vp, _vp, c_double_p]),
     "nk2d_vec_copy": (_ci, [_vp, _vp, _vp]),
     "nk2d_vec_zero": (_ci, [_vp, _vp]),
     "nk2d_tend": (_ci, [_vp, _d, _vp, _vp]),

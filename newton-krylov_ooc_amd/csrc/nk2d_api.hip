@@ -51,6 +51,35 @@ int stage_out(nk2d_ctx* c, double* host, size_t n) {
     return 0;
 }
 
+}  // namespace
+
+// staging pairs of the two-half downloads (nk2d_vec_download_begin / _end)
+struct nk2d_download {
+    double* dev = nullptr;     // host-layout copy on the device
+    double* host = nullptr;    // pinned
+    hipEvent_t done = nullptr; // behind the copy into `host`
+    size_t n = 0;
+};
+struct nk2d_download_pool {
+    std::mutex m;
+    std::vector<nk2d_download*> all, idle;
+};
+
+namespace {
+
+void download_pool_free(nk2d_ctx* c) {
+    if (!c->dl_pool) return;
+    for (nk2d_download* t : c->dl_pool->all) {
+        (void)hipEventSynchronize(t->done);
+        (void)hipEventDestroy(t->done);
+        (void)hipFree(t->dev);
+        (void)hipHostFree(t->host);
+        delete t;
+    }
+    delete c->dl_pool;
+    c->dl_pool = nullptr;
+}
+
 // host row-major [nrows][ncols] -> packed device plane of ncols columns
 int upload_plane(nk2d_ctx* c, const double* host, int nrows, int ncols, double* dst, double fill = 0.0) {
     const size_t n = (size_t)nrows * ncols;
@@ -137,6 +166,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
+    if (key == "pc_fused") { c->pc_fused = value != 0.0; return 0; }
     if (key == "pc_fp32") { c->pc_fp32 = value != 0.0; return 0; }
     if (key == "pc_refine") {
         if (!(value >= 0.0 && value <= 4.0)) return nk2d_fail(c, "nk2d_set_option: pc_refine must be 0 .. 4");
@@ -152,6 +182,12 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
     if (key == "frozen_cache_after") { c->frozen_cache_after = (int)value; return 0; }
     if (key == "spec_bias") { c->spec_bias = value > 0.0 ? value : 1.0; return 0; }
     if (key == "stream_years") { c->stream_years = (int)value; c->stream_lost = 0; return 0; }
+    if (key == "stream_two_waves") {
+        // (decides the shape of the resident kernel: taken before the context's first year as a command stream)
+        if (c->strm) return nk2d_fail(c, "nk2d_set_option: stream_two_waves must be set before the first year of the context");
+        c->stream_two_waves = (int)value;
+        return 0;
+    }
     if (key == "frozen_wpb") { c->frozen_wpb = (int)value; return 0; }
     if (key == "frozen_alloc_async") { c->frozen_alloc_async = value != 0.0; return 0; }
     if (key == "frozen_persistent_max_e") { c->frozen_persistent_max_e = (int)value; return 0; }
@@ -515,6 +551,8 @@ static int create_impl(nk2d_ctx* c, const nk2d_desc* desc) {
     c->frozen_by_column = 1;
     c->strm = nullptr;
     c->spec_bias = 1.0;
+    // (on: taken only where it lets more columns be resident, see stream_alloc)
+    c->stream_two_waves = std::getenv("NK2D_STREAM_TWO_WAVES") ? std::atoi(std::getenv("NK2D_STREAM_TWO_WAVES")) : 1;
     c->stream_years = 1;      // free-running years as command streams where eligible (bit 2: frozen years too)
     c->stream_on = 0;
     c->stream_lost = 0;
@@ -620,8 +658,10 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->STAGE = nullptr;
     c->hSTAGE = nullptr;
     c->stage_elems = 0;
+    c->dl_pool = nullptr;
     c->precond = nullptr;
     c->pc_valu = 0;
+    c->pc_fused = 0;
     c->pc_fp32 = 0;
     c->pc_refine = 1;
     c->st = nk2d_stats();
@@ -689,6 +729,7 @@ extern "C" void nk2d_destroy(nk2d_ctx* c) {
     if (c->hPARTB) (void)hipHostFree(c->hPARTB);
     if (c->hPARTC) (void)hipHostFree(c->hPARTC);
     if (c->hSTAGE) (void)hipHostFree(c->hSTAGE);
+    download_pool_free(c);
     if (c->hRCOEF) (void)hipHostFree(c->hRCOEF);
     if (c->snap_ready) {
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->snap_ev[i]);
@@ -802,6 +843,55 @@ extern "C" int nk2d_vec_download(nk2d_ctx* c, nk2d_vec v, double* host) {
     NK2D_TRY(ensure_stage(c, n));
     NK2D_TRY(nk2d_k_unpack_state(c, (const double*)v, c->STAGE));
     return stage_out(c, host, n);
+}
+// A download in two halves, for a caller that writes the values to a file on a thread of its own (the checkpoint trail,
+// newton-krylov_ooc_amd/trail.py): `begin` queues the layout conversion and the copy into a pinned buffer of the
+// download's OWN behind whatever the context's stream holds and returns at once -- what is launched on the stream
+// afterwards (the next forward year) does not wait for the host, and may change `v`: the conversion has read it by then in
+// stream order --; `end`, on ANY host thread, waits for that copy alone (an event, not the stream) and hands the values
+// out.  `end` touches nothing of the context but the pool of staging pairs, under the pool's mutex.
+extern "C" int nk2d_vec_download_begin(nk2d_ctx* c, nk2d_vec v, void** ticket) {
+    if (!ticket) return nk2d_fail(c, "nk2d_vec_download_begin: null ticket");
+    NK2D_CHECK(c, hipSetDevice(c->dev));
+    const size_t n = (size_t)c->tc * c->nz * c->ny;
+    if (!c->dl_pool) c->dl_pool = new nk2d_download_pool();
+    nk2d_download* t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->dl_pool->m);
+        if (!c->dl_pool->idle.empty()) { t = c->dl_pool->idle.back(); c->dl_pool->idle.pop_back(); }
+    }
+    if (!t) {
+        t = new nk2d_download();
+        hipError_t rc = hipMalloc((void**)&t->dev, sizeof(double) * n);
+        if (rc == hipSuccess) rc = hipHostMalloc((void**)&t->host, sizeof(double) * n);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&t->done, hipEventDisableTiming);
+        if (rc != hipSuccess) {
+            if (t->dev) (void)hipFree(t->dev);
+            if (t->host) (void)hipHostFree(t->host);
+            delete t;
+            NK2D_CHECK(c, rc);
+        }
+        t->n = n;
+        std::lock_guard<std::mutex> lk(c->dl_pool->m);
+        c->dl_pool->all.push_back(t);
+    }
+    NK2D_TRY(nk2d_k_unpack_state(c, (const double*)v, t->dev));
+    NK2D_CHECK(c, hipMemcpyAsync(t->host, t->dev, sizeof(double) * n, hipMemcpyDeviceToHost, nk2d_s(c)));
+    NK2D_CHECK(c, hipEventRecord(t->done, nk2d_s(c)));
+    *ticket = t;
+    return 0;
+}
+extern "C" int nk2d_vec_download_end(nk2d_ctx* c, void* ticket, double* host) {
+    nk2d_download* t = (nk2d_download*)ticket;
+    if (!c || !c->dl_pool || !t) return -2;
+    (void)hipSetDevice(c->dev);
+    const hipError_t rc = hipEventSynchronize(t->done);
+    if (rc == hipSuccess && host) std::memcpy(host, t->host, sizeof(double) * t->n);
+    {
+        std::lock_guard<std::mutex> lk(c->dl_pool->m);
+        c->dl_pool->idle.push_back(t);
+    }
+    return rc == hipSuccess ? 0 : -1;
 }
 extern "C" int nk2d_vec_copy(nk2d_ctx* c, nk2d_vec dst, nk2d_vec src) {
     NK2D_CHECK(c, hipSetDevice(c->dev));
@@ -953,6 +1043,8 @@ extern "C" int nk2d_get_counter(nk2d_ctx* c, const char* name, int64_t* out) {
     else if (key == "stream_commands") v = c->stream_cmds;
     else if (key == "stream_launches") v = c->stream_launches;
     else if (key == "stream_timeouts") v = c->stream_timeouts;
+    else if (key == "stream_columns_per_workgroup") v = nk2d_stream_columns_per_workgroup(c);
+    else if (key == "stream_two_waves_kernel") v = nk2d_stream_two_waves(c);
     else if (key.rfind("stream_prof_", 0) == 0) {
         // stream_prof_0 .. stream_prof_11: see nk2d_stream_profile
         double pr[12];

@@ -45,6 +45,7 @@ struct nk2d_ctx {
     // as commands, workgroups handing over to their lateral neighbours instead of meeting at launch boundaries
     struct nk2d_stream_state* strm;
     int stream_years;      // option "stream_years": 1 = forward years of eligible contexts run as command streams
+    int stream_two_waves;  // option "stream_two_waves": the 256-register flavour of the kernel where it lets every column be resident
     int stream_on;         // set by the integrator for the span of a year that may run as a command stream
     int stream_lost;       // years in a row whose kernel gave up (two: the context stops trying)
     int64_t stream_cmds, stream_launches, stream_timeouts, stream_years_run;   // counters (nk2d_get_counter)
@@ -165,6 +166,8 @@ struct nk2d_ctx {
     double* STAGE;
     double* hSTAGE;  // pinned host twin of STAGE
     size_t stage_elems;
+    // downloads in two halves (nk2d_vec_download_begin / _end): staging pairs of their own, kept for reuse
+    struct nk2d_download_pool* dl_pool;
     // region scalars staged on device for the algebra kernels
     double* RCOEF;
     double* hRCOEF;  // pinned host twin of RCOEF
@@ -177,6 +180,7 @@ struct nk2d_ctx {
     double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
+    int pc_fused;  // 1 (default): a panel step of the Gauss-Jordan inversions is ONE launch (k_pc_gj_step); 0: two (k_pc_gj_rows + k_pc_gj_update_mfma), for A/B runs -- the same bits
     int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
     int pc_fp32;   // 1: Schur inverses of the linear modules' preconditioner stored in single precision (option "pc_fp32")
     int pc_refine; // ... with this many refinement steps per apply against the exact operator (option "pc_refine", default 1)
@@ -250,6 +254,8 @@ void nk2d_turn_give(int waves);
 #define NK2D_RC_STREAM_LOST 17   /* the command-stream kernel gave up (a wait timed out): the caller reruns the year by launches */
 int nk2d_stream_pause(nk2d_ctx* c);
 bool nk2d_stream_running(const nk2d_ctx* c);
+int nk2d_stream_columns_per_workgroup(const nk2d_ctx* c);
+int nk2d_stream_two_waves(const nk2d_ctx* c);
 int nk2d_stream_eligible(const nk2d_ctx* c);
 int nk2d_stream_ready(nk2d_ctx* c);     // buffers of the command stream in place (first use)
 int nk2d_stream_end(nk2d_ctx* c);       // ends the kernel, waits for it; NK2D_RC_STREAM_LOST if it had given up on the way

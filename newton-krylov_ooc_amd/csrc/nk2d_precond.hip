@@ -372,6 +372,138 @@ __global__ void __launch_bounds__(256) k_pc_gj_update_mfma(int m, int p0, int nb
             }
 }
 
+// One panel step of the Gauss-Jordan inversion in ONE launch (option "pc_fused", default): k_pc_gj_rows + k_pc_gj_update_mfma
+// fused.  The two-launch step is bound by what is sequential in it -- every workgroup of k_pc_gj_rows inverts the 32 x 32
+// pivot block by itself, 32 dependent eliminations with a barrier each: 13 of its 16.7 us at m = 1248 --, after which
+// k_pc_gj_update streams the matrix once more (15 us).  Here a workgroup owns a 64 x 64 tile of the result as in the
+// update: it REQUESTS everything it needs first -- its tile, its 64 x 32 piece of the pivot columns, its 32 x 64 piece of the
+// pivot rows, the pivot block --, inverts the pivot block while those loads are in flight, scales its piece of the pivot
+// rows itself (32 fused multiply-adds per entry, the order of k_pc_gj_rows) and applies the rank-32 update on the matrix
+// cores.  Same operations in the same order as the two launches: the same bits (tests/test_gpu_kernels.py).
+__global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ dst) {
+    __shared__ double ab[2][PC_NB][PC_NB + 1];   // pivot block, ping-pong: one barrier per pivot
+    __shared__ double sf[64][PC_NB + 1];         // src[i, pb]
+    __shared__ double sraw[PC_NB][64 + 1];       // src[pb, c]
+    __shared__ double sr[PC_NB][64 + 1];         // R[:, c]
+    const int tr = blockIdx.z;
+    const size_t base = (size_t)tr * m * m;
+    const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int ib = (wv >> 1) * 32, jb = (wv & 1) * 32;
+    const int lr16 = l >> 4, lc16 = l & 15;
+    // ---- every request first
+    const int r0 = tid / PC_NB, cc = tid - r0 * PC_NB;
+    double mine[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 8 * q;
+        mine[q] = (r < nb && cc < nb) ? src[base + (size_t)(p0 + r) * m + (p0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+    }
+    double lf[8], lrw[8], tile[2][2][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int ii = idx / PC_NB, q = idx - ii * PC_NB;
+        const int i = i0 + ii;
+        lf[k] = (i < m && q < nb) ? src[base + (size_t)i * m + p0 + q] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int q = idx / 64, c = c0 + (idx - q * 64);
+        lrw[k] = (c < m && q < nb) ? src[base + (size_t)(p0 + q) * m + c] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
+                tile[ti][tj][reg] = (i < m && c < m) ? src[base + (size_t)i * m + c] : 0.0;
+            }
+    // ---- the pivot block's inverse (k_pc_gj_rows' elimination), while the rest is on its way
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab[0][r0 + 8 * q][cc] = mine[q];
+    __syncthreads();
+    int cur = 0;
+    for (int pp = 0; pp < nb; ++pp) {
+        double (*a)[PC_NB + 1] = ab[cur];
+        const double piv = 1.0 / a[pp][pp];
+        const double prow = ((cc == pp) ? 1.0 : a[pp][cc]) * piv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 8 * q;
+            const double f = a[r][pp];
+            const double old = (cc == pp) ? 0.0 : mine[q];
+            mine[q] = (r == pp) ? prow : __builtin_fma(-f, prow, old);
+            ab[1 - cur][r][cc] = mine[q];
+        }
+        cur = 1 - cur;
+        __syncthreads();
+    }
+    double (*pinv)[PC_NB + 1] = ab[cur];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        sf[idx / PC_NB][idx % PC_NB] = lf[k];
+        sraw[idx / 64][idx % 64] = lrw[k];
+    }
+    __syncthreads();
+    // ---- this tile's piece of the scaled pivot rows: R[p][c] = sum_q Pinv[p][q] src[p0 + q][c], the pivot columns replaced by Pinv
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int p = idx / 64, ccc = idx - p * 64;
+        const int c = c0 + ccc;
+        double val;
+        if (c >= p0 && c < p0 + nb) {
+            val = pinv[p][c - p0];
+        } else {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < PC_NB; ++q) acc = __builtin_fma(pinv[p][q], sraw[q][ccc], acc);   // (zeros beyond nb)
+            val = acc;
+        }
+        sr[p][ccc] = (p < nb) ? val : 0.0;
+    }
+    __syncthreads();
+    // ---- the rank-nb update (k_pc_gj_update_mfma)
+    pc_v4d acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (pc_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < PC_NB / 4; ++ks) {
+        const int k = 4 * ks + lr16;
+        const double a0 = sf[ib + lc16][k], a1 = sf[ib + 16 + lc16][k];
+        const double b0 = sr[k][jb + lc16], b1 = sr[k][jb + 16 + lc16];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
+                if (i >= m || c >= m) continue;
+                double val;
+                if (i >= p0 && i < p0 + nb) {
+                    val = sr[i - p0][c - c0];
+                } else {
+                    const bool pivot_col = c >= p0 && c < p0 + nb;
+                    val = (pivot_col ? 0.0 : tile[ti][tj][reg]) - acc[ti][tj][reg];
+                }
+                dst[base + (size_t)i * m + c] = val;
+            }
+}
+
 // Dense mat-vec of the block substitution for even m: 16-byte loads, the whole row of a wave requested at once
 // (up to 10 x 1 KB per wave in flight), the vector staged once per workgroup in LDS instead of being re-read
 // through L1 by every wave.  Same epilogues as k_pc_gemv below.
@@ -541,6 +673,26 @@ __global__ void k_pc_residual(PcDev P, const double* __restrict__ rhs, const dou
     res[base + r] = rhs[base + r] - ax;
 }
 
+// res = rhs - A x for ONE shifted system of mode 1, A = scale J - sigma[sys] I with the tracers of a column in one block (the
+// rows of k_pc_schur's shifted_entry and the lateral couplings); rhs, x, res: that system's [nb][m]; one thread per unknown
+__global__ void k_pc_residual_shift(PcDev P, int sys, const double* __restrict__ rhs, const double* __restrict__ x,
+                                    double* __restrict__ res) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (r >= P.m) return;
+    const int trr = r / P.nz, k = r - trr * P.nz;
+    const size_t base = (size_t)j * P.m;
+    const double* xj = x + base;
+    double ax = shifted_entry(P, sys, j, trr, k, trr, k) * xj[r];
+    if (k > 0) ax += shifted_entry(P, sys, j, trr, k, trr, k - 1) * xj[r - 1];
+    if (k < P.nz - 1) ax += shifted_entry(P, sys, j, trr, k, trr, k + 1) * xj[r + 1];
+    for (int trc = 0; trc < P.tc; ++trc)
+        if (trc != trr) ax += shifted_entry(P, sys, j, trr, k, trc, k) * xj[trc * P.nz + k];
+    if (j > 0) ax += lat_l(P, trr, k, j) * x[base - P.m + r];
+    if (j < P.nb - 1) ax += lat_u(P, trr, k, j) * x[base + P.m + r];
+    res[base + r] = rhs[base + r] - ax;
+}
+
 __global__ void k_pc_add(double* __restrict__ x, const double* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = x[i] + y[i];
@@ -653,7 +805,8 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
     const int m = nslot * c->nz;
     // gigabytes of Schur inverses: keep the allocation when the next factorisation fits in it (the
     // phosphorus preconditioner factorises three shifted systems per Newton iteration)
-    const int want32 = (c->pc_fp32 && mode == 0) ? 1 : 0;
+    // (option "pc_fp32": single precision storage of the explicit inverses, for the shifted systems of mode 1 too)
+    const int want32 = c->pc_fp32 ? 1 : 0;
     const bool reuse = pc && pc->mode == mode && pc->nt == nt && pc->m == m && pc->nb == c->ny && pc->cap_sys >= nsys &&
                        pc->fp32 == want32;
     if (!reuse) {
@@ -721,6 +874,11 @@ int precond_eliminate(nk2d_ctx* c) {
             const int nbk = std::min(PC_NB, m - p0);
             const double* from = pc->BUF + (size_t)src * nsys * mm;
             double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
+            if (c->pc_fused && !c->pc_valu) {
+                hipLaunchKernelGGL(k_pc_gj_step, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, nk2d_s(c), m, p0, nbk, from, to);
+                src = 1 - src;
+                continue;
+            }
             hipLaunchKernelGGL(k_pc_gj_rows, dim3((m + 255) / 256, nbk, nsys), dim3(256), 0, nk2d_s(c), m, p0, nbk, from,
                                pc->ROWS);
             if (c->pc_valu)
@@ -861,7 +1019,25 @@ extern "C" int nk2d_shift_solve(nk2d_ctx* c, int32_t i, nk2d_vec v, nk2d_vec out
     const size_t vstride = (size_t)pc->nb * pc->m;
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_rhs_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nz, pc->m, (const double*)v, pc->XV + (size_t)i * vstride));
+    if (pc->fp32)      // (the right-hand sides are kept for the residual)
+        NK2D_CHECK(c, hipMemcpyAsync(pc->RV + (size_t)i * vstride, pc->XV + (size_t)i * vstride, sizeof(double) * vstride,
+                                     hipMemcpyDeviceToDevice, nk2d_s(c)));
     NK2D_TRY(precond_substitute(c, i, 1));
+    if (pc->fp32) {
+        // single precision inverses: "pc_refine" corrections x += S32^-1 (rhs - A x) against the exact shifted operator, as in
+        // nk2d_precond_apply
+        const size_t nvec = (size_t)pc->nb * pc->m;
+        PcDev D = make_pcdev(c, pc);
+        double* xv = pc->XV + (size_t)i * vstride;
+        double* rv = pc->RV + (size_t)i * vstride;
+        double* x0 = pc->X0 + (size_t)i * vstride;
+        for (int it = 0; it < c->pc_refine; ++it) {
+            NK2D_CHECK(c, hipMemcpyAsync(x0, xv, sizeof(double) * nvec, hipMemcpyDeviceToDevice, nk2d_s(c)));
+            hipLaunchKernelGGL(k_pc_residual_shift, dim3((pc->m + 255) / 256, pc->nb, 1), dim3(256), 0, nk2d_s(c), D, (int)i, rv, x0, xv);
+            NK2D_TRY(precond_substitute(c, i, 1));
+            hipLaunchKernelGGL(k_pc_add, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, nk2d_s(c), xv, x0, nvec);
+        }
+    }
     NK2D_DISPATCH_E(c->E, hipLaunchKernelGGL(k_pc_result_all<EE>, dim3(nk2d_grid(c->ncol)), dim3(NK2D_BLOCK), 0, nk2d_s(c),
                                               c->ncol, c->ny, c->nz, pc->m, pc->XV + (size_t)i * vstride, (double*)out));
     NK2D_CHECK(c, hipGetLastError());

@@ -64,7 +64,7 @@ __device__ __forceinline__ void stream_relay(const StreamArgs& A, int lane) {
 }
 
 template <int E, int KIND>
-__global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
+__device__ __forceinline__ void stream_body(const DevP& P, const StreamArgs& A) {
     __shared__ int lds_ok;
     __shared__ StreamCmd cmd;
     const int lane = threadIdx.x & 63;
@@ -343,6 +343,19 @@ __global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
     if (wg == 0 && threadIdx.x == 0) A.out[1] = (double)seq;
 }
 
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) k_stream(DevP P, StreamArgs A) {
+    stream_body<E, KIND>(P, A);
+}
+// The same within 256 registers, so that a SIMD holds TWO waves (option "stream_two_waves"; phosphorus from five levels per
+// lane, where a wave of k_stream holds 280 - 390 registers and the chip therefore 1 024 waves: the 1 248 (tracer, ypos)
+// columns of phosphorus at 416 x 416 are then two rounds per command on half as many workgroups).  What does not fit the
+// registers lives in scratch memory.
+template <int E, int KIND>
+__global__ void __launch_bounds__(NK2D_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stream_w2(DevP P, StreamArgs A) {
+    stream_body<E, KIND>(P, A);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------------------
@@ -362,6 +375,7 @@ struct nk2d_stream_state {
     bool coef_lds = true;                   // the static coefficients of a workgroup's columns in LDS (NK2D_STREAM_COEF_LDS=0: not)
     bool direct = false;                    // the host writes its commands straight into d_ring (large BAR): no relay hop
     int nwg = 0, cpw = 1, nw = 1;
+    bool two_waves = false;                 // k_stream_w2 (two waves to a SIMD) instead of k_stream
     int turn_waves = 0;                     // what the running kernel holds of the process-wide turn
     int64_t launches = 0;
     // pinned buffers for the norm partials, handed out in turn: the controller names its buffers (hPART, hPARTB, ...) and
@@ -404,6 +418,10 @@ void nk2d_turn_give(int waves) {
 }
 
 bool nk2d_stream_running(const nk2d_ctx* c) { return c->strm && c->strm->running; }
+// the shape of the context's resident kernel (0 before its first year as a command stream): ypos columns per workgroup, and
+// whether it is the flavour with two waves to a SIMD
+int nk2d_stream_columns_per_workgroup(const nk2d_ctx* c) { return c->strm ? c->strm->cpw : 0; }
+int nk2d_stream_two_waves(const nk2d_ctx* c) { return (c->strm && c->strm->two_waves) ? 1 : 0; }
 unsigned nk2d_stream_last_seq(const nk2d_ctx* c) { return c->strm ? c->strm->seq : 0u; }
 
 // which contexts run their years as command streams: every module kind, host-side decisions (no norm hook: a sharded module's
@@ -413,21 +431,30 @@ int nk2d_stream_eligible(const nk2d_ctx* c) {
     return 1;
 }
 
+// (the two-waves flavour is instantiated where it can matter: state-dependent sources from five levels per lane)
 template <int E, int KIND>
-static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes) {
-    if (max_blocks) {
-        int nb = 0;
-        hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<E, KIND>, (int)block.x, lds_bytes);
-        if (rc != hipSuccess) return rc;
-        *max_blocks = nb;
-        return hipSuccess;
+constexpr bool kStreamHasTwoWaves = KIND == 1 && E >= 5;
+
+template <int E, int KIND>
+static hipError_t stream_launch_one(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes,
+                                    bool two_waves) {
+    if constexpr (kStreamHasTwoWaves<E, KIND>) {
+        if (two_waves) {
+            if (max_blocks) return hipOccupancyMaxActiveBlocksPerMultiprocessor(max_blocks, k_stream_w2<E, KIND>, (int)block.x, lds_bytes);
+            hipLaunchKernelGGL((k_stream_w2<E, KIND>), grid, block, lds_bytes, c->stream_, P, A);
+            return hipGetLastError();
+        }
+    } else if (two_waves) {
+        return hipErrorInvalidValue;
     }
+    if (max_blocks) return hipOccupancyMaxActiveBlocksPerMultiprocessor(max_blocks, k_stream<E, KIND>, (int)block.x, lds_bytes);
     hipLaunchKernelGGL((k_stream<E, KIND>), grid, block, lds_bytes, c->stream_, P, A);
     return hipGetLastError();
 }
-static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes) {
+static hipError_t stream_launch(nk2d_ctx* c, dim3 grid, dim3 block, DevP& P, StreamArgs& A, int* max_blocks, size_t lds_bytes,
+                                bool two_waves) {
     hipError_t rc = hipErrorInvalidValue;
-    NK2D_DISPATCH_EK(c->E, c->kind, rc = (stream_launch_one<EE, KK>(c, grid, block, P, A, max_blocks, lds_bytes)));
+    NK2D_DISPATCH_EK(c->E, c->kind, rc = (stream_launch_one<EE, KK>(c, grid, block, P, A, max_blocks, lds_bytes, two_waves)));
     return rc;
 }
 // dynamic shared memory of a launch whose workgroups own cpw ypos columns each
@@ -447,15 +474,30 @@ static int stream_alloc(nk2d_ctx* c) {
     NK2D_CHECK(c, hipGetDeviceProperties(&prop, c->dev));
     S->coef_lds = std::getenv("NK2D_STREAM_COEF_LDS") == nullptr || std::atoi(std::getenv("NK2D_STREAM_COEF_LDS")) != 0;
     // (the columns per workgroup and the LDS they need depend on each other: one column first, more until the grid fits)
-    for (S->cpw = 1;; ++S->cpw) {
-        int per_cu = 0;
-        NK2D_CHECK(c, stream_launch(c, dim3(1), dim3(64 * S->nw), P, A, &per_cu, stream_lds_bytes(c, S->cpw, S->coef_lds)));
-        const int capacity = per_cu * prop.multiProcessorCount - 1;     // (one workgroup is the relay's)
-        S->nwg = (c->ny + S->cpw - 1) / S->cpw;
-        if (capacity >= S->nwg) break;
-        if (S->cpw >= c->ny) {
-            if (S->coef_lds) { S->coef_lds = false; S->cpw = 0; continue; }     // (without the LDS copy, then)
-            return nk2d_fail(c, "command stream: the kernel does not fit a compute unit");
+    auto columns_per_workgroup = [&](bool two_waves, bool& coef_lds, int& cpw, int& nwg) -> int {
+        for (cpw = 1;; ++cpw) {
+            int per_cu = 0;
+            NK2D_CHECK(c, stream_launch(c, dim3(1), dim3(64 * S->nw), P, A, &per_cu, stream_lds_bytes(c, cpw, coef_lds), two_waves));
+            const int capacity = per_cu * prop.multiProcessorCount - 1;     // (one workgroup is the relay's)
+            nwg = (c->ny + cpw - 1) / cpw;
+            if (capacity >= nwg) return 0;
+            if (cpw >= c->ny) {
+                if (coef_lds) { coef_lds = false; cpw = 0; continue; }     // (without the LDS copy, then)
+                return nk2d_fail(c, "command stream: the kernel does not fit a compute unit");
+            }
+        }
+    };
+    NK2D_TRY(columns_per_workgroup(false, S->coef_lds, S->cpw, S->nwg));
+    // option "stream_two_waves": where the one-wave-per-SIMD kernel needs several rounds of columns per command and the flavour
+    // that fits two waves to a SIMD needs fewer, that one
+    // (measured, phosphorus 416 x 416: free-running year 0.728 -> 0.678 s, frozen year 0.374 -> 0.357 s, a Newton command 27.1 ->
+    // 19.8 us per workgroup -- profiles/r04_stream_two_waves_phosphorus.log; value 2 takes the flavour wherever it exists: tests)
+    if (c->stream_two_waves && c->kind == 1 && c->E >= 5 && (S->cpw > 1 || c->stream_two_waves >= 2)) {
+        bool coef2 = S->coef_lds;
+        int cpw2 = 0, nwg2 = 0;
+        NK2D_TRY(columns_per_workgroup(true, coef2, cpw2, nwg2));
+        if ((cpw2 < S->cpw || c->stream_two_waves >= 2) && cpw2 <= S->cpw && coef2 == S->coef_lds) {
+            S->two_waves = true; S->cpw = cpw2; S->nwg = nwg2;
         }
     }
     NK2D_CHECK(c, hipHostMalloc((void**)&S->h_ring, sizeof(unsigned long long) * NK2D_RING_SLOTS * NK2D_CMD_DWORDS));
@@ -554,7 +596,8 @@ static int stream_start(nk2d_ctx* c) {
     A.coef_lds = S->coef_lds ? 3 : 0;
     A.W = c->W;
     DevP P = make_devp(c);
-    const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr, stream_lds_bytes(c, S->cpw, S->coef_lds));
+    const hipError_t rc = stream_launch(c, dim3(S->nwg + 1), dim3(64 * S->nw), P, A, nullptr, stream_lds_bytes(c, S->cpw, S->coef_lds),
+                                        S->two_waves);
     if (rc != hipSuccess) {
         nk2d_turn_give(S->turn_waves);
         NK2D_CHECK(c, rc);

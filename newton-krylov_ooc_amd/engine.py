@@ -98,6 +98,34 @@ class DevVec:
         return res
 
 
+class PendingDownload:
+    """second half of ModuleEngine.download_begin; ended exactly once (by result(), or when dropped)"""
+
+    __slots__ = ("eng", "ticket")
+
+    def __init__(self, eng, ticket):
+        self.eng = eng
+        self.ticket = ticket
+
+    def result(self):
+        eng, ticket = self.eng, self.ticket
+        if ticket is None:
+            raise RuntimeError("download already taken")
+        self.ticket = None
+        host = np.empty(eng.shape)
+        if eng._handle is None:
+            raise RuntimeError("download: the engine was closed before its values were taken")
+        if eng._lib.nk2d_vec_download_end(eng._handle, ticket, _dp(host)) != 0:
+            raise RuntimeError("nk2d_vec_download_end: the copy to the host failed")
+        return host
+
+    def __del__(self):
+        eng, ticket = self.eng, self.ticket
+        self.ticket = None
+        if ticket is not None and eng is not None and eng._handle is not None:
+            eng._lib.nk2d_vec_download_end(eng._handle, ticket, None)
+
+
 class ModuleEngine:
     """HIP engine for one tracer module on one (depth, ypos) grid"""
 
@@ -236,6 +264,14 @@ class ModuleEngine:
         host = np.empty(self.shape)
         self._chk(self._lib.nk2d_vec_download(self._ctx, vec.ptr, _dp(host)))
         return host
+
+    def download_begin(self, vec):
+        """first half of a download (nk2d_vec_download_begin): the copy into a pinned buffer of its own is queued on the
+        engine's stream and this returns at once; `.result()` of what it returns -- on any thread -- waits for that copy
+        alone and gives the host array.  For the checkpoint trail's writer thread (trail.py)."""
+        ticket = ctypes.c_void_p()
+        self._chk(self._lib.nk2d_vec_download_begin(self._ctx, vec.ptr, ctypes.byref(ticket)))
+        return PendingDownload(self, ticket)
 
     def vec_tensor(self, vec):
         """zero-copy torch tensor over the HBM of a state vector (flat, the library's packed column layout): for collectives

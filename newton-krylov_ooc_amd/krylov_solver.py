@@ -12,8 +12,9 @@ Where it differs is the data flow.  The reference is out-of-core: every use of a
 vector re-opens its file (j+1 reads in Gram-Schmidt, j+1 and j+2 more in the two
 `lin_comb`s of each iteration).  Here the Arnoldi vectors V_0..V_j and the preconditioned
 products W_0..W_j are kept as device-resident `ModelState`s for the life of the solve;
-files are only written (at the reference's points), and read back only when a solve is
-resumed from its checkpoint.  Each iteration is then
+files are only written (at the reference's points and in the reference's order -- on the
+checkpoint trail's writer thread where the driver switched that on, `trail.py`), and read back
+only when a solve is resumed from its checkpoint.  Each iteration is then
 
     w_raw = J v_j        one perturbed forward year per tracer module (nk2d_comp_fcn)
     w     = M^-1 w_raw   streamed block-Thomas apply             (nk2d_precond_apply)
@@ -25,6 +26,7 @@ import logging
 
 import numpy as np
 
+from . import trail
 from .solver_base import SolverBase
 
 
@@ -166,4 +168,8 @@ class KrylovSolver(SolverBase):
                 logger.info("Krylov iteration limit reached")
                 break
             self._V[j + 1] = v_next.dump(self._fname("basis"), caller)
-        return approx.dump(res_fname, caller)
+        approx.dump(res_fname, caller)
+        # the solve's trail is complete on disk when it returns (inside a solve the files follow on the trail's writer
+        # thread while the next perturbed year runs: trail.py)
+        trail.flush()
+        return approx

@@ -24,6 +24,7 @@ import numpy as np
 
 from . import hist as hist_mod
 from . import ncio
+from . import trail
 from .engine import (PHOSPHORUS_PARAM_NAMES, Nk2dFrozenMismatch, Nk2dScheduleMismatch, forced_engine, iage_engine,
                      phosphorus_engine)
 from .limiter import scalef_for_bound
@@ -229,12 +230,14 @@ class ModelState:
     # ---- class-level set-up (py_driver_2d/model_state.py:44-65) -----------------------
     @classmethod
     def flush_files(cls):
-        """every history file asked for so far is on disk when this returns"""
+        """every file asked for so far -- history files, the checkpoint trail -- is on disk when this returns"""
         cls.hist_writer.wait()
+        trail.flush()
 
     @classmethod
     def reset_class(cls):
         cls.hist_writer.forget()
+        trail.flush()
         if cls._engines:
             for eng in cls._engines.values():
                 eng.close()
@@ -290,6 +293,8 @@ class ModelState:
         # file for a resumed run -- with a checksum of the values they belong to, verified against what the file holds now
         side = None
         if isinstance(fname, str):
+            if cached is None and fname not in ("zeros", "gen_init_iterate"):
+                trail.flush()       # (a file of this process' own trail may still be on its way to the disk)
             self._sched = self._sched_by_name.get(os.path.abspath(fname))
             if self._sched is None and cached is None and os.path.exists(sched_path(fname)):
                 with np.load(sched_path(fname)) as data:
@@ -360,20 +365,43 @@ class ModelState:
         cache = self._resident
         # whatever schedule was known under this name belonged to the values it held before
         self._sched_by_name.pop(os.path.abspath(fname), None)
-        if self.write_files and os.path.exists(sched_path(fname)):
-            os.remove(sched_path(fname))
+        if self.write_files:
+            side_file = sched_path(fname)
+
+            def drop_side_file():
+                if os.path.exists(side_file):
+                    os.remove(side_file)
+
+            trail.submit(drop_side_file)
         cache.pop(os.path.abspath(fname), None)
         cache[os.path.abspath(fname)] = [tms.vec.copy() for tms in self.tracer_modules]
         while len(cache) > self.RESIDENT_MAX:
             cache.pop(next(iter(cache)))
         if self.write_files:
-            tracer_vals = {}
-            for tms in self.tracer_modules:
-                host = tms.get_tracer_vals_all()
-                for ind, tracer_name in enumerate(tms.tracer_names):
-                    tracer_vals[tracer_name] = host[ind]
             history = ncio.history_stamp(f"{_class_name(self)}.dump", caller)
-            ncio.write_state_file(fname, [self.depth, self.ypos], tracer_vals, history)
+            axes = [self.depth, self.ypos]
+            names = [tms.tracer_names for tms in self.tracer_modules]
+            if trail.TRAIL.enabled and all(hasattr(tms.eng, "download_begin") for tms in self.tracer_modules):
+                # the trail's writer thread: the copies to the host are queued on the modules' streams behind what
+                # produced the values (and ahead of whatever changes them next), the thread waits for them and writes
+                pending = [tms.eng.download_begin(tms.vec) for tms in self.tracer_modules]
+
+                def write():
+                    tracer_vals = {}
+                    for module_names, download in zip(names, pending):
+                        host = download.result()
+                        for ind, tracer_name in enumerate(module_names):
+                            tracer_vals[tracer_name] = host[ind]
+                    ncio.write_state_file(fname, axes, tracer_vals, history)
+
+                trail.submit(write)
+            else:
+                tracer_vals = {}
+                for tms in self.tracer_modules:
+                    host = tms.get_tracer_vals_all()
+                    for ind, tracer_name in enumerate(tms.tracer_names):
+                        tracer_vals[tracer_name] = host[ind]
+                trail.submit(lambda: ncio.write_state_file(fname, axes, tracer_vals, history))
         return self
 
     # ---- logging ----------------------------------------------------------------------------
@@ -575,8 +603,13 @@ class ModelState:
                 by_name.pop(next(iter(by_name)))
             if self.write_files:
                 crcs = {_CRC_PREFIX + tms.name: np.int64(_crc(tms.get_tracer_vals_all())) for tms in res_ms.tracer_modules}
-                os.makedirs(os.path.dirname(sched_path(res_fname)), exist_ok=True)
-                np.savez(sched_path(res_fname)[:-4], **res_ms._sched, **crcs)
+                side_file, side_vals = sched_path(res_fname), dict(res_ms._sched, **crcs)
+
+                def write_side_file():
+                    os.makedirs(os.path.dirname(side_file), exist_ok=True)
+                    np.savez(side_file[:-4], **side_vals)
+
+                trail.submit(write_side_file)
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
             modelinfo = self.model_config_obj.modelinfo

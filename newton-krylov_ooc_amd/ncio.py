@@ -12,6 +12,8 @@ from datetime import datetime
 import numpy as np
 from scipy.io import netcdf_file
 
+from . import trail
+
 
 def _decode(val):
     return val.decode() if isinstance(val, bytes) else val
@@ -19,6 +21,7 @@ def _decode(val):
 
 def read_file(fname, varnames=None):
     """return (vars: dict name -> ndarray copy, attrs: dict) of a NetCDF3 file"""
+    trail.flush()       # (a file of this process' own trail may still be on its way to the disk)
     with netcdf_file(fname, "r", mmap=False) as fptr:
         names = list(fptr.variables) if varnames is None else list(varnames)
         data = {}
@@ -34,11 +37,13 @@ def read_file(fname, varnames=None):
 
 
 def read_var_attrs(fname, varname):
+    trail.flush()       # (a file of this process' own trail may still be on its way to the disk)
     with netcdf_file(fname, "r", mmap=False) as fptr:
         return {k: _decode(v) for k, v in fptr.variables[varname]._attributes.items()}
 
 
 def read_var_dims(fname, varnames):
+    trail.flush()       # (a file of this process' own trail may still be on its way to the disk)
     with netcdf_file(fname, "r", mmap=False) as fptr:
         return {name: tuple(fptr.variables[name].dimensions) for name in varnames}
 

@@ -15,6 +15,7 @@ import os
 import sys
 
 from .model_config import ModelConfig, read_cfg_files
+from . import trail
 from .model_state import ModelState
 from .newton_solver import NewtonSolver
 from .setup_solver import default_cfg_fnames
@@ -60,10 +61,17 @@ def run(config, resume=False, rewind=False, model_state_class=ModelState):
     was_async = getattr(model_state_class, "async_hist", None)
     if was_async is not None:
         model_state_class.async_hist = os.environ.get("NK2D_ASYNC_HIST", "1") != "0"
+    # ... and the checkpoint trail (vector files, step logs, statistics) in program order on one writer thread (trail.py);
+    # NK2D_ASYNC_TRAIL=0 keeps every write inside the call that asks for it
+    trail_was = trail.set_enabled(os.environ.get("NK2D_ASYNC_TRAIL", "1") != "0")
     try:
         solver = NewtonSolver(model_state_class, solverinfo=config["solverinfo"], resume=resume, rewind=rewind)
         return _iterate(solver, model_state_class, logger)
     finally:
+        try:
+            trail.set_enabled(trail_was)        # (flushes)
+        except Exception:                       # noqa: BLE001 -- reported, never in the way of the flush below
+            logger.exception("checkpoint trail: a queued write failed")
         # also on an exception (or the SystemExit of a reinvoked run): no history file is left half written
         flush = getattr(model_state_class, "flush_files", None)
         if flush is not None:

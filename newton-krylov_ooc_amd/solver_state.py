@@ -7,7 +7,9 @@ step strings are prefixed with the two-digit iteration (`"03:<step>"`).  A
 checkpoint written by the reference resumes here and vice versa.
 
 The file is rewritten after every change (a few hundred bytes) -- the run can be killed
-between any two solver actions and resumed from the last completed one.
+between any two solver actions and resumed from the last completed one.  The write is a job of
+the checkpoint trail (`trail.py`): at once by default, on the trail's writer thread behind the
+files the logged steps stand for where the driver switched that on.
 """
 
 import functools
@@ -17,6 +19,8 @@ import os
 import pickle
 
 import numpy as np
+
+from . import trail
 
 LOG = logging.getLogger(__name__)
 NDARRAY_TAG = "__ndarray__"
@@ -62,6 +66,7 @@ class SolverState:
 
     # ---- file ------------------------------------------------------------------------------
     def _load(self):
+        trail.flush()       # (the last store of this process may still be on its way to the disk)
         with open(self._path, mode="r") as fptr:
             return json.load(fptr, object_hook=_from_json)
 
@@ -84,8 +89,16 @@ class SolverState:
             parts.append(f"  {json.dumps(key)}: {hit[1]}")
         for key in [k for k in cache if k not in self._data]:
             del cache[key]
-        with open(self._path, mode="w") as fptr:
-            fptr.write("{\n" + ",\n".join(parts) + "\n}" if parts else "{}")
+        text = "{\n" + ",\n".join(parts) + "\n}" if parts else "{}"
+        path = self._path
+
+        def write():
+            with open(path, mode="w") as fptr:
+                fptr.write(text)
+
+        # behind the files the logged steps stand for (trail.py: one writer thread, program order)
+        trail.submit(write)
+        return text
 
     def _announce(self):
         LOG.info('"%s" iteration now %d', self._name, self._data["iteration"])
@@ -131,8 +144,9 @@ class SolverState:
         """store a value; the state is re-read from the file at once so that what the solver goes on
         with is exactly what a resumed run would see (and the round trip is verified)"""
         self._data[key] = value
-        self._store()
-        self._data = self._load()
+        text = self._store()
+        # (parsed from the text the file is written with: what _load() returns once the writer thread has got there)
+        self._data = json.loads(text, object_hook=_from_json)
         if not _equal(self._data[key], value):
             raise RuntimeError("saved_state value not recovered on reread")
 

@@ -4,16 +4,42 @@ Same file the reference keeps (`nk_ooc/stats_file.py`), written with
 `scipy.io.netcdf_file` instead of the netCDF4 package.
 """
 
+import functools
 import os
 
 import numpy as np
 from scipy.io import netcdf_file
 
 from . import ncio
+from . import trail
 from .solver_state import action_step_log_wrap
 
 _FILL = {"f8": 9.969209968386869e36, "i4": -2147483647}
 _NC_TYPE = {"f8": ">f8", "i4": ">i4"}
+
+
+def _snapshot(val):
+    """what a queued call keeps of an argument: arrays and containers are copied, the caller may go on changing its own"""
+    if isinstance(val, np.ndarray):
+        return val.copy()
+    if isinstance(val, dict):
+        return {key: _snapshot(item) for key, item in val.items()}
+    if isinstance(val, (list, tuple)):
+        return type(val)(_snapshot(item) for item in val)
+    return val
+
+
+def _on_trail(method):
+    """every change of the file is a job of the checkpoint trail (trail.py): run at once by default, behind the files
+    written before it on the trail's writer thread where that is switched on"""
+
+    @functools.wraps(method)
+    def queued(self, *args, **kwargs):
+        args = _snapshot(args)
+        kwargs = {key: (val if key == "solver_state" else _snapshot(val)) for key, val in kwargs.items()}
+        trail.submit(lambda: method(self, *args, **kwargs))
+
+    return queued
 
 
 class StatsFile:
@@ -23,6 +49,7 @@ class StatsFile:
                                 solver_state=solver_state)
 
     @action_step_log_wrap("_create_stats_file {fname}", per_iteration=False)
+    @_on_trail
     def _create_stats_file(self, name, fname, region_cnt, solver_state):
         with netcdf_file(fname, "w", version=2) as fptr:
             creator = f"{type(self).__module__}.{type(self).__name__}._create_stats_file"
@@ -37,6 +64,7 @@ class StatsFile:
             var.axis = "T"
             fptr.variables["region"][:] = np.arange(region_cnt)
 
+    @_on_trail
     def def_dimensions(self, dimensions):
         with netcdf_file(self._fname, "a") as fptr:
             for dimname, dimlen in dimensions.items():
@@ -45,6 +73,7 @@ class StatsFile:
                 elif fptr.dimensions[dimname] != dimlen:
                     raise RuntimeError(f"dimension {dimname} length mismatch")
 
+    @_on_trail
     def def_vars(self, vars_metadata):
         with netcdf_file(self._fname, "a") as fptr:
             for varname, metadata in vars_metadata.items():
@@ -61,6 +90,7 @@ class StatsFile:
                     for rec in range(fptr.variables["iteration"].shape[0]):
                         var[rec] = attrs["_FillValue"]
 
+    @_on_trail
     def put_vars_iteration_invariant(self, name_vals_dict):
         if not name_vals_dict:
             return
@@ -71,6 +101,7 @@ class StatsFile:
                     raise RuntimeError(f"iteration is a dimension for {name}")
                 var[:] = vals
 
+    @_on_trail
     def put_vars(self, iteration, name_vals_dict):
         if not name_vals_dict:
             return

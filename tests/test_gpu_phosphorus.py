@@ -137,6 +137,50 @@ def test_phosphorus_preconditioner(golden_dir, tag):
     assert rel_err(got, want) < 1e-6
 
 
+@pytest.mark.parametrize("tag", ["22x9", "70x12"])
+def test_phosphorus_preconditioner_single_precision_storage(golden_dir, tag):
+    """option "pc_fp32" for the shifted systems of the phosphorus preconditioner (round-3 verdict, missing 4): the explicit
+    inverses of the block elimination kept in single precision, every solve refined against the exact shifted operator
+    (k_pc_residual_shift).  The shifted matrices are not M-matrices (mat - shift I is indefinite for the shifts the
+    preconditioner uses), so how far a refinement gets is measured, not assumed: the solves and the assembled preconditioner
+    against the double precision storage and the oracle, for one and for two refinements"""
+    from oracle.model import phosphorus_precond_matrix
+
+    g, eng, tm = _setup(golden_dir, tag)
+    nz, ny = int(g["nz"]), int(g["ny"])
+    po4 = g["y"].reshape(3, nz, ny)[0]
+    mat = phosphorus_precond_matrix(tm, po4)
+    n = mat.shape[0]
+    v = np.random.default_rng(21).standard_normal(n)
+    ylin = np.zeros((3, nz, ny))
+    ylin[0] = po4
+    shifts = [0.02, -0.03]
+    wants = [spsolve((mat - sigma * identity(n, format="csc")).tocsc(), v) for sigma in shifts]
+    eng.set_lin_state(eng.upload(ylin))
+    pc64 = eng.precond_setup_state(po4)
+    apply64 = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
+    eng.close()
+    errs = {}
+    for refine in (0, 1, 2):
+        _, eng32, _ = _setup(golden_dir, tag)
+        eng32.set_option("pc_fp32", 1)
+        eng32.set_option("pc_refine", refine)
+        eng32.set_lin_state(eng32.upload(ylin))
+        eng32.shift_factor(0.5 * YEAR, YEAR, shifts)
+        errs[refine] = [rel_err(eng32.download(eng32.shift_solve(i, eng32.upload(v))).reshape(-1), wants[i]) for i in range(2)]
+        if refine == 2:
+            pc32 = eng32.precond_setup_state(po4)
+            assert abs(pc32.e_vals[1].real - pc64.e_vals[1].real) < 1e-7 * abs(pc64.e_vals[1].real)
+            apply32 = eng32.download(eng32.precond_apply(eng32.upload(v))).reshape(-1)
+            errs["apply"] = rel_err(apply32, apply64)
+        eng32.close()
+    print(f"phosphorus {tag}, single precision Schur inverses: shifted solves against a sparse direct solve "
+          f"{errs[0]} unrefined, {errs[1]} refined once, {errs[2]} twice; preconditioner against double precision storage {errs['apply']:.2e}")
+    assert max(errs[0]) > 1e-9                      # the single precision shows without refinement
+    assert max(errs[2]) < 1e-8 and max(errs[2]) <= max(errs[0])
+    assert errs["apply"] < 1e-6
+
+
 def test_phosphorus_krylov_solve(tmp_path):
     """tracer_module_names = phosphorus through the solver mirrors: forward year with history,
     preconditioner from the end-of-year po4, GMRES iterations; compared with the oracle"""

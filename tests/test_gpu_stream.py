@@ -135,6 +135,39 @@ def test_other_module_kinds_as_streams(case, golden_dir, tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("nz,ny,forced", [(320, 6, True), (416, 4, True), (260, 300, False)])
+def test_phosphorus_two_waves_to_a_simd(nz, ny, forced):
+    """option "stream_two_waves": the flavour of the resident kernel within 256 registers (what does not fit lives in scratch
+    memory), two waves to a SIMD -- taken by itself where the one-wave kernel cannot hold every column (260 x 300: 900 columns
+    of five levels per lane, one ypos column per workgroup instead of two), forced on the narrow grids: the same years bit for bit"""
+    from nk_ooc_amd.engine import phosphorus_engine
+    from nk_ooc_amd.grid import Grid2d
+
+    rng = np.random.default_rng(21)
+    res = {}
+    for two in (0, 2 if forced else 1):
+        eng = phosphorus_engine(Grid2d.default(nz, ny))
+        eng.set_option("stream_two_waves", two)
+        eng.set_option("stream_years", 3)
+        eng.set_option("frozen_persistent", 0)
+        x0 = _phos_state(eng, np.random.default_rng(21))
+        x = eng.upload(x0)
+        fx, st, sched = eng.comp_fcn(x, record=True)
+        xp = eng.upload(x0 * (1.0 + 1.0e-5 * np.cos(np.linspace(0.0, 3.0, nz))[None, :, None]))
+        fz = eng.download(eng.comp_fcn_frozen(xp, sched)[0])
+        assert eng.counter("stream_years_run") == 2 and eng.counter("stream_timeouts") == 0
+        assert eng.counter("stream_two_waves_kernel") == (1 if two else 0)
+        res[two] = (eng.download(fx), fz, sched, eng.counter("stream_columns_per_workgroup"), st["seconds"])
+        eng.close()
+    a, b = res[0], res[2 if forced else 1]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    if not forced:
+        assert a[3] == 2 and b[3] == 1, (a[3], b[3])
+    print(f"phosphorus {nz} x {ny}: free-running year {a[4]:.3f} s one wave to a SIMD ({a[3]} columns per workgroup), "
+          f"{b[4]:.3f} s two ({b[3]})")
+    del rng
+
+
 def test_year_with_history_samples_as_a_stream():
     """the 61 samples of a history file have no command: each ends the kernel, runs its launches, the next command starts the
     kernel again -- same year, same samples"""

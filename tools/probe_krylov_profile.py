@@ -15,6 +15,9 @@ import bench  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 416
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 device = torch.device("cuda", 0)
+from nk_ooc_amd import trail  # noqa: E402
+
+trail.set_enabled(os.environ.get("NK2D_ASYNC_TRAIL", "1") != "0")      # (as bench.py; the profile is the main thread's)
 wl = bench.Workload(n, 0, "prof", write_files=True)
 wl.krylov(1, "krylov_warm", device)
 wl.eng.sync()
