@@ -395,9 +395,9 @@ int nk2d_set_norm_hook_vec(nk2d_ctx* ctx, nk2d_norm_hook_vec_fn fn, void* user, 
    column -- the three stages and the complex system on waves of their own; 2 a pair of waves per column -- stages and
    real system on one, complex system on the other; same arguments, bit-identical results; -1, the default: chosen per
    context where all waves fit the chip at once -- teams up to 128 columns, pairs up to 512, nk2d_team_auto),
-   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "pc_fused" (1, default: a panel step of the
-   preconditioner's Gauss-Jordan inversions is one launch that inverts the pivot block while its tile is on its way; 0: the
-   two launches of rounds 1 - 3, the same bits), "sweep_wpb",
+   "pc_valu" (1: the round-1 preconditioner kernels, for A/B runs), "pc_fused" (1, default: from blocks of 1024 rows a panel
+   step of the preconditioner's Gauss-Jordan inversions is ONE launch whose first workgroup also inverts the NEXT step's
+   pivot block; 2: at every size; 0: the two launches of rounds 1 - 3 -- the same bits either way), "sweep_wpb",
    (closed experiments removed in round 4: "xcd_map", "prefactor" -- profiles/r03_prefactor holds their measurements),
    "frozen_err_check" (k: SciPy's error estimate on every k-th step of a frozen year, default 128; 0 off),
    "frozen_persistent" / "frozen_persistent_max_e" / "frozen_cache_gb" (the one-launch frozen year, see nk2d_get_counter),

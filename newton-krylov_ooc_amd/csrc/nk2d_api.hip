@@ -166,7 +166,7 @@ extern "C" int nk2d_set_option(nk2d_ctx* c, const char* name, double value) {
         return 0;
     }
     if (key == "pc_valu") { c->pc_valu = value != 0.0; return 0; }
-    if (key == "pc_fused") { c->pc_fused = value != 0.0; return 0; }
+    if (key == "pc_fused") { c->pc_fused = (int)value; return 0; }
     if (key == "pc_fp32") { c->pc_fp32 = value != 0.0; return 0; }
     if (key == "pc_refine") {
         if (!(value >= 0.0 && value <= 4.0)) return nk2d_fail(c, "nk2d_set_option: pc_refine must be 0 .. 4");
@@ -661,7 +661,7 @@ extern "C" int nk2d_create(const nk2d_desc* desc, nk2d_ctx** out) {
     c->dl_pool = nullptr;
     c->precond = nullptr;
     c->pc_valu = 0;
-    c->pc_fused = 0;
+    c->pc_fused = 1;
     c->pc_fp32 = 0;
     c->pc_refine = 1;
     c->st = nk2d_stats();

@@ -180,7 +180,7 @@ struct nk2d_ctx {
     double rho_c0, rho_dlog;   // first grid shift, log10 spacing
     // preconditioner (banded LU), see nk2d_precond.hip
     void* precond;
-    int pc_fused;  // 1 (default): a panel step of the Gauss-Jordan inversions is ONE launch (k_pc_gj_step); 0: two (k_pc_gj_rows + k_pc_gj_update_mfma), for A/B runs -- the same bits
+    int pc_fused;  // 1 (default): a panel step of the Gauss-Jordan inversions is ONE launch (k_pc_gj_step) for blocks of 1024 rows and more; 2: at every size; 0: two launches (k_pc_gj_rows + k_pc_gj_update_mfma) -- the same bits
     int pc_valu;   // 1: the round-1 preconditioner kernels (VALU rank-32 update, 8-byte mat-vec loads), for A/B runs
     int pc_fp32;   // 1: Schur inverses of the linear modules' preconditioner stored in single precision (option "pc_fp32")
     int pc_refine; // ... with this many refinement steps per apply against the exact operator (option "pc_refine", default 1)

@@ -47,6 +47,7 @@ struct Precond {
     double* X0;    // first solution [tc][nb][m]
     int fp32;
     double* BUF;   // Gauss-Jordan ping-pong [2][tc][m][m]
+    double* PINV;  // inverses of this and the next panel step's pivot block [2][tc][32][32] (k_pc_gj_step)
     double* ROWS;  // scaled pivot rows    [tc][NB][m]
     double* YV;    // forward-sweep vectors [tc][nb][m]
     double* XV;    // solution vectors      [tc][nb][m]
@@ -372,34 +373,87 @@ __global__ void __launch_bounds__(256) k_pc_gj_update_mfma(int m, int p0, int nb
             }
 }
 
-// One panel step of the Gauss-Jordan inversion in ONE launch (option "pc_fused", default): k_pc_gj_rows + k_pc_gj_update_mfma
-// fused.  The two-launch step is bound by what is sequential in it -- every workgroup of k_pc_gj_rows inverts the 32 x 32
-// pivot block by itself, 32 dependent eliminations with a barrier each: 13 of its 16.7 us at m = 1248 --, after which
-// k_pc_gj_update streams the matrix once more (15 us).  Here a workgroup owns a 64 x 64 tile of the result as in the
-// update: it REQUESTS everything it needs first -- its tile, its 64 x 32 piece of the pivot columns, its 32 x 64 piece of the
-// pivot rows, the pivot block --, inverts the pivot block while those loads are in flight, scales its piece of the pivot
-// rows itself (32 fused multiply-adds per entry, the order of k_pc_gj_rows) and applies the rank-32 update on the matrix
-// cores.  Same operations in the same order as the two launches: the same bits (tests/test_gpu_kernels.py).
-__global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ dst) {
-    __shared__ double ab[2][PC_NB][PC_NB + 1];   // pivot block, ping-pong: one barrier per pivot
-    __shared__ double sf[64][PC_NB + 1];         // src[i, pb]
-    __shared__ double sraw[PC_NB][64 + 1];       // src[pb, c]
-    __shared__ double sr[PC_NB][64 + 1];         // R[:, c]
+// One panel step of the Gauss-Jordan inversion in ONE launch, the pivot block's inverse computed one step AHEAD (option
+// "pc_fused").  The two-launch step is bound by what is sequential in it: every workgroup of k_pc_gj_rows inverts the
+// 32 x 32 pivot block by itself -- 32 dependent eliminations with a barrier each, 13 of its 16.7 us at m = 1248 -- before
+// k_pc_gj_update streams the matrix once more (15 us).  (Fusing the two as they are, every workgroup of the update
+// inverting the block while its tile is on its way, was measured first: 800 workgroups at two to a compute unit are two
+// rounds of 13 us, 0.53 -> 0.85 s for the set-up at 416 x 416.)  Here a workgroup owns a 64 x 64 tile of the result as in
+// the update; it reads the pivot block's inverse from `pinv_in`, scales its 32 x 64 piece of the pivot rows itself (32 fused
+// multiply-adds per entry, the order of k_pc_gj_rows) and applies the rank-32 update on the matrix cores.  The ONE
+// workgroup whose tile holds the NEXT pivot block -- a 32 x 32 quadrant of it, one wave's -- then inverts that block and
+// leaves the inverse in `pinv_out` for the next launch: the sequential part runs once per step, beside the streaming part
+// instead of ahead of it (that workgroup is the launch's first).  Same operations in the same order as the two launches:
+// the same bits (tests/test_gpu_krylov.py).
+__device__ __forceinline__ int pc_invert_block(double (*ab)[PC_NB][PC_NB + 1], double (&mine)[4], int r0, int cc, int nb) {
+    int cur = 0;
+    for (int pp = 0; pp < nb; ++pp) {
+        double (*a)[PC_NB + 1] = ab[cur];
+        const double piv = 1.0 / a[pp][pp];
+        const double prow = ((cc == pp) ? 1.0 : a[pp][cc]) * piv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 8 * q;
+            const double f = a[r][pp];
+            const double old = (cc == pp) ? 0.0 : mine[q];
+            mine[q] = (r == pp) ? prow : __builtin_fma(-f, prow, old);
+            ab[1 - cur][r][cc] = mine[q];
+        }
+        cur = 1 - cur;
+        __syncthreads();
+    }
+    return cur;
+}
+
+// inverse of the FIRST pivot block of every system (the later ones come out of k_pc_gj_step): pinv [nsys][32][32], identity
+// beyond nb
+__global__ void __launch_bounds__(256) k_pc_pivot_invert(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ pinv) {
+    __shared__ double ab[2][PC_NB][PC_NB + 1];
     const int tr = blockIdx.z;
     const size_t base = (size_t)tr * m * m;
-    const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tid = threadIdx.x;
-    const int wv = tid >> 6, l = tid & 63;
-    const int ib = (wv >> 1) * 32, jb = (wv & 1) * 32;
-    const int lr16 = l >> 4, lc16 = l & 15;
-    // ---- every request first
-    const int r0 = tid / PC_NB, cc = tid - r0 * PC_NB;
+    const int r0 = threadIdx.x / PC_NB, cc = threadIdx.x - r0 * PC_NB;
     double mine[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = r0 + 8 * q;
         mine[q] = (r < nb && cc < nb) ? src[base + (size_t)(p0 + r) * m + (p0 + cc)] : ((r == cc) ? 1.0 : 0.0);
+        ab[0][r][cc] = mine[q];
     }
+    __syncthreads();
+    pc_invert_block(ab, mine, r0, cc, nb);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pinv[((size_t)tr * PC_NB + r0 + 8 * q) * PC_NB + cc] = mine[q];
+}
+
+__global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const double* __restrict__ src, double* __restrict__ dst,
+                                                    const double* __restrict__ pinv_in, double* __restrict__ pinv_out) {
+    __shared__ double sr[PC_NB][64 + 1];         // R[:, c]
+    // src[i, pb] and src[pb, c]; once the update has read them, the next pivot block's ping-pong (its workgroup only)
+    __shared__ double lds_ops[64 * (PC_NB + 1) + PC_NB * (64 + 1)];
+    static_assert(2 * PC_NB * (PC_NB + 1) <= 64 * (PC_NB + 1) + PC_NB * (64 + 1), "the ping-pong must fit the operand staging");
+    double (*sf)[PC_NB + 1] = reinterpret_cast<double (*)[PC_NB + 1]>(lds_ops);
+    double (*sraw)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(lds_ops + 64 * (PC_NB + 1));
+    double (*ab)[PC_NB][PC_NB + 1] = reinterpret_cast<double (*)[PC_NB][PC_NB + 1]>(lds_ops);
+    const int tr = blockIdx.z;
+    const size_t base = (size_t)tr * m * m;
+    // the next pivot block: rows / columns p1 .. p1 + nb1 of the result, inside tile (tn, tn); its workgroup runs first
+    const int p1 = p0 + PC_NB;
+    const bool has_next = p1 < m;
+    const int nb1 = has_next ? min(PC_NB, m - p1) : 0;
+    const int tn = p1 / 64;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (has_next) {
+        if (bx == 0 && by == 0) { bx = tn; by = tn; }
+        else if (bx == tn && by == tn) { bx = 0; by = 0; }
+    }
+    const bool owns_next = has_next && bx == tn && by == tn;
+    const int i0 = by * 64, c0 = bx * 64;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int ib = (wv >> 1) * 32, jb = (wv & 1) * 32;
+    const int lr16 = l >> 4, lc16 = l & 15;
+    const int r0 = tid / PC_NB, cc = tid - r0 * PC_NB;
+    // ---- every request first
     double lf[8], lrw[8], tile[2][2][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -423,27 +477,6 @@ __global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const
                 const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
                 tile[ti][tj][reg] = (i < m && c < m) ? src[base + (size_t)i * m + c] : 0.0;
             }
-    // ---- the pivot block's inverse (k_pc_gj_rows' elimination), while the rest is on its way
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ab[0][r0 + 8 * q][cc] = mine[q];
-    __syncthreads();
-    int cur = 0;
-    for (int pp = 0; pp < nb; ++pp) {
-        double (*a)[PC_NB + 1] = ab[cur];
-        const double piv = 1.0 / a[pp][pp];
-        const double prow = ((cc == pp) ? 1.0 : a[pp][cc]) * piv;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = r0 + 8 * q;
-            const double f = a[r][pp];
-            const double old = (cc == pp) ? 0.0 : mine[q];
-            mine[q] = (r == pp) ? prow : __builtin_fma(-f, prow, old);
-            ab[1 - cur][r][cc] = mine[q];
-        }
-        cur = 1 - cur;
-        __syncthreads();
-    }
-    double (*pinv)[PC_NB + 1] = ab[cur];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int idx = tid + 256 * k;
@@ -451,22 +484,29 @@ __global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const
         sraw[idx / 64][idx % 64] = lrw[k];
     }
     __syncthreads();
-    // ---- this tile's piece of the scaled pivot rows: R[p][c] = sum_q Pinv[p][q] src[p0 + q][c], the pivot columns replaced by Pinv
+    // ---- this tile's piece of the scaled pivot rows: R[p][c] = sum_q Pinv[p][q] src[p0 + q][c], the pivot columns replaced by
+    // Pinv.  A thread owns column c0 + l of rows wave + 4 k: the rows of Pinv it needs are the same for the whole wave -- scalar
+    // operands, fetched through the scalar cache -- and an entry of the column is read from LDS once for its eight rows
+    {
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const double* __restrict__ pin = pinv_in + (size_t)tr * PC_NB * PC_NB;
+        double accr[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int idx = tid + 256 * k;
-        const int p = idx / 64, ccc = idx - p * 64;
-        const int c = c0 + ccc;
-        double val;
-        if (c >= p0 && c < p0 + nb) {
-            val = pinv[p][c - p0];
-        } else {
-            double acc = 0.0;
+        for (int k = 0; k < 8; ++k) accr[k] = 0.0;
 #pragma unroll
-            for (int q = 0; q < PC_NB; ++q) acc = __builtin_fma(pinv[p][q], sraw[q][ccc], acc);   // (zeros beyond nb)
-            val = acc;
+        for (int q = 0; q < PC_NB; ++q) {
+            const double sv = sraw[q][l];                                                   // (zeros beyond nb)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) accr[k] = __builtin_fma(pin[(wvu + 4 * k) * PC_NB + q], sv, accr[k]);
         }
-        sr[p][ccc] = (p < nb) ? val : 0.0;
+        const int c = c0 + l;
+        const bool pivot_col = c >= p0 && c < p0 + nb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = wvu + 4 * k;
+            const double val = pivot_col ? pin[p * PC_NB + (c - p0)] : accr[k];
+            sr[p][l] = (p < nb) ? val : 0.0;
+        }
     }
     __syncthreads();
     // ---- the rank-nb update (k_pc_gj_update_mfma)
@@ -485,23 +525,40 @@ __global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
+    // (the wave whose quadrant is the next pivot block keeps what it stores -- where the operands were staged, once every
+    // wave of the workgroup has read them)
+    const bool my_quadrant = owns_next && ib == p1 - i0 && jb == p1 - c0;
+    if (owns_next) __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int i = i0 + ib + 16 * ti + lr16 + 4 * reg, c = c0 + jb + 16 * tj + lc16;
-                if (i >= m || c >= m) continue;
-                double val;
-                if (i >= p0 && i < p0 + nb) {
-                    val = sr[i - p0][c - c0];
-                } else {
-                    const bool pivot_col = c >= p0 && c < p0 + nb;
-                    val = (pivot_col ? 0.0 : tile[ti][tj][reg]) - acc[ti][tj][reg];
+                const int il = 16 * ti + lr16 + 4 * reg, cl = 16 * tj + lc16;
+                const int i = i0 + ib + il, c = c0 + jb + cl;
+                double val = (il == cl) ? 1.0 : 0.0;        // (beyond the matrix: the identity the pivot block is padded with)
+                if (i < m && c < m) {
+                    if (i >= p0 && i < p0 + nb) {
+                        val = sr[i - p0][c - c0];
+                    } else {
+                        const bool pivot_col = c >= p0 && c < p0 + nb;
+                        val = (pivot_col ? 0.0 : tile[ti][tj][reg]) - acc[ti][tj][reg];
+                    }
+                    dst[base + (size_t)i * m + c] = val;
                 }
-                dst[base + (size_t)i * m + c] = val;
+                if (my_quadrant) ab[0][il][cl] = val;
             }
+    if (!owns_next) return;
+    // ---- the next step's pivot block, inverted here (k_pc_gj_rows' elimination, once instead of by every workgroup)
+    __syncthreads();
+    double mine[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mine[q] = ab[0][r0 + 8 * q][cc];
+    __syncthreads();
+    pc_invert_block(ab, mine, r0, cc, nb1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pinv_out[((size_t)tr * PC_NB + r0 + 8 * q) * PC_NB + cc] = mine[q];
 }
 
 // Dense mat-vec of the block substitution for even m: 16-byte loads, the whole row of a wave requested at once
@@ -787,7 +844,7 @@ PcDev make_pcdev(const nk2d_ctx* c, const Precond* pc) {
 void nk2d_precond_free(nk2d_ctx* c) {
     Precond* pc = (Precond*)c->precond;
     if (!pc) return;
-    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->ROWS, pc->PREV, pc->RV, pc->X0};
+    double* bufs[] = {pc->PJ, pc->SINV, pc->BUF, pc->YV, pc->XV, pc->ROWS, pc->PREV, pc->RV, pc->X0, pc->PINV};
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (pc->SINV32) (void)hipFree(pc->SINV32);
@@ -813,7 +870,7 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
         nk2d_precond_free(c);
         pc = new Precond();
         c->precond = pc;
-        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->ROWS = pc->PREV = pc->RV = pc->X0 = nullptr;
+        pc->PJ = pc->SINV = pc->BUF = pc->YV = pc->XV = pc->ROWS = pc->PREV = pc->RV = pc->X0 = pc->PINV = nullptr;
         pc->SINV32 = nullptr;
         pc->fp32 = want32;
         pc->cap_sys = std::max(nsys, mode == 1 ? 2 : nsys);
@@ -841,6 +898,7 @@ int precond_build(nk2d_ctx* c, int mode, int nt, int nslot, int nsys, const doub
             NK2D_CHECK(c, hipMalloc((void**)&pc->SINV, sizeof(double) * cap * pc->nb * mm));
         }
         NK2D_CHECK(c, hipMalloc((void**)&pc->BUF, sizeof(double) * 2 * cap * mm));
+        NK2D_CHECK(c, hipMalloc((void**)&pc->PINV, sizeof(double) * 2 * cap * PC_NB * PC_NB));
         NK2D_CHECK(c, hipMalloc((void**)&pc->ROWS, sizeof(double) * cap * PC_NB * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->YV, sizeof(double) * cap * pc->nb * pc->m));
         NK2D_CHECK(c, hipMalloc((void**)&pc->XV, sizeof(double) * cap * pc->nb * pc->m));
@@ -874,8 +932,17 @@ int precond_eliminate(nk2d_ctx* c) {
             const int nbk = std::min(PC_NB, m - p0);
             const double* from = pc->BUF + (size_t)src * nsys * mm;
             double* to = pc->BUF + (size_t)(1 - src) * nsys * mm;
-            if (c->pc_fused && !c->pc_valu) {
-                hipLaunchKernelGGL(k_pc_gj_step, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, nk2d_s(c), m, p0, nbk, from, to);
+            // (measured, set-up of iage: 416 x 416 0.529 -> 0.496 s, 208 x 208 0.088 -> 0.096 s, 104 x 104 0.022 -> 0.024 s --
+            // the launch is as long as its one workgroup that also inverts the next pivot block, 13 of ~ 22 us at every size;
+            // value 1 therefore takes it from m = 1024, 2 everywhere: profiles/r04_pc_fused_panel_step.log)
+            if (!c->pc_valu && (c->pc_fused >= 2 || (c->pc_fused == 1 && m >= 1024))) {
+                // (the first pivot block's inverse by a launch of its own, the others by the step before)
+                double* pin = pc->PINV + (size_t)((p0 / PC_NB) & 1) * nsys * PC_NB * PC_NB;
+                double* pout = pc->PINV + (size_t)(1 - ((p0 / PC_NB) & 1)) * nsys * PC_NB * PC_NB;
+                if (p0 == 0)
+                    hipLaunchKernelGGL(k_pc_pivot_invert, dim3(1, 1, nsys), dim3(256), 0, nk2d_s(c), m, 0, nbk, from, pin);
+                hipLaunchKernelGGL(k_pc_gj_step, dim3((m + 63) / 64, (m + 63) / 64, nsys), dim3(256), 0, nk2d_s(c), m, p0, nbk, from, to,
+                                   (const double*)pin, pout);
                 src = 1 - src;
                 continue;
             }

@@ -61,22 +61,23 @@ def test_precond_single_precision_storage(nz, ny, vv, kh):
 
 @pytest.mark.parametrize("nz,ny", [(26, 26), (70, 40), (130, 9), (416, 3)])
 def test_precond_one_launch_panel_steps_are_the_two_launches(nz, ny):
-    """option "pc_fused" (default): a panel step of the Gauss-Jordan inversions as ONE launch (k_pc_gj_step: the pivot block is
-    inverted while the tile is on its way) against the two launches of rounds 1 - 3 (k_pc_gj_rows + k_pc_gj_update_mfma) -- the
-    same operations in the same order, so the applies agree bit for bit; block sizes with a partial last panel included
-    (3 nz = 78, 210, 390, 1248 = 39 full panels), and against the oracle's stable form as before"""
+    """option "pc_fused": a panel step of the Gauss-Jordan inversions as ONE launch (k_pc_gj_step: the inverse of the pivot
+    block comes from the step before, whose first workgroup inverted it beside the streaming update) against the two launches
+    of rounds 1 - 3 (k_pc_gj_rows + k_pc_gj_update_mfma) -- the same operations in the same order, so the applies agree bit
+    for bit; block sizes with a partial last panel included (3 nz = 78, 210, 390; 1248 = 39 full panels, where the one
+    launch is the default), and against the oracle's stable form as before"""
     _, tm = oracle_iage(nz, ny)
     rng = np.random.default_rng(8)
     v = rng.standard_normal(2 * nz * ny)
     got = {}
-    for fused in (1, 0):
+    for fused in (2, 0):
         eng = make_engine(nz, ny)
         eng.set_option("pc_fused", fused)
         got[fused] = eng.download(eng.precond_apply(eng.upload(v))).reshape(-1)
         eng.close()
-    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(got[0], got[2])
     if nz * ny <= 3000:
-        assert rel_err(got[1], apply_precond_stable(tm, v)) < 1e-9
+        assert rel_err(got[2], apply_precond_stable(tm, v)) < 1e-9
 
 
 def test_precond_golden_within_reference_noise(golden_dir):
