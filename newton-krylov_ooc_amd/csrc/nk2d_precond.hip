@@ -453,7 +453,9 @@ __global__ void __launch_bounds__(256) k_pc_gj_step(int m, int p0, int nb, const
     const int ib = (wv >> 1) * 32, jb = (wv & 1) * 32;
     const int lr16 = l >> 4, lc16 = l & 15;
     const int r0 = tid / PC_NB, cc = tid - r0 * PC_NB;
-    // ---- every request first
+    // ---- every request first.  (Holding the other workgroups' requests back behind those of the one with the inversion ahead
+    // of it was tried -- s_sleep in units of 0.4 us: every unit is added to the launch, 416 x 416 0.491 -> 0.494 / 0.503 / 0.523 s
+    // for 2 / 4 / 6 units: the launch is as long as its streaming part, the inversion is hidden.)
     double lf[8], lrw[8], tile[2][2][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
