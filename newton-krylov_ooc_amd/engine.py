@@ -218,6 +218,10 @@ class ModuleEngine:
 
     def close(self):
         if self._handle is not None:
+            # (a vector file queued on the checkpoint trail's writer thread may still hold a download of this engine)
+            from . import trail
+
+            trail.drain()
             self._lib.nk2d_destroy(self._handle)
             self._handle = None
 

@@ -70,9 +70,18 @@ class Trail:
 
     def flush(self):
         """everything submitted so far is on disk; an exception a job raised is raised here"""
+        if threading.current_thread() is self._thread:
+            return
         if self._jobs is not None:
             self._jobs.join()
         self._raise_pending()
+
+    def drain(self):
+        """wait for the queue to empty WITHOUT taking delivery of a job's exception (it stays for the next submit / flush):
+        for whoever must not pull the rug from under a queued job -- an engine about to destroy its context"""
+        # (never from the writer thread itself -- an engine whose last reference goes away while a job runs is finalised there)
+        if self._jobs is not None and threading.current_thread() is not self._thread:
+            self._jobs.join()
 
     def pending(self):
         return 0 if self._jobs is None else self._jobs.unfinished_tasks
@@ -81,6 +90,7 @@ class Trail:
 TRAIL = Trail()
 submit = TRAIL.submit
 flush = TRAIL.flush
+drain = TRAIL.drain
 
 
 def set_enabled(flag):
