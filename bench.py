@@ -978,6 +978,7 @@ def main():
                 eng.sync()
                 if world > 1:
                     torch.distributed.barrier()
+                eng.profile_reset(1)      # (the bytes of the Newton commands of these years: roofline_free_year below)
                 t_f = time.perf_counter()
                 wl.krylov(2, "krylov_free", device)
                 eng.sync()
@@ -995,6 +996,23 @@ def main():
                 out["config"]["value_reference_semantic"] = 2.0 * world / t_f
                 out["roofline"]["value_reference_semantic"] = 2.0 * world / t_f
                 free_st = ModelState.last_stats[0]
+                free_totals = eng.profile_totals()
+                # the free-running year (k_stream: one resident kernel executes the host controller's launches as commands): the
+                # algorithmic bytes of EVERY Newton command the year executed -- the speculative ones that were dropped and the
+                # iterations of attempts that failed included, they ran -- over the seconds of the year
+                out["roofline_free_year"] = {
+                    "what": "algorithmic bytes of all Newton-iteration commands of one free-running perturbed year (command stream; "
+                            "dropped speculation and failed attempts included) / the seconds of that year (set-up, error-estimate and "
+                            "step-boundary commands in the time, their bytes not counted)",
+                    "bytes_per_year": free_totals["bytes"] / 2.0,
+                    "newton_commands_per_year": free_totals["launches"] / 2.0,
+                    "seconds_per_year": free_st["seconds"],
+                    "achieved": free_totals["bytes"] / 2.0 / free_st["seconds"] / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": free_totals["bytes"] / 2.0 / free_st["seconds"] / 1e9 / HBM_PEAK_GBS,
+                    "years_as_command_streams": eng.counter("stream_years_run") > 0,
+                }
+                out["roofline"]["free_year_frac"] = out["roofline_free_year"]["frac"]
                 out["jvp"]["free_running_products"] = {"jvps_per_s": 2.0 * world / t_f, "ms_per_jvp": 1000.0 * t_f / 2.0,
                                                        "krylov_iterations": 2,
                                                        "perturbed_year": {k: free_st[k] for k in year_keys},

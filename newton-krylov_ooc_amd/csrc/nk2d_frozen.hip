@@ -448,6 +448,38 @@ static hipError_t launch_frozen(nk2d_ctx* c, bool team, dim3 grid, DevP& P, Froz
     return forced ? launch_frozen_e<2, 0>(c, grid, P, A) : launch_frozen_e<0, 0>(c, grid, P, A);
 }
 
+// the slab of a schedule cache with room for `cap` rows from a thread of the library's own (hipMalloc of 120 GB: 0.03 - 3 s);
+// what the cache held before is given back by that thread first.  alloc_state 1 while it runs, 2 / 3 when done / refused
+static void frozen_alloc_in_thread(nk2d_frozen_cache* fc, int dev, size_t slab_bytes, size_t cap, double* old_slab, CacheRow* old_rows,
+                                   FrozenRow* old_frows) {
+    if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
+    fc->alloc_state.store(1);
+    fc->alloc_thread = std::thread([fc, dev, slab_bytes, cap, old_slab, old_rows, old_frows]() {
+        bool ok = hipSetDevice(dev) == hipSuccess;
+        if (old_slab) (void)hipFree(old_slab);
+        if (old_rows) (void)hipFree(old_rows);
+        if (old_frows) (void)hipFree(old_frows);
+        fc->alloc_slab = nullptr; fc->alloc_rows = nullptr; fc->alloc_frows = nullptr;
+        ok = ok && hipMalloc((void**)&fc->alloc_slab, slab_bytes) == hipSuccess;
+        ok = ok && hipMalloc((void**)&fc->alloc_rows, sizeof(CacheRow) * cap) == hipSuccess;
+        ok = ok && hipMalloc((void**)&fc->alloc_frows, sizeof(FrozenRow) * cap) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (fc->alloc_slab) (void)hipFree(fc->alloc_slab);
+            if (fc->alloc_rows) (void)hipFree(fc->alloc_rows);
+            if (fc->alloc_frows) (void)hipFree(fc->alloc_frows);
+        }
+        fc->alloc_cap = cap;
+        fc->alloc_state.store(ok ? 2 : 3);
+    });
+}
+
+// (Asking for that slab EARLIER -- at the end of the free-running year whose steps the products will repeat, so that it is
+// there when the first product comes -- was built and measured in round 4 and taken out again: in a fresh process the
+// hipMalloc of 120 GB holds the driver for ~ 4 s, and the preconditioner's set-up, which lies between F(x) and the first
+// product and allocates its 10 GB of inverses, waited behind it: set-up 0.50 -> 4.18 s, spin-up of iage 416 x 416 3.98 / 5.14 ->
+// 9.34 s (profiles/r04_prealloc_experiment.log).  Beside the first products, which allocate nothing, the same request costs
+// them 0.1 - 1.2 s in all.)
 int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vector<char>* err_rows) {
     const bool needs_state = c->kind == 1 || (c->kind == 2 && c->d.sms_nrec > 0 && c->d.sink_thres > 0.0);
     if (!c->frozen_persistent || needs_state || c->hist_n != 0 || c->norm_hook || n < 1) return 1;
@@ -532,27 +564,7 @@ int nk2d_frozen_persistent(nk2d_ctx* c, const double* sched, int64_t n, std::vec
             }
             if (in_thread) {
                 // (the new slab and tables come from the thread: launch by launch until they are there)
-                if (fc->alloc_thread.joinable()) fc->alloc_thread.join();
-                fc->alloc_state.store(1);
-                const int dev = c->dev;
-                fc->alloc_thread = std::thread([fc, dev, slab_bytes, cap, old_slab, old_rows, old_frows]() {
-                    bool ok = hipSetDevice(dev) == hipSuccess;
-                    if (old_slab) (void)hipFree(old_slab);
-                    if (old_rows) (void)hipFree(old_rows);
-                    if (old_frows) (void)hipFree(old_frows);
-                    fc->alloc_slab = nullptr; fc->alloc_rows = nullptr; fc->alloc_frows = nullptr;
-                    ok = ok && hipMalloc((void**)&fc->alloc_slab, slab_bytes) == hipSuccess;
-                    ok = ok && hipMalloc((void**)&fc->alloc_rows, sizeof(CacheRow) * cap) == hipSuccess;
-                    ok = ok && hipMalloc((void**)&fc->alloc_frows, sizeof(FrozenRow) * cap) == hipSuccess;
-                    if (!ok) {
-                        (void)hipGetLastError();
-                        if (fc->alloc_slab) (void)hipFree(fc->alloc_slab);
-                        if (fc->alloc_rows) (void)hipFree(fc->alloc_rows);
-                        if (fc->alloc_frows) (void)hipFree(fc->alloc_frows);
-                    }
-                    fc->alloc_cap = cap;
-                    fc->alloc_state.store(ok ? 2 : 3);
-                });
+                frozen_alloc_in_thread(fc, c->dev, slab_bytes, cap, old_slab, old_rows, old_frows);
                 return 1;
             }
             NK2D_CHECK(c, hipMalloc((void**)&fc->slab, slab_bytes));
