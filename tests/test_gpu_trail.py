@@ -130,3 +130,45 @@ def test_resume_reads_behind_the_writer_thread(tmp_path):
     finally:
         trail.set_enabled(was)
         ModelState.reset_class()
+
+
+@pytest.mark.parametrize("kill_after", ["w_raw_01.nc", "perturb_fcn_w_raw_02.nc", "krylov_res_00.nc"])
+def test_a_killed_solve_leaves_a_resumable_prefix(tmp_path, kill_after):
+    """the claim trail.py makes: a run that dies finds a PREFIX of the synchronous trail on disk -- every step the step log
+    names has its file, complete --, and `--resume` goes on from it to the result of the uninterrupted solve, bit for bit.
+    A solve in a process of its own is ended abruptly (os._exit at the first submit after a given file of the trail is on disk:
+    the main thread is ahead of the writer, what is queued is lost); a third process resumes (out-of-core contract of
+    /root/reference/nk_ooc/solver_state.py:13-157 and krylov_solver.py:85-181)"""
+    import subprocess
+    import sys
+
+    from nk_ooc_amd import ncio
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "trail_kill_worker.py")
+    full_dir, part_dir = str(tmp_path / "full"), str(tmp_path / "part")
+    os.makedirs(full_dir)
+    os.makedirs(part_dir)
+    done = subprocess.run([sys.executable, worker, full_dir, "full"], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    victim = subprocess.run([sys.executable, worker, part_dir, "victim", os.path.join(part_dir, "krylov_00", kill_after)],
+                            capture_output=True, text=True, timeout=300)
+    assert victim.returncode == 9, (victim.returncode, victim.stderr[-2000:])
+    assert not os.path.exists(os.path.join(part_dir, "result_victim.npy"))
+    # what is on disk: a step log that parses, and behind every step it names the file the step stands for
+    kdir = os.path.join(part_dir, "krylov_00")
+    state = json.load(open(os.path.join(kdir, "Krylov_state.json")))
+    assert state["iteration"] < 3
+    named = [entry.split(" complete for ")[1] for entry in state["step_log"] if " complete for " in entry]
+    assert named, state["step_log"]
+    for fname in named:
+        assert os.path.exists(fname), fname
+        data, _ = ncio.read_file(fname)
+        assert all(np.all(np.isfinite(val)) for val in data.values()), fname
+    assert os.path.exists(os.path.join(kdir, kill_after))
+    resumed = subprocess.run([sys.executable, worker, part_dir, "resume"], capture_output=True, text=True, timeout=300)
+    assert resumed.returncode == 0, resumed.stderr[-3000:]
+    assert "iteration 3" in resumed.stdout and "jvp mode frozen" in resumed.stdout, resumed.stdout
+    assert np.array_equal(np.load(os.path.join(part_dir, "result_resume.npy")), np.load(os.path.join(full_dir, "result_full.npy")))
+    h_full = json.load(open(os.path.join(full_dir, "krylov_00", "Krylov_state.json")))["h_mat"]
+    h_part = json.load(open(os.path.join(kdir, "Krylov_state.json")))["h_mat"]
+    assert h_full == h_part

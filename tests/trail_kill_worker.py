@@ -1,0 +1,58 @@
+"""worker of tests/test_gpu_trail.py::test_a_killed_solve_leaves_a_resumable_prefix: one Krylov solve of a 20 x 5 iage set-up with
+the checkpoint trail on its writer thread.
+    python trail_kill_worker.py WORKDIR full|victim|resume [KILL_AFTER_FILE]
+victim: the process ends abruptly (os._exit, no flush, no atexit) at the first submit that finds KILL_AFTER_FILE on disk -- the
+main thread is ahead of the writer by then, whatever is still queued is lost.  (From the main thread, between two library calls:
+no resident kernel is on the GPU at that moment.)"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nk_ooc_amd import trail  # noqa: E402
+from nk_ooc_amd.krylov_solver import KrylovSolver  # noqa: E402
+from nk_ooc_amd.model_config import ModelConfig  # noqa: E402
+from nk_ooc_amd.model_state import ModelState  # noqa: E402
+from nk_ooc_amd.setup_solver import gen_grid_vars_file, make_config  # noqa: E402
+
+workdir, mode = sys.argv[1], sys.argv[2]
+cfg = make_config(workdir, 20, 5, extra_solverinfo={"krylov_rel_tol": "0.0", "krylov_max_iter": "3"})
+if mode != "resume":
+    gen_grid_vars_file(cfg["modelinfo"])
+ModelState.reset_class()
+ModelState.model_config_obj = ModelConfig(cfg["modelinfo"])
+ModelState.write_files = True
+trail.set_enabled(True)
+if mode == "victim":
+    kill_after = sys.argv[3]
+    serve_one = trail.TRAIL.submit
+
+    def submit_and_watch(job):
+        if os.path.exists(kill_after):
+            os._exit(9)             # (whatever the writer thread still holds never reaches the disk)
+        serve_one(job)
+
+    trail.TRAIL.submit = submit_and_watch
+    trail.submit = submit_and_watch
+    import nk_ooc_amd.model_state as ms_mod
+    import nk_ooc_amd.solver_state as ss_mod
+    import nk_ooc_amd.stats_file as sf_mod
+
+    for mod in (ms_mod, ss_mod, sf_mod):
+        mod.trail.submit = submit_and_watch
+iterate_fname = os.path.join(workdir, "iterate_00.nc")
+fcn_fname = os.path.join(workdir, "fcn_00.nc")
+if mode == "resume":
+    iterate = ModelState(iterate_fname)
+    fcn = ModelState(fcn_fname)         # (with the schedule side file the first process left: products on frozen years again)
+else:
+    iterate = ModelState("gen_init_iterate").dump(iterate_fname, "worker")
+    fcn = iterate.comp_fcn(fcn_fname, None)
+    trail.flush()
+info = dict(cfg["solverinfo"], Krylov_workdir=os.path.join(workdir, "krylov_00"))
+solver = KrylovSolver(iterate, info, resume=(mode == "resume"), rewind=False, hist_fname=None)
+inc = solver.solve(os.path.join(workdir, "increment_00.nc"), fcn)
+np.save(os.path.join(workdir, f"result_{mode}.npy"), inc.tracer_modules[0].get_tracer_vals_all())
+print(f"{mode}: iteration {solver.get_iteration()}, jvp mode {ModelState.last_jvp_mode}", flush=True)
+ModelState.reset_class()
