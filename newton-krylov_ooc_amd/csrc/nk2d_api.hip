@@ -875,9 +875,15 @@ extern "C" int nk2d_vec_download_begin(nk2d_ctx* c, nk2d_vec v, void** ticket) {
         std::lock_guard<std::mutex> lk(c->dl_pool->m);
         c->dl_pool->all.push_back(t);
     }
-    NK2D_TRY(nk2d_k_unpack_state(c, (const double*)v, t->dev));
-    NK2D_CHECK(c, hipMemcpyAsync(t->host, t->dev, sizeof(double) * n, hipMemcpyDeviceToHost, nk2d_s(c)));
-    NK2D_CHECK(c, hipEventRecord(t->done, nk2d_s(c)));
+    int rc = nk2d_k_unpack_state(c, (const double*)v, t->dev);
+    if (rc == 0 && hipMemcpyAsync(t->host, t->dev, sizeof(double) * n, hipMemcpyDeviceToHost, nk2d_s(c)) != hipSuccess)
+        rc = nk2d_fail(c, "nk2d_vec_download_begin: the copy to the host could not be queued");
+    if (rc == 0 && hipEventRecord(t->done, nk2d_s(c)) != hipSuccess) rc = nk2d_fail(c, "nk2d_vec_download_begin: hipEventRecord failed");
+    if (rc != 0) {      // (the staging pair goes back to the pool: no ticket was handed out)
+        std::lock_guard<std::mutex> lk(c->dl_pool->m);
+        c->dl_pool->idle.push_back(t);
+        return rc;
+    }
     *ticket = t;
     return 0;
 }
