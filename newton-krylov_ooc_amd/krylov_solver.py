@@ -90,7 +90,29 @@ class KrylovSolver(SolverBase):
         return store[index]
 
     def _basis(self, index):
-        return self._resident(self._V, "basis", index)
+        try:
+            return self._resident(self._V, "basis", index)
+        except FileNotFoundError:
+            if index < 1:
+                raise
+            return self._rebuild_basis(index)
+
+    def _rebuild_basis(self, index):
+        """a resumed run whose predecessor died between `inc_iteration` and the dump of the next Arnoldi vector (the
+        reference's own window, krylov_solver.py:167-181: the vector is written only when the loop goes on): v_index again
+        from what IS on disk -- the preconditioned product `w_{index-1}` orthogonalised against v_0 .. v_{index-1} and
+        scaled by the last sub-diagonal entry of the saved Hessenberg matrix --, the same operations on the same values"""
+        logging.getLogger(__name__).warning("basis vector %d is not on disk: rebuilt from w_%02d and the saved Hessenberg matrix",
+                                            index, index - 1)
+        hess = self._solver_state.get_value_saved_state("h_mat")
+        if hess.shape[2] != index:
+            raise FileNotFoundError(f"{self._fname('basis', index)}: not on disk, and the saved Hessenberg matrix is not "
+                                    f"that of iteration {index - 1}")
+        vec = self._state_cls(self._fname("w", index - 1))
+        vec.mgs_against([self._basis(i) for i in range(index)])
+        vec /= hess[:, -1, -1, :]
+        self._V[index] = vec.dump(self._fname("basis", index), f"{self._tag}._rebuild_basis")
+        return self._V[index]
 
     def _prod(self, index):
         return self._resident(self._W, "w", index)

@@ -7,6 +7,7 @@ the same on-disk format (CDF-2, big-endian f8) is produced and read here with
 `scipy.io.netcdf_file(version=2)`, so files written by either side open in the other.
 """
 
+import os
 from datetime import datetime
 
 import numpy as np
@@ -76,7 +77,10 @@ def write_state_file(fname, axes, tracer_vals, history, extra_vars=None):
 
     axes: [depth_axis, ypos_axis]; tracer_vals: ordered dict name -> (nz, ny) array;
     extra_vars: optional dict name -> (dims, dtype, attrs, values)"""
-    with netcdf_file(fname, "w", version=2) as fptr:
+    # (under a temporary name, renamed when complete: a run killed inside the write leaves no half-written vector file under a
+    # name a resumed run would open)
+    partial = fname + ".partial"
+    with netcdf_file(partial, "w", version=2) as fptr:
         fptr.history = history
         for axis in axes:
             _define_axis(fptr, axis)
@@ -96,6 +100,7 @@ def write_state_file(fname, axes, tracer_vals, history, extra_vars=None):
         if extra_vars:
             for name, (_, _, _, vals) in extra_vars.items():
                 fptr.variables[name][:] = vals
+    os.replace(partial, fname)
 
 
 def write_vars_file(fname, dimensions, variables, history):

@@ -93,8 +93,12 @@ class SolverState:
         path = self._path
 
         def write():
-            with open(path, mode="w") as fptr:
+            # under a temporary name, then renamed: whoever opens the file -- a resumed run after this one was killed -- finds
+            # a complete step log, the one before or this one, never a truncated one (the rewrite-in-place of the reference,
+            # solver_state.py:60-72, leaves an empty file to a run killed inside it)
+            with open(path + ".partial", mode="w") as fptr:
                 fptr.write(text)
+            os.replace(path + ".partial", path)
 
         # behind the files the logged steps stand for (trail.py: one writer thread, program order)
         trail.submit(write)

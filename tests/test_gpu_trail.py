@@ -132,12 +132,13 @@ def test_resume_reads_behind_the_writer_thread(tmp_path):
         ModelState.reset_class()
 
 
-@pytest.mark.parametrize("kill_after", ["w_raw_01.nc", "perturb_fcn_w_raw_02.nc", "krylov_res_00.nc"])
+@pytest.mark.parametrize("kill_after", ["w_raw_01.nc", "perturb_fcn_w_raw_02.nc", "krylov_res_00.nc", "@iteration1"])
 def test_a_killed_solve_leaves_a_resumable_prefix(tmp_path, kill_after):
     """the claim trail.py makes: a run that dies finds a PREFIX of the synchronous trail on disk -- every step the step log
     names has its file, complete --, and `--resume` goes on from it to the result of the uninterrupted solve, bit for bit.
     A solve in a process of its own is ended abruptly (os._exit at the first submit after a given file of the trail is on disk:
-    the main thread is ahead of the writer, what is queued is lost); a third process resumes (out-of-core contract of
+    the main thread is ahead of the writer, what is queued is lost -- or, "@iteration1", right behind the step log's
+    `inc_iteration`, before the next Arnoldi vector is written: the reference's own window); a third process resumes (out-of-core contract of
     /root/reference/nk_ooc/solver_state.py:13-157 and krylov_solver.py:85-181)"""
     import subprocess
     import sys
@@ -164,7 +165,12 @@ def test_a_killed_solve_leaves_a_resumable_prefix(tmp_path, kill_after):
         assert os.path.exists(fname), fname
         data, _ = ncio.read_file(fname)
         assert all(np.all(np.isfinite(val)) for val in data.values()), fname
-    assert os.path.exists(os.path.join(kdir, kill_after))
+    if kill_after == "@iteration1":
+        # the reference's own window: the step log is at iteration 1, the Arnoldi vector of that iteration was never written
+        # (the resumed solver rebuilds it from w_00 and the saved Hessenberg matrix, KrylovSolver._rebuild_basis)
+        assert state["iteration"] == 1 and not os.path.exists(os.path.join(kdir, "basis_01.nc"))
+    else:
+        assert os.path.exists(os.path.join(kdir, kill_after))
     resumed = subprocess.run([sys.executable, worker, part_dir, "resume"], capture_output=True, text=True, timeout=300)
     assert resumed.returncode == 0, resumed.stderr[-3000:]
     assert "iteration 3" in resumed.stdout and "jvp mode frozen" in resumed.stdout, resumed.stdout

@@ -29,7 +29,17 @@ if mode == "victim":
     serve_one = trail.TRAIL.submit
 
     def submit_and_watch(job):
-        if os.path.exists(kill_after):
+        if kill_after.endswith("@iteration1"):
+            # the reference's own window (krylov_solver.py:167-181): the step log says iteration 1, the Arnoldi vector of that
+            # iteration is not written yet -- deterministically: everything queued reaches the disk, then the first submit
+            # behind the step log's `inc_iteration` (the dump of basis_01) is where the process dies
+            import json
+
+            trail.TRAIL.drain()
+            state_fname = os.path.join(os.path.dirname(kill_after), "Krylov_state.json")
+            if os.path.exists(state_fname) and json.load(open(state_fname))["iteration"] >= 1:
+                os._exit(9)
+        elif os.path.exists(kill_after):
             os._exit(9)             # (whatever the writer thread still holds never reaches the disk)
         serve_one(job)
 
