@@ -145,7 +145,9 @@ class KrylovSolver(SolverBase):
     def _hessenberg(self, j, ntm, nreg):
         hess = np.zeros((ntm, j + 2, j + 1, nreg))
         if j > 0:
-            hess[:, :-1, :-1, :] = self._solver_state.get_value_saved_state("h_mat")
+            # (the leading block: a resumed run whose predecessor died between saving this iteration's matrix and
+            # `inc_iteration` finds the matrix of iteration j already there -- its first j columns are those of iteration j - 1)
+            hess[:, :-1, :-1, :] = self._solver_state.get_value_saved_state("h_mat")[:, :j + 1, :j, :]
         return hess
 
     def _arnoldi_step(self, fcn, j):

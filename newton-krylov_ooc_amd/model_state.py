@@ -712,9 +712,13 @@ class ModelState:
             elif tms.eng.state_dependent_precond:
                 self._ensure_forced_precond(tms, precond_fname)
         res_ms = self._new([tms._like(tms.eng.precond_apply(tms.vec)) for tms in self.tracer_modules])
+        # the file first, then the step that names it.  (The reference logs the step and THEN dumps, model_state.py:266-270: a run
+        # killed in between has the step on record and no file, and its resumed run fails on the missing file.  The same files
+        # and the same step log come out; tests/test_gpu_trail.py kills a solve at this point among others.)
+        res_ms.dump(res_fname, f"{_class_name(self)}.apply_precond_jacobian")
         if solver_state is not None:
             solver_state.log_step(fcn_complete_step)
-        return res_ms.dump(res_fname, f"{_class_name(self)}.apply_precond_jacobian")
+        return res_ms
 
     def _third_end_indices(self, time_vals):
         """samples of the precond file closest to the end of each third of the year (forced.py:222-233)"""

@@ -14,7 +14,7 @@ reference functions, oracle/radau.py after scipy/integrate/_ivp/radau.py as driv
   (c) the free-running year of the default mode against the oracle's own free-running year (SciPy's decisions) at the
       reference's CI tolerance (atol 1e-6, rtol 1e-3).
 
-The oracle's nine years run side by side in spawned worker processes (they never touch the GPU) while the device side of
+The oracle's eleven years (nine of the deep grids, two of 52 x 52) run side by side in spawned worker processes (they never touch the GPU) while the device side of
 all three sizes is long done; the margins go to gpurun_out/r04_oracle_deep_margins.json (copied to profiles/)."""
 import json
 import multiprocessing as mp
@@ -28,6 +28,10 @@ from helpers import oracle_iage, oracle_year_job, rel_err
 pytestmark = pytest.mark.gpu
 
 SIZES = [(416, 8), (320, 8), (512, 6)]
+# ... and 52 x 52 (one level per lane; the one-launch year of a four-wave team per column): replay and product only -- its two
+# oracle years ride in the same pool of worker processes instead of taking 160 s of a test of their own
+# (tests/test_gpu_comp_fcn.py had them until round 4); the free-running 52 x 52 year is held against solve_ivp goldens there
+SIZES_REPLAY = [(52, 52)] + SIZES          # (its oracle years are the longest: queued first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -46,10 +50,10 @@ def deep():
     from nk_ooc_amd.grid import Grid2d
 
     ctx = mp.get_context("spawn")
-    pool = ctx.Pool(processes=min(9, max(2, (os.cpu_count() or 4) - 2)))
+    pool = ctx.Pool(processes=min(11, max(2, (os.cpu_count() or 4) - 2)))
     out = {}
     try:
-        for nz, ny in SIZES:
+        for nz, ny in SIZES_REPLAY:
             model, _ = oracle_iage(nz, ny)
             eng = iage_engine(Grid2d.default(nz, ny, 0.1, 1000.0))
             eng.set_option("device_ctl", 0)
@@ -80,8 +84,8 @@ def deep():
                 "w_launches": eng.download(w_l).reshape(-1), "sigma": float(sigma[0]),
                 "one_launch_years": years, "fallbacks": eng.frozen_fallbacks(), "rejected": stp["nrejected"],
                 "jobs": [pool.apply_async(oracle_year_job, ((nz, ny, x0.reshape(-1), rows),)),
-                         pool.apply_async(oracle_year_job, ((nz, ny, (x0 + float(sigma[0]) * v).reshape(-1), rows),)),
-                         pool.apply_async(oracle_year_job, ((nz, ny, x0.reshape(-1), None),))],
+                         pool.apply_async(oracle_year_job, ((nz, ny, (x0 + float(sigma[0]) * v).reshape(-1), rows),))]
+                        + ([pool.apply_async(oracle_year_job, ((nz, ny, x0.reshape(-1), None),))] if (nz, ny) in SIZES else []),
             }
             eng.close()
             out[(nz, ny)] = rec
@@ -105,7 +109,7 @@ def _record(key, value):
         json.dump(data, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("nz,ny", SIZES)
+@pytest.mark.parametrize("nz,ny", SIZES_REPLAY)
 def test_default_mode_steps_replayed_by_the_oracle(deep, nz, ny):
     rec = deep[(nz, ny)]
     f0 = rec["oracle"][0]
@@ -116,7 +120,7 @@ def test_default_mode_steps_replayed_by_the_oracle(deep, nz, ny):
     assert np.allclose(rec["fx"], f0, rtol=1e-6, atol=1e-8)
 
 
-@pytest.mark.parametrize("nz,ny", SIZES)
+@pytest.mark.parametrize("nz,ny", SIZES_REPLAY)
 def test_one_launch_frozen_product_against_the_oracle(deep, nz, ny):
     rec = deep[(nz, ny)]
     assert rec["one_launch_years"] >= 1, "the perturbed year of the product did not take the one-launch path"

@@ -1,9 +1,10 @@
 """worker of tests/test_gpu_trail.py::test_a_killed_solve_leaves_a_resumable_prefix: one Krylov solve of a 20 x 5 iage set-up with
 the checkpoint trail on its writer thread.
     python trail_kill_worker.py WORKDIR full|victim|resume [KILL_AFTER_FILE]
-victim: the process ends abruptly (os._exit, no flush, no atexit) at the first submit that finds KILL_AFTER_FILE on disk -- the
-main thread is ahead of the writer by then, whatever is still queued is lost.  (From the main thread, between two library calls:
-no resident kernel is on the GPU at that moment.)"""
+victim: the process ends abruptly (os._exit, no flush, no atexit) at the first submit behind KILL_AFTER_FILE -- the job it was
+about to queue and everything the solve would have written after it are lost.  (From the main thread, between two library
+calls: no resident kernel is on the GPU at that moment; the writer's queue is drained first so that every run dies at the
+same point of the trail.)"""
 import os
 import sys
 
@@ -29,18 +30,19 @@ if mode == "victim":
     serve_one = trail.TRAIL.submit
 
     def submit_and_watch(job):
+        # the same point of the trail in every run: what is queued reaches the disk first, then the first submit behind the
+        # chosen file (or step) is where the process dies -- with the job it was about to queue, and everything after it, lost
+        trail.TRAIL.drain()
         if kill_after.endswith("@iteration1"):
             # the reference's own window (krylov_solver.py:167-181): the step log says iteration 1, the Arnoldi vector of that
-            # iteration is not written yet -- deterministically: everything queued reaches the disk, then the first submit
-            # behind the step log's `inc_iteration` (the dump of basis_01) is where the process dies
+            # iteration is not written yet (the first submit behind the step log's `inc_iteration` is the dump of basis_01)
             import json
 
-            trail.TRAIL.drain()
             state_fname = os.path.join(os.path.dirname(kill_after), "Krylov_state.json")
             if os.path.exists(state_fname) and json.load(open(state_fname))["iteration"] >= 1:
                 os._exit(9)
         elif os.path.exists(kill_after):
-            os._exit(9)             # (whatever the writer thread still holds never reaches the disk)
+            os._exit(9)
         serve_one(job)
 
     trail.TRAIL.submit = submit_and_watch
